@@ -1,0 +1,231 @@
+/*
+ * thk.h — C-ABI of libthk: MI355X (gfx950) native single-token LLaMA decode
+ * behind TokenHawk's host API.
+ *
+ * This is the drop-in boundary.  It replaces everything the
+ * reference does below th_eval_gpu / cmdbuf_*: the WebGPU runtime calls
+ * (wgpuDeviceCreateBuffer, wgpuQueueWriteBuffer, wgpuCommandEncoder*,
+ * wgpuQueueSubmit, wgpuBufferMapAsync …) and the 16 WGSL kernels in th.cpp.
+ * Each entry point cites the reference interface it stands in for
+ * (/root/reference file:line).  INTEGRATION.md shows the C++ binding a
+ * TokenHawk maintainer would add on top of it.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.
+ *   - Every call returns 0 on success or a negative thk_status; the message is
+ *     available from thk_last_error(ctx).  No exceptions cross the boundary.
+ *     (The reference printf's + assert(false)'s and returns an empty
+ *     CommandBuffer, th.cpp:541-608; release builds then continue silently —
+ *     this ABI fails loudly instead.)
+ *   - A thk_ctx is bound to ONE HIP device and ONE stream.  All ops are
+ *     enqueued on that stream in call order and are asynchronous unless stated
+ *     otherwise; thk_sync() drains it.  Thread-compatible, not thread-safe.
+ *   - "dev" pointers are device addresses valid on the ctx's device (from
+ *     thk_buf_ptr, or any hipMalloc'd/torch-owned memory).
+ *   - Weights are GGML f16 row-major [R rows (out features), C cols (in
+ *     features)]; activations and KV caches are f32, as in the reference.
+ */
+#ifndef THK_H
+#define THK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden */
+
+#define THK_ABI_VERSION 1
+
+typedef struct thk_ctx thk_ctx;
+typedef struct thk_buf thk_buf;
+typedef struct thk_model thk_model;
+
+typedef enum thk_status {
+    THK_OK = 0,
+    THK_ERR_INVALID = -1,   /* bad argument / shape the kernels do not support */
+    THK_ERR_HIP = -2,       /* a HIP runtime call failed (message has hipGetErrorString) */
+    THK_ERR_OOM = -3,
+    THK_ERR_STATE = -4,     /* call order violated (e.g. eval before finalize) */
+    THK_ERR_NOTFOUND = -5,  /* unknown tensor name */
+    THK_ERR_RCCL = -6
+} thk_status;
+
+/* TensorType (th.hpp:20-34); values match the ggjt ftype field (loader :18-19). */
+typedef enum thk_dtype { THK_F32 = 0, THK_F16 = 1 } thk_dtype;
+
+/* lm-head combine mode: CORRECT sums both K halves for every
+ * logit; FAITHFUL reproduces cmdbuf_vector_reduce(...,8) (th-llama.cpp:262,
+ * th.cpp:3930-3943, :3992-3996), which skips 160 of every 4000 logits. */
+typedef enum thk_lmhead_mode { THK_LMHEAD_CORRECT = 0, THK_LMHEAD_FAITHFUL = 1 } thk_lmhead_mode;
+
+/* ---------------------------------------------------------------- context
+ * Replaces WGPUDevice + WGPUQueue (cli/main.cpp:72-105). */
+int thk_abi_version(void);
+int thk_ctx_create(int device_ordinal, thk_ctx** out);
+/* Bind to a caller-owned hipStream_t (e.g. torch's current stream). */
+int thk_ctx_create_on_stream(int device_ordinal, void* hip_stream, thk_ctx** out);
+int thk_ctx_destroy(thk_ctx* ctx);
+int thk_sync(thk_ctx* ctx);                       /* wgpuDeviceTick spin, th-llama.cpp:700-706 */
+const char* thk_last_error(thk_ctx* ctx);         /* never NULL */
+void* thk_ctx_stream(thk_ctx* ctx);               /* the hipStream_t in use */
+/* Device properties the host layer reports (name, CU count, HBM bytes). */
+int thk_ctx_device_info(thk_ctx* ctx, char* name, size_t name_cap, int* n_cu, size_t* hbm_bytes);
+
+/* ---------------------------------------------------------------- buffers
+ * Replace TensorBuffer's GPU half (th.hpp:83-148, th.cpp:150-229):
+ * wgpuDeviceCreateBuffer / wgpuQueueWriteBuffer / CopyBufferToBuffer / MapAsync. */
+int thk_buf_alloc(thk_ctx* ctx, size_t bytes, thk_buf** out);   /* zero-initialised */
+int thk_buf_free(thk_ctx* ctx, thk_buf* buf);
+void* thk_buf_ptr(thk_buf* buf);
+size_t thk_buf_size(thk_buf* buf);
+int thk_buf_upload(thk_ctx* ctx, thk_buf* dst, size_t dst_off, const void* host, size_t bytes);   /* blocking */
+int thk_buf_download(thk_ctx* ctx, thk_buf* src, size_t src_off, void* host, size_t bytes);       /* blocking */
+int thk_buf_copy(thk_ctx* ctx, thk_buf* dst, size_t dst_off, thk_buf* src, size_t src_off, size_t bytes);
+
+/* ---------------------------------------------------------------- operators
+ * One per starred kernel of SURVEY.md §2b, explicit dims instead of constants
+ * baked into generated WGSL.  All pointers are dev pointers. */
+
+/* cmdbuf_vector_mat_mul_trans (th.hpp:404-412, th.cpp:2839-3139):
+ * y[r] = sum_c x[c] * f16(W[r,c]), f32 accumulate.  Requires C % 256 == 0. */
+int thk_matvec_f16(thk_ctx* ctx, const void* W, int64_t R, int64_t C, const float* x, float* y);
+
+/* cmdbuf_rms_norm (th.hpp:328-333, th.cpp:1153-1296): in place per row,
+ * x /= sqrt(mean(x^2) + 1e-6).  Requires N % 256 == 0. */
+int thk_rms_norm(thk_ctx* ctx, float* x, int64_t rows, int64_t N);
+
+/* cmdbuf_row_element_multiply (th.hpp:335-341, th.cpp:1298-1449): x[r,c] *= gain[c]. */
+int thk_row_element_multiply(thk_ctx* ctx, float* x, const float* gain, int64_t rows, int64_t N);
+
+/* cmdbuf_RoPE (th.hpp:343-349, th.cpp:1452-1616): x viewed [n_tok,H,D], in place,
+ * position of token t is n_past + t.  Uses a host-built cos/sin table (libm f32). */
+int thk_rope(thk_ctx* ctx, float* x, int64_t n_tok, int64_t H, int64_t D, int64_t n_past);
+
+/* K/V append, wgpuCommandEncoderCopyBufferToBuffer at th-llama.cpp:332-339:
+ * kcache[pos,:,:] = k; vcache[pos,:,:] = v; caches f32 [n_ctx,H,D]. */
+int thk_kv_append(thk_ctx* ctx, float* kcache, float* vcache, const float* k, const float* v,
+                  int64_t pos, int64_t H, int64_t D);
+
+/* Decode attention for one query token over T cached positions.  Replaces the
+ * chain transpose x3 + mat_mul(QK^T, scale 1/sqrt(D)) + row_softmax + mat_mul(PV)
+ * + transpose (th-llama.cpp:341-397; kernels K8,K9,K10 th.cpp:863-1151, :396-861,
+ * :1865-2119).  Reads the caches in place ([n_ctx,H,D]); out is [H*D]. */
+int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache, const float* vcache,
+                    int64_t T, int64_t H, int64_t D, float* out);
+
+/* cmdbuf_row_softmax (th.hpp:359-365, th.cpp:1865-2119): in place, rows x N. */
+int thk_row_softmax(thk_ctx* ctx, float* x, int64_t rows, int64_t N);
+
+/* cmdbuf_addition (th.hpp:367-374), cmdbuf_silu (:396-401),
+ * cmdbuf_element_mult_in_place (:386-392). */
+int thk_add(thk_ctx* ctx, const float* a, const float* b, float* c, int64_t n);
+int thk_silu(thk_ctx* ctx, float* x, int64_t n);
+int thk_mul_inplace(thk_ctx* ctx, float* a, const float* b, int64_t n);
+
+/* lm-head: cmdbuf_vector_multi_mat_mul_split_trans + cmdbuf_vector_reduce
+ * (th.hpp:427-449, th.cpp:3516-4127) over the UNSPLIT [V,E] f16 matrix (the
+ * 256 MB WebGPU buffer limit that forced the split does not exist here). */
+int thk_lmhead_f16(thk_ctx* ctx, const void* W, int64_t V, int64_t E, const float* x, float* logits, int mode);
+
+/* Greedy pick, llama_sample_top_p_top_k temp<=0 branch (th-llama.cpp:826-838):
+ * smallest index attaining the max.  id_out is a dev int32. */
+int thk_argmax(thk_ctx* ctx, const float* logits, int64_t V, int32_t* id_out);
+
+/* Embedding row fetch (th-llama.cpp:577-584 + loader :185-195): x = f32(table[token,:]),
+ * table f16 [V,E] on device (the reference keeps an f32 copy on the host). */
+int thk_embed_f16(thk_ctx* ctx, const void* table, int64_t E, int32_t token, float* x);
+
+/* Prefill GEMM on MFMA (config C3; stands in for cmdbuf_mat_mul with f16 B and
+ * transposeB=1 on the batch path, th-llama.cpp:307-311): Y[M,R] = X[M,C] * W[R,C]^T,
+ * X,Y f32 row-major, W f16.  X is split into f16 hi+lo parts so the product keeps
+ * ~f32 activation precision.  Requires C % 32 == 0. */
+int thk_gemm_f16_prefill(thk_ctx* ctx, const void* W, int64_t R, int64_t C, const float* X, int64_t M, float* Y);
+
+/* Synthetic tensor generator (bit-identical to oracle/thk_oracle.c orc_synth_*):
+ * fills n elements of a dev buffer from (name, seed, sigma). */
+int thk_synth_f16(thk_ctx* ctx, const char* name, uint64_t seed, float sigma, int64_t n, void* out);
+int thk_synth_gain_f32(thk_ctx* ctx, const char* name, uint64_t seed, float sigma, int64_t n, float* out);
+
+/* ---------------------------------------------------------------- model
+ * Replaces LlamaModel's device state + th_eval_gpu (th-llama.hpp:100-179,
+ * th-llama.cpp:464-660) for a contiguous layer range (pipeline stage). */
+typedef struct thk_hparams {
+    int32_t n_vocab, n_embd, n_mult, n_head, n_layer, n_ctx;   /* th-llama.hpp:103-112 */
+} thk_hparams;
+
+/* Stage flags */
+#define THK_STAGE_EMBED 1u  /* this stage owns tok_embeddings and starts from a token id */
+#define THK_STAGE_HEAD  2u  /* this stage owns norm + output and produces logits / argmax */
+
+/* layers [layer_begin, layer_end) live on this ctx; n_seq independent sequences
+ * (each with its own KV caches and position) can be in flight. */
+int thk_model_create(thk_ctx* ctx, const thk_hparams* hp, int32_t layer_begin, int32_t layer_end,
+                     uint32_t stage_flags, int32_t n_seq, thk_model** out);
+int thk_model_destroy(thk_model* m);
+int32_t thk_model_n_ff(const thk_model* m);
+
+/* Called by the GGML loader in file order (replaces load_weights' TensorBuffer
+ * upload, th-llama-loader.cpp:121-265).  name is the ggjt tensor name; ne0 = columns
+ * (input features), ne1 = rows (1 for 1-D tensors).  Tensors of layers outside the
+ * stage (or embeddings/head on a stage without them) are accepted and ignored. */
+int thk_model_set_tensor(thk_model* m, const char* name, int dtype, int64_t ne0, int64_t ne1, const void* host);
+/* Device-side fill of every tensor this stage owns with the synthetic generator. */
+int thk_model_fill_synthetic(thk_model* m, uint64_t seed, float sigma);
+/* Allocates caches/working buffers, builds the RoPE table and captures the
+ * per-sequence decode hipGraphs (replaces post_load_init_model + build_pipelines_llama,
+ * th-llama-loader.cpp:330-435, th-llama.cpp:66-76). */
+int thk_model_finalize(thk_model* m);
+int thk_model_reset_kv(thk_model* m, int32_t seq);          /* web "[cmd] reset", web/main.cpp:164-170 */
+int thk_model_set_lmhead_mode(thk_model* m, int mode);      /* default THK_LMHEAD_CORRECT */
+
+/* th_eval_gpu for n_tokens tokens fed one at a time (kAllowedSubsequentBatchSize=1,
+ * th-llama.cpp:15,:202): runs this stage for each token at positions n_past..;
+ * blocking.  tokens may be NULL on a non-embed stage; hidden_inout (host f32[E],
+ * may be NULL) supplies the stage input when there is no embedding and receives the
+ * stage output; logits_out (host f32[V], may be NULL) receives the last token's logits
+ * on a head stage. */
+int thk_model_eval(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past,
+                   float* hidden_inout, float* logits_out);
+
+/* Batched prompt prefill (config C3) through the MFMA GEMM path: same contract as
+ * thk_model_eval with n_past == 0..; full-model stages only. */
+int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past,
+                      float* logits_out);
+
+/* Stream-ordered decode loop (no host round trip per token; what bench.py times).
+ * Device-resident per-sequence state: position, current token, generated-token log. */
+int thk_model_seq_set(thk_model* m, int32_t seq, int32_t token, int32_t pos);      /* async H2D */
+/* Enqueue one decode step of sequence `seq` on the stream (graph replay):
+ *   embed stage: x = emb[token[seq]]  else x = *hidden_in (dev f32[E])
+ *   head stage : logits -> greedy token; token[seq] = it; appended to the log
+ *   else       : *hidden_out (dev f32[E]) = stage output
+ *   advance != 0: pos[seq] += 1 afterwards (0 = keep re-evaluating the same slot,
+ *                 the fixed-T=512 benchmark protocol of BASELINE.md) */
+int thk_model_decode_step(thk_model* m, int32_t seq, int advance);
+void* thk_model_hidden_in(thk_model* m, int32_t seq);   /* dev f32[E], RCCL recv target */
+void* thk_model_hidden_out(thk_model* m, int32_t seq);  /* dev f32[E], RCCL send source */
+void* thk_model_token_dev(thk_model* m, int32_t seq);   /* dev int32: current/next token id */
+void* thk_model_logits_dev(thk_model* m, int32_t seq);  /* dev f32[V] (head stage) */
+/* Blocking: copy the generated-token log (up to cap ids) and position of `seq`. */
+int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out, int32_t cap, int32_t* n_out, int32_t* pos_out);
+
+/* Bytes of HBM this stage streams per decode step at context length T
+ * (weights + KV read + KV write + gains; SURVEY.md §8d formula) — used by bench.py. */
+int64_t thk_model_bytes_per_token(const thk_model* m, int32_t T);
+/* Time the last `n` kernels of interest: enables per-kernel hipEvent timing of one
+ * decode step outside graph replay; fills names/ms arrays (diagnostics for bench.py). */
+int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_entries, char (*names)[48], float* ms, int32_t* n_out);
+
+/* Tuning knobs (integers, by name) so the bench can sweep launch geometry without
+ * rebuilding: e.g. "gemv_blocks_per_cu", "attn_splits", "use_graph".  Must be set
+ * before thk_model_finalize.  Unknown names return THK_ERR_NOTFOUND. */
+int thk_set_tunable(thk_ctx* ctx, const char* name, int64_t value);
+int thk_get_tunable(thk_ctx* ctx, const char* name, int64_t* value);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* THK_H */

@@ -1,0 +1,873 @@
+// thk_capi.cpp — implementation of the C-ABI in include/thk.h on top of the HIP
+// runtime and the kernels in thk_kernels.hip / thk_prefill.hip.
+//
+// Replaces the reference's WebGPU dispatch layer: TensorBuffer's GPU half
+// (th.cpp:150-229), the 16 cmdbuf_* encoders (th.cpp:617-4351) and th_eval_gpu
+// (th-llama.cpp:464-660).  One decode step = ONE hipGraph replay (embed, 5 fused
+// kernels per layer, lm-head + greedy pick) instead of 773 dispatches, 129 copies and
+// a blocking map-read per token.
+#include "../../include/thk.h"
+#include "thk_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace thk;
+
+// ---------------------------------------------------------------- objects
+struct thk_buf {
+    void* ptr = nullptr;
+    size_t size = 0;
+};
+
+struct thk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err = "";
+    std::map<std::string, int64_t> tun;
+    int n_cu = 256;
+    size_t hbm_bytes = 0;
+    std::string dev_name;
+    void* scratch = nullptr;        // operator-API scratch (attention partials, arg-max keys)
+    size_t scratch_bytes = 0;
+    float* rope_tab = nullptr;      // operator-API RoPE table
+    size_t rope_tab_floats = 0;
+};
+
+struct LayerW {
+    uint16_t *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
+    float *attention_norm = nullptr, *ffn_norm = nullptr;
+};
+
+struct SeqBuf {
+    float* kv = nullptr;             // [n_local_layers][2][n_ctx*E] f32
+    SeqState* st = nullptr;          // device
+    int32_t* gen_log = nullptr;      // device, kGenLogCap
+    float* hidden_in = nullptr;      // device f32[E]
+    float* hidden_out = nullptr;     // device f32[E]
+    float* logits = nullptr;         // device f32[V] (head stage)
+    int32_t* advance = nullptr;      // device flag read by the finishing kernel
+    int advance_host = -1;           // last value written
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+static const int kGenLogCap = 4096;
+
+struct thk_model {
+    thk_ctx* ctx = nullptr;
+    thk_hparams hp{};
+    int n_ff = 0, l0 = 0, l1 = 0, n_seq = 1;
+    uint32_t flags = 0;
+    int lm_mode = THK_LMHEAD_CORRECT;
+    bool finalized = false;
+    std::vector<LayerW> layers;       // local layers
+    uint16_t* tok_embeddings = nullptr;
+    float* norm = nullptr;
+    uint16_t* output = nullptr;
+    std::vector<SeqBuf> seqs;
+    // working buffers shared by all sequences (steps run back to back on one stream)
+    float *x = nullptr, *q = nullptr, *u = nullptr, *attn_out = nullptr, *part_o = nullptr, *part_ml = nullptr;
+    unsigned long long* block_best = nullptr;
+    float* rope_tab = nullptr;        // [n_ctx][D/2][2]
+    // launch geometry resolved at finalize
+    int nsplit = 4, tc = 128, nt = 1, use_graph = 1;
+    int var_qkv = 0, var_wo = 0, var_w13 = 0, var_w2 = 0, var_head = 0;
+    int grid_qkv = 0, grid_wo = 0, grid_w13 = 0, grid_w2 = 0, grid_head = 0;
+    void* prefill_ws = nullptr; size_t prefill_ws_bytes = 0;
+};
+
+// ---------------------------------------------------------------- helpers
+static int fail(thk_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+#define HIPCHK(ctx, call)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) return fail((ctx), THK_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define REQUIRE(ctx, cond, ...) do { if (!(cond)) return fail((ctx), THK_ERR_INVALID, __VA_ARGS__); } while (0)
+
+static int64_t tun(thk_ctx* ctx, const char* name) {
+    auto it = ctx->tun.find(name);
+    return it == ctx->tun.end() ? 0 : it->second;
+}
+static void default_tunables(thk_ctx* ctx) {
+    ctx->tun["gemv_blocks_per_cu"] = 4;   // resident 256-thread workgroups per CU for the streaming mat-vecs
+    ctx->tun["gemv_bpc_qkv"] = 0;         // per-kernel override (0 = gemv_blocks_per_cu)
+    ctx->tun["gemv_bpc_wo"] = 0;
+    ctx->tun["gemv_bpc_w13"] = 0;
+    ctx->tun["gemv_bpc_w2"] = 0;
+    ctx->tun["gemv_bpc_head"] = 0;
+    ctx->tun["gemv_variant_qkv"] = 0;     // (rows/iteration, slots/batch) variant, see gemv_variant()
+    ctx->tun["gemv_variant_wo"] = 0;
+    ctx->tun["gemv_variant_w13"] = 0;
+    ctx->tun["gemv_variant_w2"] = 0;
+    ctx->tun["gemv_variant_head"] = 0;
+    ctx->tun["gemv_nt"] = 1;              // non-temporal weight loads
+    ctx->tun["attn_splits"] = 4;          // context splits per head (1,2,4,8)
+    ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
+}
+static int grid_for(thk_ctx* ctx, const char* specific, int n_groups) {
+    int64_t bpc = tun(ctx, specific);
+    if (bpc <= 0) bpc = tun(ctx, "gemv_blocks_per_cu");
+    if (bpc <= 0) bpc = 4;
+    int64_t g = (int64_t)ctx->n_cu * bpc;
+    const int64_t need = (n_groups + kWaves - 1) / kWaves;
+    if (g > need) g = need;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+static int ensure_scratch(thk_ctx* ctx, size_t bytes) {
+    if (ctx->scratch_bytes >= bytes) return THK_OK;
+    if (ctx->scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
+    HIPCHK(ctx, hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return THK_OK;
+}
+// RoPE table for positions [p0, p0+n): (cos, sin) of p * 10000^(-j/D), j even — the f32
+// libm evaluation order of oracle orc_rope_angles (th.cpp:1476-1484).
+static void build_rope_table(std::vector<float>& tab, int D, int p0, int n) {
+    const int half = D / 2;
+    tab.resize((size_t)n * half * 2);
+    for (int p = 0; p < n; ++p)
+        for (int jp = 0; jp < half; ++jp) {
+            const float theta = powf(10000.0f, (-(float)(2 * jp)) / (float)D);
+            const float pf = (float)(p0 + p);
+            tab[((size_t)p * half + jp) * 2] = cosf(pf * theta);
+            tab[((size_t)p * half + jp) * 2 + 1] = sinf(pf * theta);
+        }
+}
+static uint64_t splitmix64_h(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+static uint64_t synth_key(const char* name, uint64_t seed) {
+    uint64_t h = 0xCBF29CE484222325ull;
+    for (const unsigned char* p = (const unsigned char*)name; *p; ++p) { h ^= *p; h *= 0x100000001B3ull; }
+    return h ^ splitmix64_h(seed);
+}
+static float synth_scale(float sigma) { return (float)((double)sigma / 37837.2275); }
+
+// ---------------------------------------------------------------- context
+extern "C" int thk_abi_version(void) { return THK_ABI_VERSION; }
+
+static int ctx_create_common(int device, hipStream_t stream, bool own, thk_ctx** out) {
+    if (!out) return THK_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return THK_ERR_HIP;
+    if (device < 0 || device >= count) return THK_ERR_INVALID;
+    thk_ctx* ctx = new thk_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return THK_ERR_HIP; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        ctx->hbm_bytes = prop.totalGlobalMem;
+        ctx->dev_name = prop.name;
+    }
+    if (own) {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return THK_ERR_HIP; }
+        ctx->own_stream = true;
+    } else {
+        ctx->stream = stream;
+    }
+    default_tunables(ctx);
+    *out = ctx;
+    return THK_OK;
+}
+extern "C" int thk_ctx_create(int device_ordinal, thk_ctx** out) { return ctx_create_common(device_ordinal, nullptr, true, out); }
+extern "C" int thk_ctx_create_on_stream(int device_ordinal, void* hip_stream, thk_ctx** out) {
+    return ctx_create_common(device_ordinal, (hipStream_t)hip_stream, false, out);
+}
+extern "C" int thk_ctx_destroy(thk_ctx* ctx) {
+    if (!ctx) return THK_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->rope_tab) hipFree(ctx->rope_tab);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return THK_OK;
+}
+extern "C" int thk_sync(thk_ctx* ctx) {
+    if (!ctx) return THK_ERR_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return THK_OK;
+}
+extern "C" const char* thk_last_error(thk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" void* thk_ctx_stream(thk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" int thk_ctx_device_info(thk_ctx* ctx, char* name, size_t name_cap, int* n_cu, size_t* hbm_bytes) {
+    if (!ctx) return THK_ERR_INVALID;
+    if (name && name_cap) { strncpy(name, ctx->dev_name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
+    if (n_cu) *n_cu = ctx->n_cu;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return THK_OK;
+}
+extern "C" int thk_set_tunable(thk_ctx* ctx, const char* name, int64_t value) {
+    if (!ctx || !name) return THK_ERR_INVALID;
+    auto it = ctx->tun.find(name);
+    if (it == ctx->tun.end()) return fail(ctx, THK_ERR_NOTFOUND, "unknown tunable '%s'", name);
+    it->second = value;
+    return THK_OK;
+}
+extern "C" int thk_get_tunable(thk_ctx* ctx, const char* name, int64_t* value) {
+    if (!ctx || !name || !value) return THK_ERR_INVALID;
+    auto it = ctx->tun.find(name);
+    if (it == ctx->tun.end()) return fail(ctx, THK_ERR_NOTFOUND, "unknown tunable '%s'", name);
+    *value = it->second;
+    return THK_OK;
+}
+
+// ---------------------------------------------------------------- buffers
+extern "C" int thk_buf_alloc(thk_ctx* ctx, size_t bytes, thk_buf** out) {
+    if (!ctx || !out) return THK_ERR_INVALID;
+    *out = nullptr;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    thk_buf* b = new thk_buf();
+    b->size = bytes;
+    hipError_t e = hipMalloc(&b->ptr, bytes ? bytes : 1);
+    if (e != hipSuccess) { delete b; return fail(ctx, e == hipErrorOutOfMemory ? THK_ERR_OOM : THK_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    e = hipMemsetAsync(b->ptr, 0, bytes ? bytes : 1, ctx->stream);
+    if (e != hipSuccess) { hipFree(b->ptr); delete b; return fail(ctx, THK_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)); }
+    *out = b;
+    return THK_OK;
+}
+extern "C" int thk_buf_free(thk_ctx* ctx, thk_buf* buf) {
+    if (!buf) return THK_OK;
+    if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+    if (buf->ptr) hipFree(buf->ptr);
+    delete buf;
+    return THK_OK;
+}
+extern "C" void* thk_buf_ptr(thk_buf* buf) { return buf ? buf->ptr : nullptr; }
+extern "C" size_t thk_buf_size(thk_buf* buf) { return buf ? buf->size : 0; }
+extern "C" int thk_buf_upload(thk_ctx* ctx, thk_buf* dst, size_t dst_off, const void* host, size_t bytes) {
+    if (!ctx || !dst || (!host && bytes)) return THK_ERR_INVALID;
+    REQUIRE(ctx, dst_off + bytes <= dst->size, "upload of %zu bytes at %zu exceeds buffer of %zu", bytes, dst_off, dst->size);
+    HIPCHK(ctx, hipMemcpyAsync((char*)dst->ptr + dst_off, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_buf_download(thk_ctx* ctx, thk_buf* src, size_t src_off, void* host, size_t bytes) {
+    if (!ctx || !src || (!host && bytes)) return THK_ERR_INVALID;
+    REQUIRE(ctx, src_off + bytes <= src->size, "download of %zu bytes at %zu exceeds buffer of %zu", bytes, src_off, src->size);
+    HIPCHK(ctx, hipMemcpyAsync(host, (const char*)src->ptr + src_off, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_buf_copy(thk_ctx* ctx, thk_buf* dst, size_t dst_off, thk_buf* src, size_t src_off, size_t bytes) {
+    if (!ctx || !dst || !src) return THK_ERR_INVALID;
+    REQUIRE(ctx, dst_off + bytes <= dst->size && src_off + bytes <= src->size, "copy range out of bounds");
+    HIPCHK(ctx, hipMemcpyAsync((char*)dst->ptr + dst_off, (const char*)src->ptr + src_off, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return THK_OK;
+}
+
+// ---------------------------------------------------------------- operators
+static int gemv_simple(thk_ctx* ctx, int pro, int epi, const char* var_name, const char* bpc_name, GemvArgs& a, int rows) {
+    const int nru = (int)tun(ctx, var_name);
+    const int NR = gemv_rows_per_group(a.C, epi, nru);
+    a.n_groups = (rows + NR - 1) / NR;
+    const int grid = grid_for(ctx, bpc_name, a.n_groups);
+    HIPCHK(ctx, launch_gemv(pro, epi, nru, a, grid, tun(ctx, "gemv_nt") != 0, ctx->stream));
+    return grid;
+}
+
+extern "C" int thk_matvec_f16(thk_ctx* ctx, const void* W, int64_t R, int64_t C, const float* x, float* y) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, W && x && y && R > 0, "thk_matvec_f16: null pointer or empty matrix");
+    REQUIRE(ctx, C >= 256 && C % 256 == 0, "thk_matvec_f16: C=%lld must be a multiple of 256 (th.cpp:2996-3006)", (long long)C);
+    REQUIRE(ctx, C <= 32768 && R <= 0x7FFFFFFF, "thk_matvec_f16: shape too large");
+    GemvArgs a{}; a.W[0] = (const uint16_t*)W; a.R = (int)R; a.C = (int)C; a.x = x; a.y = y;
+    const int rc = gemv_simple(ctx, GEMV_PRO_COPY, GEMV_EPI_STORE, C > 8192 ? "gemv_variant_w2" : "gemv_variant_wo", "gemv_blocks_per_cu", a, (int)R);
+    return rc < 0 ? rc : THK_OK;
+}
+extern "C" int thk_rms_norm(thk_ctx* ctx, float* x, int64_t rows, int64_t N) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, x && rows > 0 && N > 0, "thk_rms_norm: bad arguments");
+    REQUIRE(ctx, N % 256 == 0, "thk_rms_norm: N=%lld must be a multiple of 256 (th.cpp:1155)", (long long)N);
+    HIPCHK(ctx, launch_rms_norm(x, (int)rows, (int)N, ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_row_element_multiply(thk_ctx* ctx, float* x, const float* gain, int64_t rows, int64_t N) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, x && gain && rows > 0 && N > 0, "thk_row_element_multiply: bad arguments");
+    HIPCHK(ctx, launch_row_mul(x, gain, (int)rows, (int)N, ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_rope(thk_ctx* ctx, float* x, int64_t n_tok, int64_t H, int64_t D, int64_t n_past) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, x && n_tok > 0 && H > 0 && D > 0 && D % 2 == 0 && n_past >= 0, "thk_rope: bad arguments");
+    std::vector<float> tab;
+    build_rope_table(tab, (int)D, (int)n_past, (int)n_tok);
+    if (ctx->rope_tab_floats < tab.size()) {
+        if (ctx->rope_tab) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->rope_tab)); ctx->rope_tab = nullptr; }
+        HIPCHK(ctx, hipMalloc((void**)&ctx->rope_tab, tab.size() * 4));
+        ctx->rope_tab_floats = tab.size();
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->rope_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // tab is a stack-lifetime host buffer
+    HIPCHK(ctx, launch_rope(x, ctx->rope_tab, (int)n_tok, (int)H, (int)D, 0, ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_kv_append(thk_ctx* ctx, float* kcache, float* vcache, const float* k, const float* v, int64_t pos, int64_t H, int64_t D) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, kcache && vcache && k && v && pos >= 0 && H > 0 && D > 0, "thk_kv_append: bad arguments");
+    HIPCHK(ctx, launch_kv_append(kcache, vcache, k, v, (int)pos, (int)(H * D), ctx->stream));
+    return THK_OK;
+}
+static int valid_head_dim(int64_t D) { return D == 64 || D == 128 || D == 256; }
+static int valid_splits(int64_t s) { return s == 1 || s == 2 || s == 4 || s == 8; }
+
+extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache, const float* vcache, int64_t T, int64_t H, int64_t D, float* out) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, q && kcache && vcache && out && T > 0 && H > 0, "thk_attn_decode: bad arguments");
+    REQUIRE(ctx, valid_head_dim(D), "thk_attn_decode: head dim %lld not in {64,128,256}", (long long)D);
+    int nsplit = (int)tun(ctx, "attn_splits");
+    REQUIRE(ctx, valid_splits(nsplit), "attn_splits must be 1, 2, 4 or 8");
+    const size_t need = (size_t)H * nsplit * (D + 2) * 4;
+    int rc = ensure_scratch(ctx, need < (1u << 20) ? (1u << 20) : need);
+    if (rc != THK_OK) return rc;
+    AttnArgs a{};
+    a.q = q; a.kcache = kcache; a.vcache = vcache; a.pos_ptr = nullptr; a.pos_val = (int)T - 1;
+    a.H = (int)H; a.D = (int)D; a.nsplit = nsplit; a.tc = (int)((T + nsplit - 1) / nsplit);
+    a.scale = 1.0f / sqrtf((float)D);
+    a.part_o = (float*)ctx->scratch; a.part_ml = a.part_o + (size_t)H * nsplit * D;
+    a.out = nsplit == 1 ? out : nullptr;
+    HIPCHK(ctx, launch_attn_decode(a, ctx->stream));
+    if (nsplit > 1) HIPCHK(ctx, launch_attn_combine(a.part_o, a.part_ml, out, (int)H, (int)D, nsplit, ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_row_softmax(thk_ctx* ctx, float* x, int64_t rows, int64_t N) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, x && rows > 0 && N > 0, "thk_row_softmax: bad arguments");
+    HIPCHK(ctx, launch_row_softmax(x, (int)rows, (int)N, ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_add(thk_ctx* ctx, const float* a, const float* b, float* c, int64_t n) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, a && b && c && n > 0, "thk_add: bad arguments");
+    HIPCHK(ctx, launch_add(a, b, c, (size_t)n, ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_silu(thk_ctx* ctx, float* x, int64_t n) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, x && n > 0, "thk_silu: bad arguments");
+    HIPCHK(ctx, launch_silu(x, (size_t)n, ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_mul_inplace(thk_ctx* ctx, float* a, const float* b, int64_t n) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, a && b && n > 0, "thk_mul_inplace: bad arguments");
+    HIPCHK(ctx, launch_mul(a, b, (size_t)n, ctx->stream));
+    return THK_OK;
+}
+static void q1_constants(int V, int* split, int* cov) {   // th.cpp:3990-3996 with numSplits = 8 (th-llama.cpp:262)
+    int s = V / 8; if (s < 1) s = 1;
+    int kTile = s / 256; if (kTile == 0) kTile = 1;
+    int c = 256 * kTile; if (c > s) c = s;
+    *split = s; *cov = c;
+}
+extern "C" int thk_lmhead_f16(thk_ctx* ctx, const void* W, int64_t V, int64_t E, const float* x, float* logits, int mode) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, W && x && logits && V > 0, "thk_lmhead_f16: bad arguments");
+    REQUIRE(ctx, E >= 512 && E % 512 == 0, "thk_lmhead_f16: E=%lld must be a multiple of 512 (th.cpp:3728-3739)", (long long)E);
+    REQUIRE(ctx, mode == THK_LMHEAD_CORRECT || mode == THK_LMHEAD_FAITHFUL, "thk_lmhead_f16: bad mode");
+    int rc = ensure_scratch(ctx, 1u << 20);
+    if (rc != THK_OK) return rc;
+    GemvArgs a{}; a.W[0] = (const uint16_t*)W; a.R = (int)V; a.C = (int)E; a.x = x; a.y = logits;
+    a.lm_faithful = mode == THK_LMHEAD_FAITHFUL; q1_constants((int)V, &a.q1_split, &a.q1_cov);
+    a.block_best = (unsigned long long*)ctx->scratch;
+    rc = gemv_simple(ctx, GEMV_PRO_COPY, GEMV_EPI_HEAD, "gemv_variant_head", "gemv_bpc_head", a, (int)V);
+    return rc < 0 ? rc : THK_OK;
+}
+extern "C" int thk_argmax(thk_ctx* ctx, const float* logits, int64_t V, int32_t* id_out) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, logits && id_out && V > 0, "thk_argmax: bad arguments");
+    int rc = ensure_scratch(ctx, 1u << 20);
+    if (rc != THK_OK) return rc;
+    int nblocks = (int)((V + kBlock - 1) / kBlock); if (nblocks > 256) nblocks = 256;
+    HIPCHK(ctx, launch_argmax(logits, (int)V, (unsigned long long*)ctx->scratch, nblocks, ctx->stream));
+    HIPCHK(ctx, launch_finish_token((const unsigned long long*)ctx->scratch, nblocks, nullptr, nullptr, 0, nullptr, id_out, ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_embed_f16(thk_ctx* ctx, const void* table, int64_t E, int32_t token, float* x) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, table && x && E > 0 && token >= 0, "thk_embed_f16: bad arguments");
+    HIPCHK(ctx, launch_embed((const uint16_t*)table, nullptr, token, (int)E, x, ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_synth_f16(thk_ctx* ctx, const char* name, uint64_t seed, float sigma, int64_t n, void* out) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, name && out && n > 0, "thk_synth_f16: bad arguments");
+    HIPCHK(ctx, launch_synth_f16(synth_key(name, seed), synth_scale(sigma), (size_t)n, out, ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_synth_gain_f32(thk_ctx* ctx, const char* name, uint64_t seed, float sigma, int64_t n, float* out) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, name && out && n > 0, "thk_synth_gain_f32: bad arguments");
+    HIPCHK(ctx, launch_synth_gain(synth_key(name, seed), synth_scale(sigma), (size_t)n, out, ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_gemm_f16_prefill(thk_ctx* ctx, const void* W, int64_t R, int64_t C, const float* X, int64_t M, float* Y) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, W && X && Y && R > 0 && M > 0, "thk_gemm_f16_prefill: bad arguments");
+    REQUIRE(ctx, C >= 32 && C % 32 == 0, "thk_gemm_f16_prefill: C=%lld must be a multiple of 32", (long long)C);
+    const size_t ws = gemm_prefill_workspace_bytes((int)M, (int)C);
+    int rc = ensure_scratch(ctx, ws < (1u << 20) ? (1u << 20) : ws);
+    if (rc != THK_OK) return rc;
+    HIPCHK(ctx, launch_gemm_f16_prefill((const uint16_t*)W, (int)R, (int)C, X, (int)M, Y, ctx->scratch, ctx->stream));
+    return THK_OK;
+}
+
+// ---------------------------------------------------------------- model
+static int n_ff_of(const thk_hparams& hp) { return ((2 * (4 * hp.n_embd) / 3 + hp.n_mult - 1) / hp.n_mult) * hp.n_mult; }   // loader :349
+
+extern "C" int thk_model_create(thk_ctx* ctx, const thk_hparams* hp, int32_t layer_begin, int32_t layer_end, uint32_t stage_flags,
+                                int32_t n_seq, thk_model** out) {
+    if (!ctx || !hp || !out) return THK_ERR_INVALID;
+    *out = nullptr;
+    REQUIRE(ctx, hp->n_embd >= 512 && hp->n_embd % 512 == 0, "n_embd=%d must be a multiple of 512 (th.cpp:3728-3739)", hp->n_embd);
+    REQUIRE(ctx, hp->n_head > 0 && hp->n_embd % hp->n_head == 0, "n_head must divide n_embd");
+    REQUIRE(ctx, valid_head_dim(hp->n_embd / hp->n_head), "head dim %d not in {64,128,256}", hp->n_embd / hp->n_head);
+    REQUIRE(ctx, hp->n_mult > 0 && n_ff_of(*hp) % 256 == 0, "n_ff=%d must be a multiple of 256", n_ff_of(*hp));
+    REQUIRE(ctx, hp->n_layer > 0 && layer_begin >= 0 && layer_begin < layer_end && layer_end <= hp->n_layer, "bad layer range [%d,%d)", layer_begin, layer_end);
+    REQUIRE(ctx, hp->n_vocab > 0 && hp->n_ctx > 0 && n_seq >= 1 && n_seq <= 64, "bad n_vocab / n_ctx / n_seq");
+    REQUIRE(ctx, !(stage_flags & THK_STAGE_EMBED) || layer_begin == 0, "the embedding stage must start at layer 0");
+    REQUIRE(ctx, !(stage_flags & THK_STAGE_HEAD) || layer_end == hp->n_layer, "the head stage must end at the last layer");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    thk_model* m = new thk_model();
+    m->ctx = ctx; m->hp = *hp; m->n_ff = n_ff_of(*hp); m->l0 = layer_begin; m->l1 = layer_end; m->flags = stage_flags; m->n_seq = n_seq;
+    const size_t E = hp->n_embd, F = m->n_ff, V = hp->n_vocab;
+    m->layers.resize(layer_end - layer_begin);
+#define ALLOC(ptr, bytes)                                                                                         \
+    do {                                                                                                          \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                                       \
+        if (e_ != hipSuccess) { int rc_ = fail(ctx, e_ == hipErrorOutOfMemory ? THK_ERR_OOM : THK_ERR_HIP, "hipMalloc(%zu) for %s: %s", (size_t)(bytes), #ptr, hipGetErrorString(e_)); thk_model_destroy(m); return rc_; } \
+    } while (0)
+    for (auto& L : m->layers) {
+        ALLOC(L.wq, E * E * 2); ALLOC(L.wk, E * E * 2); ALLOC(L.wv, E * E * 2); ALLOC(L.wo, E * E * 2);
+        ALLOC(L.w1, F * E * 2); ALLOC(L.w3, F * E * 2); ALLOC(L.w2, E * F * 2);
+        ALLOC(L.attention_norm, E * 4); ALLOC(L.ffn_norm, E * 4);
+    }
+    if (stage_flags & THK_STAGE_EMBED) ALLOC(m->tok_embeddings, V * E * 2);
+    if (stage_flags & THK_STAGE_HEAD) { ALLOC(m->norm, E * 4); ALLOC(m->output, V * E * 2); }
+#undef ALLOC
+    *out = m;
+    return THK_OK;
+}
+
+static void free_seq(SeqBuf& s) {
+    if (s.exec) hipGraphExecDestroy(s.exec);
+    if (s.graph) hipGraphDestroy(s.graph);
+    hipFree(s.kv); hipFree(s.st); hipFree(s.gen_log); hipFree(s.hidden_in); hipFree(s.hidden_out); hipFree(s.logits); hipFree(s.advance);
+    s = SeqBuf();
+}
+static void free_working(thk_model* m) {
+    for (auto& s : m->seqs) free_seq(s);
+    m->seqs.clear();
+    hipFree(m->x); hipFree(m->q); hipFree(m->u); hipFree(m->attn_out); hipFree(m->part_o); hipFree(m->part_ml); hipFree(m->block_best); hipFree(m->rope_tab);
+    hipFree(m->prefill_ws);
+    m->x = m->q = m->u = m->attn_out = m->part_o = m->part_ml = nullptr; m->block_best = nullptr; m->rope_tab = nullptr;
+    m->prefill_ws = nullptr; m->prefill_ws_bytes = 0;
+    m->finalized = false;
+}
+extern "C" int thk_model_destroy(thk_model* m) {
+    if (!m) return THK_OK;
+    hipSetDevice(m->ctx->device);
+    hipStreamSynchronize(m->ctx->stream);
+    free_working(m);
+    for (auto& L : m->layers) { hipFree(L.wq); hipFree(L.wk); hipFree(L.wv); hipFree(L.wo); hipFree(L.w1); hipFree(L.w2); hipFree(L.w3); hipFree(L.attention_norm); hipFree(L.ffn_norm); }
+    hipFree(m->tok_embeddings); hipFree(m->norm); hipFree(m->output);
+    delete m;
+    return THK_OK;
+}
+extern "C" int32_t thk_model_n_ff(const thk_model* m) { return m ? m->n_ff : 0; }
+
+// name -> device slot; returns 0 ok, 1 = tensor belongs to another stage (ignored), <0 error
+static int tensor_slot(thk_model* m, const char* name, void** dst, int64_t* ne0, int64_t* ne1, int* dtype) {
+    const int64_t E = m->hp.n_embd, F = m->n_ff, V = m->hp.n_vocab;
+    *dst = nullptr;
+    if (!strcmp(name, "tok_embeddings.weight")) { *ne0 = E; *ne1 = V; *dtype = THK_F16; *dst = m->tok_embeddings; return *dst ? 0 : 1; }
+    if (!strcmp(name, "norm.weight")) { *ne0 = E; *ne1 = 1; *dtype = THK_F32; *dst = m->norm; return *dst ? 0 : 1; }
+    if (!strcmp(name, "output.weight")) { *ne0 = E; *ne1 = V; *dtype = THK_F16; *dst = m->output; return *dst ? 0 : 1; }
+    int l = -1; char rest[64];
+    if (sscanf(name, "layers.%d.%63s", &l, rest) != 2 || l < 0 || l >= m->hp.n_layer) return THK_ERR_NOTFOUND;
+    const bool local = l >= m->l0 && l < m->l1;
+    LayerW dummy; LayerW& L = local ? m->layers[l - m->l0] : dummy;
+    struct { const char* n; void* p; int64_t c, r; int t; } tab[] = {
+        {"attention_norm.weight", L.attention_norm, E, 1, THK_F32}, {"ffn_norm.weight", L.ffn_norm, E, 1, THK_F32},
+        {"attention.wq.weight", L.wq, E, E, THK_F16}, {"attention.wk.weight", L.wk, E, E, THK_F16},
+        {"attention.wv.weight", L.wv, E, E, THK_F16}, {"attention.wo.weight", L.wo, E, E, THK_F16},
+        {"feed_forward.w1.weight", L.w1, E, F, THK_F16}, {"feed_forward.w2.weight", L.w2, F, E, THK_F16},
+        {"feed_forward.w3.weight", L.w3, E, F, THK_F16}};
+    for (auto& t : tab)
+        if (!strcmp(rest, t.n)) { *ne0 = t.c; *ne1 = t.r; *dtype = t.t; *dst = t.p; return local ? 0 : 1; }
+    return THK_ERR_NOTFOUND;
+}
+extern "C" int thk_model_set_tensor(thk_model* m, const char* name, int dtype, int64_t ne0, int64_t ne1, const void* host) {
+    if (!m || !name || !host) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    void* dst; int64_t c, r; int t;
+    const int rc = tensor_slot(m, name, &dst, &c, &r, &t);
+    if (rc < 0) return fail(ctx, THK_ERR_NOTFOUND, "unknown tensor '%s'", name);
+    if (ne1 <= 0) ne1 = 1;
+    REQUIRE(ctx, c == ne0 && r == ne1, "tensor '%s': shape [%lld,%lld] expected [%lld,%lld]", name, (long long)ne1, (long long)ne0, (long long)r, (long long)c);
+    REQUIRE(ctx, t == dtype, "tensor '%s': dtype %d expected %d (only GGML f16 models are supported, README.md:5)", name, dtype, t);
+    if (rc == 1) return THK_OK;   // another stage owns it
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst, host, (size_t)(c * r) * (t == THK_F16 ? 2 : 4), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_model_fill_synthetic(thk_model* m, uint64_t seed, float sigma) {
+    if (!m) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    const size_t E = m->hp.n_embd, F = m->n_ff, V = m->hp.n_vocab;
+    const float sc = synth_scale(sigma);
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (m->tok_embeddings) HIPCHK(ctx, launch_synth_f16(synth_key("tok_embeddings.weight", seed), sc, V * E, m->tok_embeddings, st));
+    if (m->norm) HIPCHK(ctx, launch_synth_gain(synth_key("norm.weight", seed), sc, E, m->norm, st));
+    if (m->output) HIPCHK(ctx, launch_synth_f16(synth_key("output.weight", seed), sc, V * E, m->output, st));
+    for (int l = m->l0; l < m->l1; ++l) {
+        LayerW& L = m->layers[l - m->l0];
+        char nm[96];
+#define NM(s) (snprintf(nm, sizeof nm, "layers.%d." s, l), synth_key(nm, seed))
+        HIPCHK(ctx, launch_synth_gain(NM("attention_norm.weight"), sc, E, L.attention_norm, st));
+        HIPCHK(ctx, launch_synth_gain(NM("ffn_norm.weight"), sc, E, L.ffn_norm, st));
+        HIPCHK(ctx, launch_synth_f16(NM("attention.wq.weight"), sc, E * E, L.wq, st));
+        HIPCHK(ctx, launch_synth_f16(NM("attention.wk.weight"), sc, E * E, L.wk, st));
+        HIPCHK(ctx, launch_synth_f16(NM("attention.wv.weight"), sc, E * E, L.wv, st));
+        HIPCHK(ctx, launch_synth_f16(NM("attention.wo.weight"), sc, E * E, L.wo, st));
+        HIPCHK(ctx, launch_synth_f16(NM("feed_forward.w1.weight"), sc, F * E, L.w1, st));
+        HIPCHK(ctx, launch_synth_f16(NM("feed_forward.w2.weight"), sc, E * F, L.w2, st));
+        HIPCHK(ctx, launch_synth_f16(NM("feed_forward.w3.weight"), sc, F * E, L.w3, st));
+#undef NM
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return THK_OK;
+}
+extern "C" int thk_model_set_lmhead_mode(thk_model* m, int mode) {
+    if (!m) return THK_ERR_INVALID;
+    REQUIRE(m->ctx, mode == THK_LMHEAD_CORRECT || mode == THK_LMHEAD_FAITHFUL, "bad lm-head mode %d", mode);
+    REQUIRE(m->ctx, !m->finalized, "set the lm-head mode before thk_model_finalize (it is baked into the captured graph)");
+    m->lm_mode = mode;
+    return THK_OK;
+}
+
+// ----- one decode step of this stage, enqueued on the ctx stream (eager or under capture)
+struct StepProf {
+    std::vector<std::string> names;
+    std::vector<hipEvent_t> events;   // events[i] recorded before kernel i; one extra at the end
+};
+static int prof_mark(thk_ctx* ctx, StepProf* p, const char* name) {
+    if (!p) return THK_OK;
+    hipEvent_t ev;
+    HIPCHK(ctx, hipEventCreate(&ev));
+    HIPCHK(ctx, hipEventRecord(ev, ctx->stream));
+    p->events.push_back(ev);
+    if (name) p->names.push_back(name);
+    return THK_OK;
+}
+#define MARK(name) do { int rc_ = prof_mark(ctx, prof, name); if (rc_ != THK_OK) return rc_; } while (0)
+
+static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
+    thk_ctx* ctx = m->ctx;
+    hipStream_t st = ctx->stream;
+    SeqBuf& sb = m->seqs[seq];
+    const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, V = m->hp.n_vocab, T = m->hp.n_ctx;
+    const bool nt = m->nt != 0;
+    const int nl = m->l1 - m->l0;
+    const float* xin = sb.hidden_in;
+    if (m->flags & THK_STAGE_EMBED) {
+        MARK("embed");
+        HIPCHK(ctx, launch_embed(m->tok_embeddings, sb.st, 0, E, m->x, st));
+        xin = m->x;
+    }
+    for (int i = 0; i < nl; ++i) {
+        const LayerW& L = m->layers[i];
+        float* kc = sb.kv + (size_t)i * 2 * T * E;
+        float* vc = kc + (size_t)T * E;
+        const float* xr_in = i == 0 ? xin : m->x;
+        {   // rms_norm*gain -> wq,wk,wv -> RoPE -> K/V append   (steps 1-4, th-llama.cpp:299-339)
+            GemvArgs a{};
+            a.W[0] = L.wq; a.W[1] = L.wk; a.W[2] = L.wv; a.R = E; a.C = E; a.n_groups = 3 * E / 2;
+            a.x = xr_in; a.gain = L.attention_norm; a.y = m->q;
+            a.kcache = kc; a.vcache = vc; a.rope_tab = m->rope_tab; a.pos_ptr = &sb.st->pos; a.E = E; a.D = D;
+            MARK("norm_qkv_rope_kv");
+            HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_ROPE_KV, m->var_qkv, a, m->grid_qkv, nt, st));
+        }
+        {   // attention over the cache in place   (steps 5-9, th-llama.cpp:341-397)
+            AttnArgs a{};
+            a.q = m->q; a.kcache = kc; a.vcache = vc; a.pos_ptr = &sb.st->pos; a.H = H; a.D = D; a.nsplit = m->nsplit; a.tc = m->tc;
+            a.scale = 1.0f / sqrtf((float)D);
+            a.out = m->nsplit == 1 ? m->attn_out : nullptr; a.part_o = m->part_o; a.part_ml = m->part_ml;
+            MARK("attn_decode");
+            HIPCHK(ctx, launch_attn_decode(a, st));
+        }
+        {   // split combine -> wo -> + residual   (steps 10-11, th-llama.cpp:401-413)
+            GemvArgs a{};
+            a.W[0] = L.wo; a.R = E; a.C = E;
+            const int NR = gemv_rows_per_group(E, GEMV_EPI_RESID, m->var_wo);
+            a.n_groups = (E + NR - 1) / NR;
+            a.x = m->attn_out; a.part_o = m->part_o; a.part_ml = m->part_ml; a.H = H; a.D = D; a.nsplit = m->nsplit;
+            a.resid = xr_in; a.y = m->x;
+            MARK("attn_wo_resid");
+            HIPCHK(ctx, launch_gemv(m->nsplit == 1 ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, m->var_wo, a, m->grid_wo, nt, st));
+        }
+        {   // rms_norm*gain -> w1,w3 -> silu*gate   (steps 12-14, th-llama.cpp:415-438)
+            GemvArgs a{};
+            a.W[0] = L.w1; a.W[1] = L.w3; a.R = F; a.C = E; a.n_groups = F;
+            a.x = m->x; a.gain = L.ffn_norm; a.y = m->u;
+            MARK("norm_w13_swiglu");
+            HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_SWIGLU, m->var_w13, a, m->grid_w13, nt, st));
+        }
+        {   // w2 -> + residual   (steps 15-16, th-llama.cpp:440-451)
+            GemvArgs a{};
+            a.W[0] = L.w2; a.R = E; a.C = F;
+            const int NR = gemv_rows_per_group(F, GEMV_EPI_RESID, m->var_w2);
+            a.n_groups = (E + NR - 1) / NR;
+            a.x = m->u; a.resid = m->x;
+            a.y = (i == nl - 1 && !(m->flags & THK_STAGE_HEAD)) ? sb.hidden_out : m->x;
+            MARK("w2_resid");
+            HIPCHK(ctx, launch_gemv(GEMV_PRO_COPY, GEMV_EPI_RESID, m->var_w2, a, m->grid_w2, nt, st));
+        }
+    }
+    if (m->flags & THK_STAGE_HEAD) {   // final norm -> lm-head -> greedy pick   (th-llama.cpp:240-268, :826-838)
+        GemvArgs a{};
+        a.W[0] = m->output; a.R = V; a.C = E;
+        const int NR = gemv_rows_per_group(E, GEMV_EPI_HEAD, m->var_head);
+        a.n_groups = (V + NR - 1) / NR;
+        a.x = m->x; a.gain = m->norm; a.y = sb.logits;
+        a.lm_faithful = m->lm_mode == THK_LMHEAD_FAITHFUL; q1_constants(V, &a.q1_split, &a.q1_cov);
+        a.block_best = m->block_best;
+        MARK("norm_lmhead");
+        HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, nt, st));
+        MARK("finish_token");
+        HIPCHK(ctx, launch_finish_token(m->block_best, m->grid_head, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, st));
+    } else {
+        MARK("advance_pos");
+        HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, st));
+    }
+    MARK(nullptr);
+    return THK_OK;
+}
+
+__global__ void set_seq_state_kernel(SeqState* st, int token, int pos, int reset_gen) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->token = token; st->pos = pos; if (reset_gen) st->n_gen = 0; }
+}
+static int set_seq_state(thk_model* m, int seq, int token, int pos, bool reset_gen) {
+    hipLaunchKernelGGL(set_seq_state_kernel, dim3(1), dim3(64), 0, m->ctx->stream, m->seqs[seq].st, token, pos, reset_gen ? 1 : 0);
+    HIPCHK(m->ctx, hipGetLastError());
+    return THK_OK;
+}
+static int set_advance(thk_model* m, int seq, int advance) {
+    SeqBuf& sb = m->seqs[seq];
+    advance = advance ? 1 : 0;
+    if (sb.advance_host != advance) {
+        HIPCHK(m->ctx, hipMemsetAsync(sb.advance, advance ? 1 : 0, 4, m->ctx->stream));
+        sb.advance_host = advance;
+    }
+    return THK_OK;
+}
+static int run_step(thk_model* m, int seq) {
+    if (m->use_graph && m->seqs[seq].exec) { HIPCHK(m->ctx, hipGraphLaunch(m->seqs[seq].exec, m->ctx->stream)); return THK_OK; }
+    return enqueue_step(m, seq, nullptr);
+}
+
+extern "C" int thk_model_finalize(thk_model* m) {
+    if (!m) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    free_working(m);
+    const size_t E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, V = m->hp.n_vocab, T = m->hp.n_ctx;
+    const int nl = m->l1 - m->l0;
+    // launch geometry
+    m->nsplit = (int)tun(ctx, "attn_splits");
+    REQUIRE(ctx, valid_splits(m->nsplit), "attn_splits must be 1, 2, 4 or 8");
+    m->tc = (int)((T + m->nsplit - 1) / m->nsplit);
+    m->nt = tun(ctx, "gemv_nt") != 0;
+    m->use_graph = tun(ctx, "use_graph") != 0;
+    m->var_qkv = (int)tun(ctx, "gemv_variant_qkv"); m->var_wo = (int)tun(ctx, "gemv_variant_wo");
+    m->var_w13 = (int)tun(ctx, "gemv_variant_w13"); m->var_w2 = (int)tun(ctx, "gemv_variant_w2"); m->var_head = (int)tun(ctx, "gemv_variant_head");
+    m->grid_qkv = grid_for(ctx, "gemv_bpc_qkv", (int)(3 * E / 2));
+    m->grid_wo = grid_for(ctx, "gemv_bpc_wo", (int)((E + gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo) - 1) / gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo)));
+    m->grid_w13 = grid_for(ctx, "gemv_bpc_w13", (int)F);
+    m->grid_w2 = grid_for(ctx, "gemv_bpc_w2", (int)((E + gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2) - 1) / gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2)));
+    m->grid_head = grid_for(ctx, "gemv_bpc_head", (int)((V + gemv_rows_per_group((int)E, GEMV_EPI_HEAD, m->var_head) - 1) / gemv_rows_per_group((int)E, GEMV_EPI_HEAD, m->var_head)));
+    // working buffers
+#define ALLOCZ(ptr, bytes)                                                                                              \
+    do {                                                                                                                \
+        hipError_t e_ = hipMalloc((void**)&(ptr), (bytes));                                                             \
+        if (e_ != hipSuccess) return fail(ctx, e_ == hipErrorOutOfMemory ? THK_ERR_OOM : THK_ERR_HIP, "hipMalloc(%zu) for %s: %s", (size_t)(bytes), #ptr, hipGetErrorString(e_)); \
+        HIPCHK(ctx, hipMemsetAsync((ptr), 0, (bytes), ctx->stream));                                                    \
+    } while (0)
+    ALLOCZ(m->x, E * 4); ALLOCZ(m->q, E * 4); ALLOCZ(m->u, F * 4); ALLOCZ(m->attn_out, E * 4);
+    ALLOCZ(m->part_o, H * kMaxSplit * D * 4); ALLOCZ(m->part_ml, H * kMaxSplit * 2 * 4);
+    ALLOCZ(m->block_best, (size_t)(m->grid_head > 0 ? m->grid_head : 1) * 8 + 4096);
+    ALLOCZ(m->rope_tab, T * (D / 2) * 2 * 4);
+    {
+        std::vector<float> tab;
+        build_rope_table(tab, (int)D, 0, (int)T);
+        HIPCHK(ctx, hipMemcpyAsync(m->rope_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    m->seqs.resize(m->n_seq);
+    for (auto& s : m->seqs) {
+        ALLOCZ(s.kv, (size_t)nl * 2 * T * E * 4);
+        ALLOCZ(s.st, sizeof(SeqState)); ALLOCZ(s.gen_log, (size_t)kGenLogCap * 4);
+        ALLOCZ(s.hidden_in, E * 4); ALLOCZ(s.hidden_out, E * 4); ALLOCZ(s.advance, 4);
+        if (m->flags & THK_STAGE_HEAD) ALLOCZ(s.logits, V * 4);
+        s.advance_host = 0;
+    }
+#undef ALLOCZ
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    m->finalized = true;
+    // warm-up (loads code objects, sets LDS attributes) then capture one graph per sequence
+    int rc = enqueue_step(m, 0, nullptr);
+    if (rc != THK_OK) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    rc = thk_model_reset_kv(m, 0);
+    if (rc != THK_OK) return rc;
+    if (m->use_graph) {
+        for (int s = 0; s < m->n_seq; ++s) {
+            HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_step(m, s, nullptr);
+            hipError_t e = hipStreamEndCapture(ctx->stream, &m->seqs[s].graph);
+            if (rc != THK_OK) return rc;
+            if (e != hipSuccess) return fail(ctx, THK_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+            HIPCHK(ctx, hipGraphInstantiate(&m->seqs[s].exec, m->seqs[s].graph, nullptr, nullptr, 0));
+        }
+    }
+    return THK_OK;
+}
+
+extern "C" int thk_model_reset_kv(thk_model* m, int32_t seq) {
+    if (!m) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized, "thk_model_reset_kv before thk_model_finalize");
+    REQUIRE(ctx, seq >= 0 && seq < m->n_seq, "bad sequence %d", seq);
+    const size_t bytes = (size_t)(m->l1 - m->l0) * 2 * m->hp.n_ctx * m->hp.n_embd * 4;
+    HIPCHK(ctx, hipMemsetAsync(m->seqs[seq].kv, 0, bytes, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(m->seqs[seq].st, 0, sizeof(SeqState), ctx->stream));
+    return THK_OK;
+}
+
+extern "C" int thk_model_eval(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past,
+                              float* hidden_inout, float* logits_out) {
+    if (!m) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized, "thk_model_eval before thk_model_finalize");
+    REQUIRE(ctx, seq >= 0 && seq < m->n_seq, "bad sequence %d", seq);
+    REQUIRE(ctx, n_tokens >= 1 && n_past >= 0 && n_past + n_tokens <= m->hp.n_ctx, "n_past=%d + n_tokens=%d exceeds n_ctx=%d", n_past, n_tokens, m->hp.n_ctx);
+    const bool embed = m->flags & THK_STAGE_EMBED, head = m->flags & THK_STAGE_HEAD;
+    REQUIRE(ctx, !embed || tokens, "an embedding stage needs token ids");
+    REQUIRE(ctx, embed || (hidden_inout && n_tokens == 1), "a non-embedding stage takes exactly one hidden state per call");
+    REQUIRE(ctx, !logits_out || head, "logits requested from a stage without the lm-head");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    SeqBuf& sb = m->seqs[seq];
+    const size_t E = m->hp.n_embd, V = m->hp.n_vocab;
+    if (!embed) HIPCHK(ctx, hipMemcpyAsync(sb.hidden_in, hidden_inout, E * 4, hipMemcpyHostToDevice, ctx->stream));
+    int rc = set_advance(m, seq, 0);
+    if (rc != THK_OK) return rc;
+    for (int i = 0; i < n_tokens; ++i) {
+        if (embed) REQUIRE(ctx, tokens[i] >= 0 && tokens[i] < m->hp.n_vocab, "token id %d out of range", tokens[i]);
+        rc = set_seq_state(m, seq, embed ? tokens[i] : 0, n_past + i, false);
+        if (rc != THK_OK) return rc;
+        rc = run_step(m, seq);
+        if (rc != THK_OK) return rc;
+    }
+    if (logits_out) HIPCHK(ctx, hipMemcpyAsync(logits_out, sb.logits, V * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (hidden_inout) HIPCHK(ctx, hipMemcpyAsync(hidden_inout, head ? m->x : sb.hidden_out, E * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return THK_OK;
+}
+
+extern "C" int thk_model_seq_set(thk_model* m, int32_t seq, int32_t token, int32_t pos) {
+    if (!m) return THK_ERR_INVALID;
+    REQUIRE(m->ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
+    REQUIRE(m->ctx, pos >= 0 && pos < m->hp.n_ctx && token >= 0 && token < m->hp.n_vocab, "token %d / pos %d out of range", token, pos);
+    return set_seq_state(m, seq, token, pos, true);
+}
+extern "C" int thk_model_decode_step(thk_model* m, int32_t seq, int advance) {
+    if (!m) return THK_ERR_INVALID;
+    REQUIRE(m->ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
+    int rc = set_advance(m, seq, advance);
+    if (rc != THK_OK) return rc;
+    return run_step(m, seq);
+}
+extern "C" void* thk_model_hidden_in(thk_model* m, int32_t seq) { return (m && m->finalized && seq >= 0 && seq < m->n_seq) ? m->seqs[seq].hidden_in : nullptr; }
+extern "C" void* thk_model_hidden_out(thk_model* m, int32_t seq) { return (m && m->finalized && seq >= 0 && seq < m->n_seq) ? m->seqs[seq].hidden_out : nullptr; }
+extern "C" void* thk_model_token_dev(thk_model* m, int32_t seq) { return (m && m->finalized && seq >= 0 && seq < m->n_seq) ? (void*)&m->seqs[seq].st->token : nullptr; }
+extern "C" void* thk_model_logits_dev(thk_model* m, int32_t seq) { return (m && m->finalized && seq >= 0 && seq < m->n_seq) ? m->seqs[seq].logits : nullptr; }
+
+extern "C" int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out, int32_t cap, int32_t* n_out, int32_t* pos_out) {
+    if (!m) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
+    SeqState h{};
+    HIPCHK(ctx, hipMemcpyAsync(&h, m->seqs[seq].st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int n = h.n_gen < kGenLogCap ? h.n_gen : kGenLogCap;
+    if (n > cap) n = cap;
+    if (n > 0 && tokens_out) {
+        HIPCHK(ctx, hipMemcpyAsync(tokens_out, m->seqs[seq].gen_log, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (n_out) *n_out = h.n_gen;
+    if (pos_out) *pos_out = h.pos;
+    return THK_OK;
+}
+
+extern "C" int64_t thk_model_bytes_per_token(const thk_model* m, int32_t T) {
+    if (!m) return 0;
+    const int64_t E = m->hp.n_embd, F = m->n_ff, V = m->hp.n_vocab, nl = m->l1 - m->l0;
+    int64_t b = nl * ((4 * E * E + 3 * E * F) * 2      // f16 weights
+                      + 2 * (int64_t)T * E * 4          // f32 K,V read
+                      + 2 * E * 4                       // K,V row written
+                      + 2 * E * 4);                     // two norm gains
+    if (m->flags & THK_STAGE_HEAD) b += V * E * 2 + E * 4;
+    return b;
+}
+
+extern "C" int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_entries, char (*names)[48], float* ms, int32_t* n_out) {
+    if (!m || !names || !ms || !n_out) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
+    StepProf p;
+    int rc = enqueue_step(m, seq, &p);
+    if (rc == THK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "sync failed while profiling");
+    int n = 0;
+    if (rc == THK_OK) {
+        for (size_t i = 0; i + 1 < p.events.size() && i < p.names.size() && n < max_entries; ++i, ++n) {
+            float t = 0.f;
+            hipEventElapsedTime(&t, p.events[i], p.events[i + 1]);
+            strncpy(names[n], p.names[i].c_str(), 47); names[n][47] = 0;
+            ms[n] = t;
+        }
+    }
+    for (auto ev : p.events) hipEventDestroy(ev);
+    *n_out = n;
+    return rc;
+}
+
+extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past, float* logits_out) {
+    if (!m) return THK_ERR_INVALID;
+    (void)seq; (void)tokens; (void)n_tokens; (void)n_past; (void)logits_out;
+    return fail(m->ctx, THK_ERR_STATE, "thk_model_prefill: batched MFMA prefill is not wired into the model yet; use thk_model_eval");
+}

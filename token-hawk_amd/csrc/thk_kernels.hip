@@ -1,0 +1,846 @@
+// thk_kernels.hip — hand-written CDNA4 (gfx950) kernels for the single-token
+// LLaMA decode path.  wave = 64 lanes everywhere; blocks are 256 threads (4 waves).
+//
+// Design:
+//   * The f16-weight x f32-activation mat-vec is >98 % of the bytes and is pure
+//     HBM streaming: one WAVE owns whole rows, every lane issues 16-byte
+//     (8 x f16) non-temporal loads, a wave-instruction covers 1 KiB of one row,
+//     NR rows x U chunks are issued back to back before the first use so each
+//     wave keeps 8-16 KiB in flight.  The f32 activation vector is staged ONCE
+//     per block in LDS (split lo/hi float4 layout => conflict-free
+//     ds_read_b128), by a prologue that is fused with whatever produced it
+//     (RMSNorm*gain, attention split combine, plain copy).  Accumulation is f32
+//     FMA on the hardware-converted f16 (v_cvt_f32_f16 == the reference's
+//     bit-trick decode, th.cpp:363-394).  Row sums are reduced with DPP.
+//   * Epilogues fuse what the reference runs as separate dispatches: RoPE +
+//     K/V append, residual add, SiLU*gate, lm-head split combine + arg-max.
+//   * Attention reads the f32 caches in place ([n_ctx,H,D]); no transposed copy.
+//   * Positions/tokens are read from device memory so one captured hipGraph
+//     serves every token.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "thk_kernels.hpp"
+
+namespace thk {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------- wave reductions
+// DPP butterfly inside each row of 16 lanes (quad_perm, row_half_mirror,
+// row_mirror), then the four row totals are combined through readlane.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float rdlane(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// Full-wave sum; result is wave-uniform.
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(rdlane(v, 0), rdlane(v, 16)), fmaxf(rdlane(v, 32), rdlane(v, 48)));
+}
+// Sum over aligned groups of G lanes (G = 16, 32 or 64); every lane of a group gets its group's sum.
+template <int G>
+__device__ __forceinline__ float group_sum(float v) {
+    v = row16_sum(v);
+    if (G >= 32) v += __shfl_xor(v, 16);
+    if (G >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red /* >= 4 floats of LDS */) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------- LDS x-vector layout
+// A row is walked in "slots" of 64 lanes x 8 elements (1 KiB of f16 per wave-instruction).
+// Lane l of slot c needs elements [(c*64+l)*8, +8).  They are stored as two float4
+// arrays so consecutive lanes hit consecutive 16-byte slots (conflict-free ds_read_b128):
+//   lo[c*64+l] = elems 0..3, hi[c*64+l] = elems 4..7 ; hi starts at ns*256 floats.
+// The arrays are zero-padded to ns whole slots, so a lane past the end of a row (C % 512
+// == 256) multiplies a clamped, valid weight vector by zeros: no divergent branch is
+// needed in the streaming loop.
+__device__ __forceinline__ int xs_index(int e, int ns) {   // float index in LDS for element e
+    const int g = e >> 3, j = e & 7;
+    return (j < 4 ? 0 : (ns << 8)) + (g << 2) + (j & 3);
+}
+
+// Store index for float4 #i of the padded vector; threads past the end (only possible when the
+// slot count is odd) are steered to a dummy 16-byte slot behind the vector instead of branching.
+__device__ __forceinline__ int xs_store_index(int i, int ns) {
+    return (i < (ns << 7)) ? xs_index(i << 2, ns) : (ns << 9) + 12;
+}
+
+// ---------------------------------------------------------------- GEMV prologues
+// All run with the whole block; on return xs[] holds the activation vector and a
+// __syncthreads() has been executed.
+
+// Each thread owns float4 #(tid + k*256), k < KP, of the (zero padded) vector.  With a
+// compile-time slot count the K loads are issued back to back (one L2 round trip); the
+// run-time form (NS == 0) loops.
+template <int NS> struct PrologueK { static constexpr int value = NS ? (NS * 128 + kBlock - 1) / kBlock : 1; };
+
+// plain copy (th.cpp K1 with no fused producer)
+template <int NS>
+__device__ __forceinline__ void prologue_copy(float* xs, const float* __restrict__ x, int C, int ns) {
+    if (NS != 0) {
+        constexpr int KP = PrologueK<NS>::value;
+        f4 v[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int i = threadIdx.x + k * kBlock;
+            v[k] = *reinterpret_cast<const f4*>(x + min(i << 2, C - 4));   // branch-free: clamp, then select
+        }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int i = threadIdx.x + k * kBlock;
+            const f4 o = ((i << 2) < C) ? v[k] : f4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = o;
+        }
+    } else {
+        for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((i << 2) < C) v = *reinterpret_cast<const f4*>(x + (i << 2));
+            *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = v;
+        }
+    }
+    __syncthreads();
+}
+
+// RMSNorm + gain (K4 th.cpp:1169-1198, K5 :1311-1313): xs = (x * inv) * g
+template <int NS>
+__device__ __forceinline__ void prologue_rms(float* xs, float* red, const float* __restrict__ x,
+                                             const float* __restrict__ gain, int C, int ns) {
+    if (NS != 0) {
+        constexpr int KP = PrologueK<NS>::value;
+        f4 v[KP], g[KP];
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int i = threadIdx.x + k * kBlock;
+            const int ic = min(i << 2, C - 4);                               // branch-free: clamp, then select
+            v[k] = *reinterpret_cast<const f4*>(x + ic); g[k] = *reinterpret_cast<const f4*>(gain + ic);
+        }
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int i = threadIdx.x + k * kBlock;
+            if ((i << 2) >= C) v[k] = f4{0.f, 0.f, 0.f, 0.f};
+        }
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+        ss = block_sum(ss, red);
+        const float inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int i = threadIdx.x + k * kBlock;
+            f4 o;
+            o.x = (v[k].x * inv) * g[k].x; o.y = (v[k].y * inv) * g[k].y; o.z = (v[k].z * inv) * g[k].z; o.w = (v[k].w * inv) * g[k].w;
+            *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = o;
+        }
+    } else {
+        float ss = 0.f;
+        for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
+            f4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((i << 2) < C) v = *reinterpret_cast<const f4*>(x + (i << 2));
+            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = v;   // raw copy, normalised below
+        }
+        ss = block_sum(ss, red);
+        const float inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
+        for (int i = threadIdx.x; i < (C >> 2); i += kBlock) {
+            const f4 g = *reinterpret_cast<const f4*>(gain + (i << 2));
+            f4* p = reinterpret_cast<f4*>(xs + xs_index(i << 2, ns));
+            f4 v = *p;   // same thread wrote it
+            v.x = (v.x * inv) * g.x; v.y = (v.y * inv) * g.y; v.z = (v.z * inv) * g.z; v.w = (v.w * inv) * g.w;
+            *p = v;
+        }
+    }
+    __syncthreads();
+}
+
+// Attention split combine: xs[h*D+d] = sum_s o_s[d] * e^{m_s-M} / sum_s l_s * e^{m_s-M}
+// NSP = compile-time split count so all 2*NSP loads of a float4 are issued together.
+template <int NSP>
+__device__ __forceinline__ f4 attn_combine4(const float* __restrict__ part_o, const float* __restrict__ part_ml, int e, int D) {
+    const int h = e / D, d = e - h * D;
+    float ms[NSP], ls[NSP];
+    f4 ov[NSP];
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) {
+        const float2 ml = *reinterpret_cast<const float2*>(part_ml + (h * NSP + s) * 2);
+        ms[s] = ml.x; ls[s] = ml.y;
+        ov[s] = *reinterpret_cast<const f4*>(part_o + (size_t)(h * NSP + s) * D + d);
+    }
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) M = fmaxf(M, ms[s]);
+    float L = 0.f; f4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) {
+        const float sc = (ms[s] == -INFINITY) ? 0.f : expf(ms[s] - M);
+        L += ls[s] * sc; o += ov[s] * sc;
+    }
+    return o * (1.0f / L);
+}
+template <int NS, int NSP>
+__device__ __forceinline__ void prologue_attn(float* xs, const float* __restrict__ part_o,
+                                              const float* __restrict__ part_ml, int H, int D, int ns) {
+    const int C = H * D;
+    if (NS != 0) {
+        constexpr int KP = PrologueK<NS>::value;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int i = threadIdx.x + k * kBlock, e = i << 2;
+            f4 res = attn_combine4<NSP>(part_o, part_ml, min(e, C - 4), D);
+            if (e >= C) res = f4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = res;
+        }
+    } else {
+        for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
+            const int e = i << 2;
+            f4 res = {0.f, 0.f, 0.f, 0.f};
+            if (e < C) res = attn_combine4<NSP>(part_o, part_ml, e, D);
+            *reinterpret_cast<f4*>(xs + xs_index(e, ns)) = res;
+        }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- GEMV core
+enum { PRO_COPY = GEMV_PRO_COPY, PRO_RMS = GEMV_PRO_RMS, PRO_ATTN = GEMV_PRO_ATTN };
+enum { EPI_STORE = GEMV_EPI_STORE, EPI_RESID = GEMV_EPI_RESID, EPI_ROPE_KV = GEMV_EPI_ROPE_KV, EPI_SWIGLU = GEMV_EPI_SWIGLU,
+       EPI_HEAD = GEMV_EPI_HEAD };
+
+template <bool NT>
+__device__ __forceinline__ h8 ldw(const h8* p) {
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+__device__ __forceinline__ float dot8(h8 w, f4 xl, f4 xh, float acc) {
+    acc = fmaf((float)w[0], xl.x, acc); acc = fmaf((float)w[1], xl.y, acc);
+    acc = fmaf((float)w[2], xl.z, acc); acc = fmaf((float)w[3], xl.w, acc);
+    acc = fmaf((float)w[4], xh.x, acc); acc = fmaf((float)w[5], xh.y, acc);
+    acc = fmaf((float)w[6], xh.z, acc); acc = fmaf((float)w[7], xh.w, acc);
+    return acc;
+}
+
+__device__ __forceinline__ unsigned long long argmax_key(float v, unsigned idx) {
+    unsigned b = __builtin_bit_cast(unsigned, v);
+    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);          // order-preserving map
+    return ((unsigned long long)b << 32) | (unsigned long long)(0xFFFFFFFFu - idx);   // ties: smaller idx wins
+}
+
+// One launch = one fused op.  Work unit = "row group": NR weight rows streamed
+// together by one wave.  Group g of EPI_* means:
+//   STORE/RESID/HEAD : rows NR*g .. NR*g+NR-1 of W[0]
+//   ROPE_KV (NR=2)   : rows 2g,2g+1 of the virtual [3E,E] stack W[0]=wq,W[1]=wk,W[2]=wv
+//   SWIGLU (NR=2)    : row g of W[0]=w1 and row g of W[1]=w3
+// NS = compile-time slot count (C = NS*512 or NS*512-256), 0 = run-time (any C % 256 == 0).
+// U = slots per load batch (NS % U == 0 when NS != 0): NR*U 16-byte loads per lane are issued
+// back to back with no intervening branch or wait.
+template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP>
+__global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int C = a.C;
+    const int nvec = C >> 3;                                  // 16-byte vectors per row
+    const int ns = NS ? NS : ((nvec + 63) >> 6);
+    float* xs = smem;                 // ns*512 floats
+    float* red = smem + (ns << 9);    // floats 0-3: reduction, 4-11: EPI_HEAD scratch, 12-15: dummy store slot
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    if (PRO == PRO_COPY) prologue_copy<NS>(xs, a.x, C, ns);
+    else if (PRO == PRO_RMS) prologue_rms<NS>(xs, red, a.x, a.gain, C, ns);
+    else prologue_attn<NS, (NSP > 0 ? NSP : 1)>(xs, a.part_o, a.part_ml, a.H, a.D, ns);
+
+    const int wave_global = blockIdx.x * kWaves + wave;
+    const int total_waves = gridDim.x * kWaves;
+    const f4* xlo = reinterpret_cast<const f4*>(xs);
+    const f4* xhi = reinterpret_cast<const f4*>(xs + (ns << 8));
+    const int half_c = C >> 1;
+    const int vlast = nvec - 1;
+
+    unsigned long long best = 0ull;   // EPI_HEAD running arg-max of this wave (valid in lane 0)
+
+    for (int g = wave_global; g < a.n_groups; g += total_waves) {
+        const h8* rp[NR];
+        if (EPI == EPI_ROPE_KV) {
+            const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E;
+            const uint16_t* base = which == 0 ? a.W[0] : (which == 1 ? a.W[1] : a.W[2]);
+            rp[0] = reinterpret_cast<const h8*>(base + (size_t)rr * C);
+            rp[1 % NR] = reinterpret_cast<const h8*>(base + (size_t)(rr + 1) * C);
+        } else if (EPI == EPI_SWIGLU) {
+            rp[0] = reinterpret_cast<const h8*>(a.W[0] + (size_t)g * C);
+            rp[1 % NR] = reinterpret_cast<const h8*>(a.W[1] + (size_t)g * C);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                int row = NR * g + r; if (row >= a.R) row = a.R - 1;   // tail rows recomputed, not stored
+                rp[r] = reinterpret_cast<const h8*>(a.W[0] + (size_t)row * C);
+            }
+        }
+        float acc[NR], acc_hi[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
+
+        if (NS != 0) {
+#pragma unroll
+            for (int c0 = 0; c0 < NS; c0 += U) {
+                h8 w[NR][U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int v = (c0 + u) * 64 + lane;
+                    const int vc = (c0 + u == NS - 1) ? min(v, vlast) : v;   // only the last slot can overrun
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) w[r][u] = ldw<NT>(rp[r] + vc);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep all NR*U loads ahead of the first use
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int v = (c0 + u) * 64 + lane;
+                    const f4 xl = xlo[v], xh = xhi[v];
+                    if (EPI == EPI_HEAD) {
+                        const bool hi = (v << 3) >= half_c;   // second K half (th.cpp:3549-3568)
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) {
+                            const float p = dot8(w[r][u], xl, xh, 0.f);
+                            acc[r] += hi ? 0.f : p; acc_hi[r] += hi ? p : 0.f;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) acc[r] = dot8(w[r][u], xl, xh, acc[r]);
+                    }
+                }
+            }
+        } else {
+            for (int c0 = 0; c0 < ns; c0 += U) {
+                h8 w[NR][U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (c0 + u < ns) {                       // wave-uniform
+                        const int vc = min((c0 + u) * 64 + lane, vlast);
+#pragma unroll
+                        for (int r = 0; r < NR; ++r) w[r][u] = ldw<NT>(rp[r] + vc);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (c0 + u < ns) {
+                        const int v = (c0 + u) * 64 + lane;
+                        const f4 xl = xlo[v], xh = xhi[v];
+                        if (EPI == EPI_HEAD) {
+                            const bool hi = (v << 3) >= half_c;
+#pragma unroll
+                            for (int r = 0; r < NR; ++r) {
+                                const float p = dot8(w[r][u], xl, xh, 0.f);
+                                acc[r] += hi ? 0.f : p; acc_hi[r] += hi ? p : 0.f;
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < NR; ++r) acc[r] = dot8(w[r][u], xl, xh, acc[r]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { acc[r] = wave_sum(acc[r]); if (EPI == EPI_HEAD) acc_hi[r] = wave_sum(acc_hi[r]); }
+
+        if (EPI == EPI_STORE) {
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) a.y[NR * g + r] = acc[r];
+            }
+        } else if (EPI == EPI_RESID) {       // K11 th.cpp:2136-2147: c = a + b
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) a.y[NR * g + r] = a.resid[NR * g + r] + acc[r];
+            }
+        } else if (EPI == EPI_ROPE_KV) {     // K6 th.cpp:1476-1490 + K/V append th-llama.cpp:332-339
+            if (lane == 0) {
+                const int pos = a.pos_ptr ? *a.pos_ptr : a.pos_val;
+                const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E;
+                float y0 = acc[0], y1 = acc[1 % NR];
+                if (which < 2) {
+                    const int j = rr % a.D;    // even
+                    const float cs = a.rope_tab[((size_t)pos * (a.D >> 1) + (j >> 1)) * 2];
+                    const float sn = a.rope_tab[((size_t)pos * (a.D >> 1) + (j >> 1)) * 2 + 1];
+                    const float t0 = y0 * cs - y1 * sn, t1 = y0 * sn + y1 * cs;
+                    y0 = t0; y1 = t1;
+                }
+                float* dst = which == 0 ? a.y : (which == 1 ? a.kcache + (size_t)pos * a.E : a.vcache + (size_t)pos * a.E);
+                dst[rr] = y0; dst[rr + 1] = y1;
+            }
+        } else if (EPI == EPI_SWIGLU) {      // K12 th.cpp:2706-2707, K13 :2512-2524
+            if (lane == 0) { const float u1 = acc[0]; a.y[g] = (u1 / (1.0f + expf(-u1))) * acc[1 % NR]; }
+        } else {                              // EPI_HEAD: K3 th.cpp:3926-3943 (+Q1 switch)
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int row = NR * g + r;
+                    if (row < a.R) {
+                        const bool covered = !a.lm_faithful || (row % a.q1_split) < a.q1_cov;
+                        const float v = covered ? acc[r] + acc_hi[r] : acc[r];
+                        a.y[row] = v;
+                        const unsigned long long k = argmax_key(v, (unsigned)row);
+                        best = k > best ? k : best;
+                    }
+                }
+            }
+        }
+    }
+    if (EPI == EPI_HEAD) {
+        unsigned long long* wb = reinterpret_cast<unsigned long long*>(red + 4);   // 16-byte aligned
+        __syncthreads();
+        if (lane == 0) wb[wave] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long b = wb[0];
+            for (int w = 1; w < kWaves; ++w) b = wb[w] > b ? wb[w] : b;
+            a.block_best[blockIdx.x] = b;
+        }
+    }
+}
+
+template <int NR, int U, int NS, int PRO, int EPI, int NSP>
+static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_t st) {
+    const int ns = NS ? NS : (((a.C >> 3) + 63) >> 6);
+    const size_t smem = (size_t)ns * 512 * 4 + 128;
+    auto kn = nt ? gemv_kernel<NR, U, NS, PRO, EPI, true, NSP> : gemv_kernel<NR, U, NS, PRO, EPI, false, NSP>;
+    static size_t attr_set[2] = {0, 0};   // per instantiation; first call happens outside graph capture
+    if (smem > 48 * 1024 && smem > attr_set[nt ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set[nt ? 1 : 0] = smem;
+    }
+    hipLaunchKernelGGL(kn, dim3(grid), dim3(kBlock), smem, st, a);
+    return hipGetLastError();
+}
+template <int NR, int U, int NS, int PRO, int EPI>
+static hipError_t launch_gemv_t(const GemvArgs& a, int grid, bool nt, hipStream_t st) {
+    if constexpr (PRO == PRO_ATTN) {
+        switch (a.nsplit) {
+            case 2: return launch_gemv_k<NR, U, NS, PRO, EPI, 2>(a, grid, nt, st);
+            case 4: return launch_gemv_k<NR, U, NS, PRO, EPI, 4>(a, grid, nt, st);
+            case 8: return launch_gemv_k<NR, U, NS, PRO, EPI, 8>(a, grid, nt, st);
+            default: return hipErrorInvalidValue;   // nsplit == 1 uses PRO_COPY on the finished output
+        }
+    } else {
+        return launch_gemv_k<NR, U, NS, PRO, EPI, 0>(a, grid, nt, st);
+    }
+}
+
+// Slot-count class of a column count: compile-time NS for the LLaMA-7B/13B shapes,
+// 0 (run-time loop) for everything else.
+static int ns_class(int C) {
+    switch (C) { case 4096: return 8; case 5120: return 10; case 11008: return 22; case 13824: return 27; default: return 0; }
+}
+// (NR rows per wave iteration, U slots per load batch) variants per class, selectable at run
+// time (tunable "gemv_variant_*") so launch geometry can be swept on the GPU without rebuilding.
+void gemv_variant(int C, int epi, int nru, int* NR, int* U) {
+    const bool pair = (epi == EPI_ROPE_KV || epi == EPI_SWIGLU);
+    static const int t8[4][2] = {{2, 8}, {1, 8}, {2, 4}, {4, 4}};
+    static const int t10[4][2] = {{2, 10}, {1, 10}, {2, 5}, {4, 5}};
+    static const int t22[4][2] = {{2, 11}, {1, 11}, {1, 22}, {2, 11}};
+    static const int t27[4][2] = {{2, 9}, {1, 9}, {1, 27}, {2, 9}};
+    const int (*t)[2] = t8;
+    switch (ns_class(C)) { case 10: t = t10; break; case 22: t = t22; break; case 27: t = t27; break; default: break; }
+    if (nru < 0 || nru > 3) nru = 0;
+    *NR = t[nru][0]; *U = t[nru][1];
+    if (pair && *NR != 2) { *NR = t[0][0]; *U = t[0][1]; }
+}
+
+template <int PRO, int EPI, int NS>
+static hipError_t launch_gemv_ns(int NR, int U, const GemvArgs& a, int grid, bool nt, hipStream_t st) {
+    constexpr bool pair = (EPI == EPI_ROPE_KV || EPI == EPI_SWIGLU);
+#define THK_TRY(nr, u)                                                                      \
+    if constexpr ((NS == 0 || NS % (u) == 0) && (!pair || (nr) == 2)) {                       \
+        if (NR == (nr) && U == (u)) return launch_gemv_t<nr, u, NS, PRO, EPI>(a, grid, nt, st); \
+    }
+    if constexpr (NS == 8 || NS == 0) { THK_TRY(2, 8) THK_TRY(1, 8) THK_TRY(2, 4) THK_TRY(4, 4) }
+    if constexpr (NS == 10) { THK_TRY(2, 10) THK_TRY(1, 10) THK_TRY(2, 5) THK_TRY(4, 5) }
+    if constexpr (NS == 22) { THK_TRY(2, 11) THK_TRY(1, 11) THK_TRY(1, 22) }
+    if constexpr (NS == 27) { THK_TRY(2, 9) THK_TRY(1, 9) THK_TRY(1, 27) }
+#undef THK_TRY
+    return hipErrorInvalidValue;
+}
+
+template <int PRO, int EPI>
+static hipError_t launch_gemv_pe(int nru, const GemvArgs& a, int grid, bool nt, hipStream_t st) {
+    int NR, U; gemv_variant(a.C, EPI, nru, &NR, &U);
+    switch (ns_class(a.C)) {
+        case 8: return launch_gemv_ns<PRO, EPI, 8>(NR, U, a, grid, nt, st);
+        case 10: return launch_gemv_ns<PRO, EPI, 10>(NR, U, a, grid, nt, st);
+        case 22: return launch_gemv_ns<PRO, EPI, 22>(NR, U, a, grid, nt, st);
+        case 27: return launch_gemv_ns<PRO, EPI, 27>(NR, U, a, grid, nt, st);
+        default: return launch_gemv_ns<PRO, EPI, 0>(NR, U, a, grid, nt, st);
+    }
+}
+
+int gemv_rows_per_group(int C, int epi, int nru) {
+    int NR, U; gemv_variant(C, epi, nru, &NR, &U);
+    return NR;
+}
+
+hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, bool nt, hipStream_t st) {
+    if (a.C < 256 || a.C % 256 != 0) return hipErrorInvalidValue;
+    if (epi == EPI_ROPE_KV && pro == PRO_RMS) return launch_gemv_pe<PRO_RMS, EPI_ROPE_KV>(nru, a, grid, nt, st);
+    if (epi == EPI_SWIGLU && pro == PRO_RMS) return launch_gemv_pe<PRO_RMS, EPI_SWIGLU>(nru, a, grid, nt, st);
+    if (epi == EPI_HEAD && pro == PRO_RMS) return launch_gemv_pe<PRO_RMS, EPI_HEAD>(nru, a, grid, nt, st);
+    if (epi == EPI_HEAD && pro == PRO_COPY) return launch_gemv_pe<PRO_COPY, EPI_HEAD>(nru, a, grid, nt, st);
+    if (epi == EPI_RESID && pro == PRO_ATTN) return launch_gemv_pe<PRO_ATTN, EPI_RESID>(nru, a, grid, nt, st);
+    if (epi == EPI_RESID && pro == PRO_COPY) return launch_gemv_pe<PRO_COPY, EPI_RESID>(nru, a, grid, nt, st);
+    if (epi == EPI_STORE && pro == PRO_COPY) return launch_gemv_pe<PRO_COPY, EPI_STORE>(nru, a, grid, nt, st);
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------- attention (decode)
+// grid = H * nsplit blocks; block (h, s) owns positions [s*tc, (s+1)*tc) of head h.
+// A position's head slice is D contiguous floats; D/4 lanes x float4 cover it, so a
+// wave-instruction fetches PPW = 64/(D/4) positions.  Each wave runs an online
+// softmax over its positions, the four waves are merged through LDS, and the block
+// writes (m, l, o[D]) for the split (or the normalised output when nsplit == 1).
+// Scores: S = (q.k) * 1/sqrt(D) scaled after the sum (th.cpp:527-529, th-llama.cpp:518);
+// softmax K10 th.cpp:1901-1957.
+template <int D>
+__global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnArgs a) {
+    constexpr int LPP = D / 4;          // lanes per position
+    constexpr int PPW = 64 / LPP;       // positions per wave-instruction
+    constexpr int UB = 8;               // wave-instructions per batch (K and V each)
+    __shared__ float sm_o[kWaves][D];
+    __shared__ float sm_ml[kWaves][2];
+
+    const int h = blockIdx.x / a.nsplit, s = blockIdx.x - h * a.nsplit;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / LPP, li = lane - grp * LPP;
+    const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + 1;
+    const int E = a.H * D;
+    const int t0 = s * a.tc, t1 = min(t0 + a.tc, T);
+
+    const f4 q = *reinterpret_cast<const f4*>(a.q + h * D + li * 4);
+    const float* kb = a.kcache + h * D + li * 4;
+    const float* vb = a.vcache + h * D + li * 4;
+
+    float m = -INFINITY, l = 0.f;
+    f4 o = {0.f, 0.f, 0.f, 0.f};
+    // wave w takes positions t0 + (it*kWaves + w)*PPW*UB + u*PPW + grp
+    for (int tb = t0 + wave * (PPW * UB); tb < t1; tb += kWaves * PPW * UB) {
+        f4 kv[UB], vv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int t = tb + u * PPW + grp;
+            if (t < t1) kv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(kb + (size_t)t * E));
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int t = tb + u * PPW + grp;
+            if (t < t1) vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(vb + (size_t)t * E));
+        }
+        float sc[UB];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int t = tb + u * PPW + grp;
+            float d = 0.f;
+            if (t < t1) d = q.x * kv[u].x + q.y * kv[u].y + q.z * kv[u].z + q.w * kv[u].w;
+            d = group_sum<LPP>(d) * a.scale;
+            sc[u] = (t < t1) ? d : -INFINITY;
+            bm = fmaxf(bm, sc[u]);
+        }
+        bm = wave_max(bm);                      // wave-uniform, finite (tb < t1 => lane group 0 valid)
+        const float mn = fmaxf(m, bm);
+        const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
+        l *= alpha; o *= alpha;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int t = tb + u * PPW + grp;
+            if (t < t1) {
+                const float p = expf(sc[u] - mn);
+                l += p; o += vv[u] * p;
+            }
+        }
+        m = mn;
+    }
+    // merge the PPW lane groups of the wave (same m): sum l and o across groups
+    if (PPW >= 2) { l += __shfl_xor(l, LPP); o.x += __shfl_xor(o.x, LPP); o.y += __shfl_xor(o.y, LPP); o.z += __shfl_xor(o.z, LPP); o.w += __shfl_xor(o.w, LPP); }
+    if (PPW >= 4) { l += __shfl_xor(l, 2 * LPP); o.x += __shfl_xor(o.x, 2 * LPP); o.y += __shfl_xor(o.y, 2 * LPP); o.z += __shfl_xor(o.z, 2 * LPP); o.w += __shfl_xor(o.w, 2 * LPP); }
+    if (lane < LPP) *reinterpret_cast<f4*>(&sm_o[wave][lane * 4]) = o;
+    if (lane == 0) { sm_ml[wave][0] = m; sm_ml[wave][1] = l; }
+    __syncthreads();
+    if (threadIdx.x < D) {
+        const int d = threadIdx.x;
+        float M = -INFINITY;
+        for (int w = 0; w < kWaves; ++w) M = fmaxf(M, sm_ml[w][0]);
+        float L = 0.f, od = 0.f;
+        for (int w = 0; w < kWaves; ++w) {
+            const float mw = sm_ml[w][0];
+            const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
+            L += sm_ml[w][1] * f; od += sm_o[w][d] * f;
+        }
+        if (a.out) {                     // nsplit == 1: finished output, [H*D]
+            a.out[h * D + d] = od / L;
+        } else {
+            a.part_o[(size_t)(h * a.nsplit + s) * D + d] = od;
+            if (d == 0) { a.part_ml[(h * a.nsplit + s) * 2] = M; a.part_ml[(h * a.nsplit + s) * 2 + 1] = L; }
+        }
+    }
+}
+
+hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
+    const int grid = a.H * a.nsplit;
+    switch (a.D) {
+        case 64: hipLaunchKernelGGL(attn_decode_kernel<64>, dim3(grid), dim3(kBlock), 0, st, a); break;
+        case 128: hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(grid), dim3(kBlock), 0, st, a); break;
+        case 256: hipLaunchKernelGGL(attn_decode_kernel<256>, dim3(grid), dim3(kBlock), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// Stand-alone combine of split partials -> out[H*D] (used by thk_attn_decode when nsplit > 1).
+__global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, float* out,
+                                    int H, int D, int nsplit) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= H * D) return;
+    const int h = e / D, d = e - h * D;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[(h * nsplit + s) * 2]);
+    float L = 0.f, o = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float ms = part_ml[(h * nsplit + s) * 2];
+        const float f = (ms == -INFINITY) ? 0.f : expf(ms - M);
+        L += part_ml[(h * nsplit + s) * 2 + 1] * f; o += part_o[(size_t)(h * nsplit + s) * D + d] * f;
+    }
+    out[e] = o / L;
+}
+hipError_t launch_attn_combine(const float* part_o, const float* part_ml, float* out, int H, int D, int nsplit, hipStream_t st) {
+    const int n = H * D;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, part_o, part_ml, out, H, D, nsplit);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- small element-wise kernels
+// (stand-alone forms of K4,K5,K6,K10,K11,K12,K13 for the operator API; the model path uses the fused forms)
+__global__ __launch_bounds__(kBlock) void rms_norm_kernel(float* x, int N) {
+    __shared__ float red[4];
+    float* row = x + (size_t)blockIdx.x * N;
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < N; i += kBlock) ss += row[i] * row[i];
+    ss = block_sum(ss, red);
+    const float inv = 1.0f / sqrtf(ss / (float)N + 1e-6f);
+    for (int i = threadIdx.x; i < N; i += kBlock) row[i] = row[i] * inv;
+}
+hipError_t launch_rms_norm(float* x, int rows, int N, hipStream_t st) {
+    hipLaunchKernelGGL(rms_norm_kernel, dim3(rows), dim3(kBlock), 0, st, x, N);
+    return hipGetLastError();
+}
+
+__global__ void row_mul_kernel(float* x, const float* __restrict__ g, int N, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) x[i] = x[i] * g[i % N];
+}
+hipError_t launch_row_mul(float* x, const float* g, int rows, int N, hipStream_t st) {
+    const size_t total = (size_t)rows * N;
+    hipLaunchKernelGGL(row_mul_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, g, N, total);
+    return hipGetLastError();
+}
+
+// x viewed [n_tok, H, D]; one thread per (token, head, pair)
+__global__ void rope_kernel(float* x, const float* __restrict__ tab, int n_tok, int H, int D, int n_past) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = D >> 1;
+    if (i >= n_tok * H * half) return;
+    const int jp = i % half, th = i / half, t = th / H;
+    const float cs = tab[((size_t)(n_past + t) * half + jp) * 2], sn = tab[((size_t)(n_past + t) * half + jp) * 2 + 1];
+    float* p = x + (size_t)th * D + 2 * jp;
+    const float x0 = p[0], x1 = p[1];
+    p[0] = x0 * cs - x1 * sn; p[1] = x0 * sn + x1 * cs;
+}
+hipError_t launch_rope(float* x, const float* tab, int n_tok, int H, int D, int n_past, hipStream_t st) {
+    const int n = n_tok * H * (D / 2);
+    hipLaunchKernelGGL(rope_kernel, dim3((n + 255) / 256), dim3(256), 0, st, x, tab, n_tok, H, D, n_past);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(kBlock) void row_softmax_kernel(float* x, int N) {
+    __shared__ float red[4];
+    float* row = x + (size_t)blockIdx.x * N;
+    float mx = -1e14f;   // the reference's "-inf" (th.cpp:1867)
+    for (int i = threadIdx.x; i < N; i += kBlock) mx = fmaxf(mx, row[i]);
+    mx = wave_max(mx);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < N; i += kBlock) { const float e = expf(row[i] - mx); row[i] = e; sum += e; }
+    sum = block_sum(sum, red);
+    for (int i = threadIdx.x; i < N; i += kBlock) row[i] = row[i] / sum;
+}
+hipError_t launch_row_softmax(float* x, int rows, int N, hipStream_t st) {
+    hipLaunchKernelGGL(row_softmax_kernel, dim3(rows), dim3(kBlock), 0, st, x, N);
+    return hipGetLastError();
+}
+
+__global__ void add_kernel(const float* a, const float* b, float* c, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c[i] = a[i] + b[i];
+}
+__global__ void silu_kernel(float* a, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = a[i]; a[i] = v / (1.0f + expf(-v)); }
+}
+__global__ void mul_kernel(float* a, const float* b, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = a[i] * b[i];
+}
+hipError_t launch_add(const float* a, const float* b, float* c, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, c, n); return hipGetLastError();
+}
+hipError_t launch_silu(float* a, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, n); return hipGetLastError();
+}
+hipError_t launch_mul(float* a, const float* b, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, n); return hipGetLastError();
+}
+
+__global__ void kv_append_kernel(float* kc, float* vc, const float* k, const float* v, int pos, int E) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < E) { kc[(size_t)pos * E + i] = k[i]; vc[(size_t)pos * E + i] = v[i]; }
+}
+hipError_t launch_kv_append(float* kc, float* vc, const float* k, const float* v, int pos, int E, hipStream_t st) {
+    hipLaunchKernelGGL(kv_append_kernel, dim3((E + 255) / 256), dim3(256), 0, st, kc, vc, k, v, pos, E); return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- token plumbing
+// Embedding fetch: x = f32(table[token,:]) (loader :185-195, th-llama.cpp:577-584).
+__global__ __launch_bounds__(kBlock) void embed_kernel(const uint16_t* __restrict__ table, const SeqState* st, int token_val,
+                                                       int E, float* x) {
+    const int token = st ? st->token : token_val;
+    const _Float16* row = reinterpret_cast<const _Float16*>(table) + (size_t)token * E;
+    for (int i = threadIdx.x; i < E; i += kBlock) x[i] = (float)row[i];
+}
+hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token_val, int E, float* x, hipStream_t st) {
+    hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(kBlock), 0, st, table, st_dev, token_val, E, x);
+    return hipGetLastError();
+}
+
+// Greedy pick + sequence bookkeeping after the head kernel: reduce the per-block
+// best keys, write the token (first max wins, th-llama.cpp:826-838), log it,
+// advance the position when asked.
+__global__ __launch_bounds__(kBlock) void finish_token_kernel(const unsigned long long* __restrict__ block_best, int nblocks,
+                                                              SeqState* st, int32_t* gen_log, int log_cap,
+                                                              const int* advance_ptr, int32_t* id_out) {
+    __shared__ unsigned long long sm[kBlock];
+    unsigned long long b = 0ull;
+    for (int i = threadIdx.x; i < nblocks; i += kBlock) { const unsigned long long k = block_best[i]; b = k > b ? k : b; }
+    sm[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { const unsigned long long o = sm[threadIdx.x + s]; if (o > sm[threadIdx.x]) sm[threadIdx.x] = o; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int32_t tok = (int32_t)(0xFFFFFFFFu - (unsigned)(sm[0] & 0xFFFFFFFFull));
+        if (id_out) *id_out = tok;
+        if (st) {
+            st->token = tok;
+            if (gen_log && st->n_gen < log_cap) gen_log[st->n_gen] = tok;
+            st->n_gen += 1;
+            if (advance_ptr && *advance_ptr) st->pos += 1;
+        }
+    }
+}
+hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
+                               const int* advance_ptr, int32_t* id_out, hipStream_t st) {
+    hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(kBlock), 0, st, block_best, nblocks, st_dev, gen_log, log_cap, advance_ptr, id_out);
+    return hipGetLastError();
+}
+// Non-head stages only advance the position.
+__global__ void advance_pos_kernel(SeqState* st, const int* advance_ptr) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *advance_ptr) st->pos += 1;
+}
+hipError_t launch_advance_pos(SeqState* st_dev, const int* advance_ptr, hipStream_t st) {
+    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, st, st_dev, advance_ptr);
+    return hipGetLastError();
+}
+
+// Arg-max over a logits vector already in memory (thk_argmax operator).
+__global__ __launch_bounds__(kBlock) void argmax_kernel(const float* __restrict__ logits, int V, unsigned long long* block_best) {
+    __shared__ unsigned long long sm[kBlock];
+    unsigned long long b = 0ull;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < V; i += gridDim.x * kBlock) {
+        const unsigned long long k = argmax_key(logits[i], (unsigned)i); b = k > b ? k : b;
+    }
+    sm[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { const unsigned long long o = sm[threadIdx.x + s]; if (o > sm[threadIdx.x]) sm[threadIdx.x] = o; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_best[blockIdx.x] = sm[0];
+}
+hipError_t launch_argmax(const float* logits, int V, unsigned long long* block_best, int nblocks, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(nblocks), dim3(kBlock), 0, st, logits, V, block_best);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- synthetic tensors
+// Bit-identical twin of oracle/thk_oracle.c synth_value(): integer hash, one f32
+// multiply (+ one add for gains), RNE f16 conversion.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ float synth_value(uint64_t key, uint64_t i, float scale) {
+    const uint64_t h = splitmix64(key + i);
+    const int s = (int)((h & 0xFFFF) + ((h >> 16) & 0xFFFF) + ((h >> 32) & 0xFFFF) + (h >> 48));
+    return __fmul_rn((float)(s - 131070), scale);
+}
+__global__ void synth_f16_kernel(uint64_t key, float scale, size_t n, _Float16* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = (_Float16)synth_value(key, i, scale);
+}
+__global__ void synth_gain_kernel(uint64_t key, float scale, size_t n, float* out) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = __fadd_rn(1.0f, synth_value(key, i, scale));
+}
+hipError_t launch_synth_f16(uint64_t key, float scale, size_t n, void* out, hipStream_t st) {
+    const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(synth_f16_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, key, scale, n, reinterpret_cast<_Float16*>(out));
+    return hipGetLastError();
+}
+hipError_t launch_synth_gain(uint64_t key, float scale, size_t n, float* out, hipStream_t st) {
+    const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(synth_gain_kernel, dim3(grid ? grid : 1), dim3(256), 0, st, key, scale, n, out);
+    return hipGetLastError();
+}
+
+}  // namespace thk

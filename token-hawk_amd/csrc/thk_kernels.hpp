@@ -1,0 +1,82 @@
+// thk_kernels.hpp — launch interface between the C-ABI layer (thk_capi.cpp) and the
+// HIP kernels (thk_kernels.hip, thk_prefill.hip).  Internal; not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace thk {
+
+constexpr int kBlock = 256;   // threads per workgroup (4 waves of 64)
+constexpr int kWaves = 4;
+constexpr int kMaxSplit = 8; // attention context splits per head
+
+// Device-resident per-sequence decode state (read by kernels so one hipGraph serves all tokens).
+struct SeqState {
+    int32_t pos;     // n_past of the token being evaluated (T = pos + 1)
+    int32_t token;   // current input token id / greedy result of the last step
+    int32_t n_gen;   // tokens appended to the log so far
+    int32_t pad;
+};
+
+// prologue / epilogue selectors of the fused mat-vec
+enum { GEMV_PRO_COPY = 0, GEMV_PRO_RMS = 1, GEMV_PRO_ATTN = 2 };
+enum { GEMV_EPI_STORE = 0, GEMV_EPI_RESID = 1, GEMV_EPI_ROPE_KV = 2, GEMV_EPI_SWIGLU = 3, GEMV_EPI_HEAD = 4 };
+
+struct GemvArgs {
+    const uint16_t* W[3];   // f16 row-major [R,C] matrices (see gemv_kernel for their meaning per epilogue)
+    int R;                  // rows of W[0] (STORE/RESID/HEAD)
+    int C;                  // columns (input features), multiple of 256
+    int n_groups;           // row groups to process
+    const float* x;         // PRO_COPY / PRO_RMS input vector f32[C]
+    const float* gain;      // PRO_RMS gain f32[C]
+    float* y;               // output (q for ROPE_KV, u for SWIGLU, logits for HEAD)
+    const float* resid;     // EPI_RESID
+    // EPI_ROPE_KV
+    float* kcache; float* vcache; const float* rope_tab; const int32_t* pos_ptr; int pos_val; int E; int D;
+    // PRO_ATTN
+    const float* part_o; const float* part_ml; int H; int nsplit;
+    // EPI_HEAD
+    int lm_faithful; int q1_split; int q1_cov; unsigned long long* block_best;
+};
+
+struct AttnArgs {
+    const float* q;            // [H*D]
+    const float* kcache;       // [n_ctx, H, D] f32
+    const float* vcache;
+    const int32_t* pos_ptr; int pos_val;   // T = pos + 1
+    int H, D, nsplit, tc;      // tc = positions per split
+    float scale;               // 1/sqrtf(D)
+    float* out;                // non-NULL only when nsplit == 1
+    float* part_o;             // [H, nsplit, D]
+    float* part_ml;            // [H, nsplit, 2]
+};
+
+// nru (0..3) selects the (rows per wave iteration, slots per load batch) variant for the column class of C;
+// see gemv_variant() in thk_kernels.hip.  Row groups = ceil(rows / gemv_rows_per_group).
+int gemv_rows_per_group(int C, int epi, int nru);
+void gemv_variant(int C, int epi, int nru, int* NR, int* U);
+hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, bool nt, hipStream_t st);
+hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
+hipError_t launch_attn_combine(const float* part_o, const float* part_ml, float* out, int H, int D, int nsplit, hipStream_t st);
+hipError_t launch_rms_norm(float* x, int rows, int N, hipStream_t st);
+hipError_t launch_row_mul(float* x, const float* g, int rows, int N, hipStream_t st);
+hipError_t launch_rope(float* x, const float* tab, int n_tok, int H, int D, int n_past, hipStream_t st);
+hipError_t launch_row_softmax(float* x, int rows, int N, hipStream_t st);
+hipError_t launch_add(const float* a, const float* b, float* c, size_t n, hipStream_t st);
+hipError_t launch_silu(float* a, size_t n, hipStream_t st);
+hipError_t launch_mul(float* a, const float* b, size_t n, hipStream_t st);
+hipError_t launch_kv_append(float* kc, float* vc, const float* k, const float* v, int pos, int E, hipStream_t st);
+hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token_val, int E, float* x, hipStream_t st);
+hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
+                               const int* advance_ptr, int32_t* id_out, hipStream_t st);
+hipError_t launch_advance_pos(SeqState* st_dev, const int* advance_ptr, hipStream_t st);
+hipError_t launch_argmax(const float* logits, int V, unsigned long long* block_best, int nblocks, hipStream_t st);
+hipError_t launch_synth_f16(uint64_t key, float scale, size_t n, void* out, hipStream_t st);
+hipError_t launch_synth_gain(uint64_t key, float scale, size_t n, float* out, hipStream_t st);
+
+// thk_prefill.hip
+hipError_t launch_gemm_f16_prefill(const uint16_t* W, int R, int C, const float* X, int M, float* Y, void* workspace, hipStream_t st);
+size_t gemm_prefill_workspace_bytes(int M, int C);
+
+}  // namespace thk
