@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — decode tokens/sec, LLaMA-7B f16, 512-ctx, on N MI355X (BASELINE.json metric).
+
+A "step" = every in-flight sequence advances by one greedy token at n_past = 511 (T = 512,
+the last slot of the n_ctx=512 cache; BASELINE.md protocol: the slot is re-evaluated each
+step, so all K timed steps run at the full context).  N = 1: one sequence, the whole model
+on one GPU.  N > 1: layers pipelined over the ranks (token-hawk_amd/pipeline.py), N sequences
+in flight, RCCL point-to-point hand-off of the hidden state — per-GPU work per step is
+constant, so scaling is "weak" and `value` is the aggregate tokens/s.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) with two extra
+objects: `roofline` (dominant kernel, HBM bound) and `cpu_baseline` (the oracle's fast
+flavour timed on this box's host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6290 GB/s is the float4-copy rate
+COPY_RATE_GBS = 6290.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=200)
+    p.add_argument("--warmup", type=int, default=20)
+    p.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+    p.add_argument("--ctx", type=int, default=512, help="context length T of the timed steps")
+    p.add_argument("--kv-fill", default="prompt", choices=["prompt", "seeded"],
+                   help="prompt: run the 511-token synthetic prompt through the decode path; seeded: (N>1 default off)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-kernel-profile", action="store_true")
+    p.add_argument("--tunable", action="append", default=[], help="name=value (libthk launch-geometry knob)")
+    p.add_argument("--lmhead", default="correct", choices=["correct", "faithful"])
+    return p.parse_args()
+
+
+def model_shape(thk, name):
+    return {"7b": thk.LLAMA_7B, "13b": thk.LLAMA_13B, "tiny": thk.TINY}[name]
+
+
+def synthetic_prompt(shape, T, seq):
+    """BOS + ids uniform in [3, n_vocab), seed = 511 (+ sequence index) — SURVEY.md §8d."""
+    rng = np.random.default_rng(511 + seq)
+    return np.concatenate([[1], rng.integers(3, shape.n_vocab, T - 1)]).astype(np.int32)
+
+
+def cpu_baseline(shape_name, T):
+    """Oracle fast flavour (AVX2/F16C + OpenMP) on a bounded sample of the same workload."""
+    from oracle import oracle as orc
+    oshape = {"7b": orc.LLAMA_7B, "13b": orc.LLAMA_13B, "tiny": orc.TINY}[shape_name]
+    n_sample = min(4, oshape.n_layer)
+    sample_shape = orc.ModelShape(oshape.n_vocab, oshape.n_embd, oshape.n_mult, oshape.n_head, n_sample, oshape.n_ctx)
+    t0 = time.time()
+    m = orc.OracleModel(sample_shape)
+    m.fill_synthetic()
+    steps = 3
+    m.time_decode(min(T, oshape.n_ctx) - 1, n_sample, 1)                       # touch pages
+    tl, th = m.time_decode(min(T, oshape.n_ctx) - 1, n_sample, steps)
+    m.close()
+    per_tok = tl / steps * (oshape.n_layer / n_sample) + th / steps
+    try:
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        cpu_model = "unknown"
+    return {"value": round(1.0 / per_tok, 3), "unit": "tokens/s", "cores": orc.num_threads(), "kind": "port",
+            "sample": f"{n_sample} of {oshape.n_layer} layers + lm-head, {steps} decode steps at T={T}, layer time x{oshape.n_layer // n_sample}; "
+                      f"oracle fast flavour (AVX2+F16C, OpenMP); llama.cpp unavailable; cpu='{cpu_model}'; setup {time.time() - t0:.1f}s"}
+
+
+def kernel_profile(model, shape, T, n_steps=6):
+    """Per-kernel average duration (HIP events on the libthk stream, eager launches)."""
+    agg = {}
+    for _ in range(n_steps):
+        for name, ms in model.profile_step(0):
+            a = agg.setdefault(name, [0.0, 0])
+            a[0] += ms; a[1] += 1
+    E, F, V = shape.n_embd, shape.n_ff, shape.n_vocab
+    alg = {   # algorithmic bytes per launch
+        "norm_qkv_rope_kv": 3 * E * E * 2 + 2 * E * 4 + 2 * E * 4,
+        "attn_decode": 2 * T * E * 4,
+        "attn_wo_resid": E * E * 2,
+        "norm_w13_swiglu": 2 * E * F * 2 + E * 4,
+        "w2_resid": E * F * 2,
+        "norm_lmhead": V * E * 2 + E * 4,
+    }
+    out = {}
+    for name, (tot, n) in agg.items():
+        avg_ms = tot / n
+        out[name] = {"avg_us": round(avg_ms * 1e3, 2), "launches_per_step": n // n_steps,
+                     "alg_bytes": alg.get(name, 0),
+                     "gbs": round(alg.get(name, 0) / (avg_ms * 1e-3) / 1e9, 1) if name in alg and avg_ms > 0 else None}
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
+    N = world
+    thk = graft.load_package()
+    graft.build_libthk()
+    shape = model_shape(thk, args.model)
+    T = min(args.ctx, shape.n_ctx)
+
+    import torch
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    stream = torch.cuda.Stream(device=dev)       # libthk and the RCCL P2P ops share this stream's ordering
+    with torch.cuda.stream(stream):
+        ctx = thk.Context(local_rank, stream=stream.cuda_stream)
+        for kv in args.tunable:
+            k, v = kv.split("=")
+            ctx.set_tunable(k, int(v))
+        info = ctx.device_info()
+        from token_hawk_amd.pipeline import HipStage, PipelineDriver, layer_range
+        S = N
+        t_setup = time.time()
+        if N == 1:
+            model = thk.Model(ctx, shape, n_seq=1)
+            model.fill_synthetic()
+            if args.lmhead == "faithful":
+                model.set_lmhead_mode(thk.THK_LMHEAD_FAITHFUL)
+            model.finalize()
+            stage = None
+        else:
+            stage = HipStage(thk, ctx, shape, rank, N, S, dev)
+            model = stage.model
+        l0, l1 = layer_range(shape.n_layer, rank, N)
+        ctx.sync()
+        log(f"[bench r{rank}] {info['name']} cus={info['n_cu']} layers [{l0},{l1}) model ready in {time.time() - t_setup:.1f}s")
+
+        # ---- fill the KV caches: run the (T-1)-token synthetic prompts through the decode path
+        prompts = np.stack([synthetic_prompt(shape, T, s) for s in range(S)], axis=1)     # [T, S]
+        t_fill = time.time()
+        if N == 1:
+            if T > 1:
+                model.eval(prompts[:T - 1, 0], 0, want_logits=False)
+            model.seq_set(0, int(prompts[T - 1, 0]), T - 1)
+            drv = None
+        else:
+            drv = PipelineDriver(stage, rank, N, S)
+            for s in range(S):
+                stage.set_seq(s, int(prompts[0, s]), 0)
+            if T > 1:
+                drv.run(T - 1, advance=True, forced_tokens=prompts[:T - 1])
+            if rank == 0:
+                for s in range(S):
+                    stage.set_token(s, int(prompts[T - 1, s]))
+        ctx.sync()
+        log(f"[bench r{rank}] KV filled to n_past={T - 1} in {time.time() - t_fill:.2f}s")
+
+        def run_steps(k):
+            if N == 1:
+                for _ in range(k):
+                    model.decode_step(0, advance=False)
+            else:
+                drv.run(k, advance=False)
+
+        run_steps(args.warmup)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(stream)
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        ev1.record(stream)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        ev_ms = ev0.elapsed_time(ev1)
+        if dist is not None:
+            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+
+        tokens = args.steps * S
+        value = tokens / elapsed
+        ms_per_step = elapsed / args.steps * 1e3
+        b_tok = shape.bytes_per_token(T)                       # whole-model algorithmic bytes per token
+        step_gbs = b_tok * value / 1e9 / N                     # per-GPU achieved GB/s over the whole step
+        result = {
+            "metric": "decode tokens/sec, LLaMA-7B f16, 512-ctx, 1/2/4/8 MI355X; % HBM roofline",
+            "value": round(value, 2), "unit": "tokens/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 weights x f32 activations, f32 accumulate, f32 KV",
+            "data": "synthetic (seeded Irwin-Hall~N(0,0.02^2) f16 weights, seeded prompt ids)",
+            "config": {"workload": f"LLaMA-{args.model.upper()} f16, {T}-ctx single-token greedy decode (n_past={T - 1}), "
+                                   f"{'1 sequence' if N == 1 else f'{S} sequences in flight, layers pipelined over {N} GPUs (RCCL p2p)'}",
+                       "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single",
+                       "lmhead_mode": args.lmhead,
+                       "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "gemv_nt", "use_graph")}},
+            "bytes_per_token": b_tok,
+            "step_roofline": {"achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                              "frac_of_copy_rate": round(step_gbs / COPY_RATE_GBS, 4), "event_ms_per_step": round(ev_ms / args.steps, 4)},
+        }
+        if rank == 0:
+            gen, ngen, pos = (model.seq_get(0) if (N == 1) else ([], 0, 0))
+            if N == 1:
+                result["config"]["greedy_tokens_tail"] = [int(t) for t in gen[-4:]]
+                assert pos == T - 1, "hold-position protocol violated"
+
+        # ---- dominant-kernel roofline (rank 0, eager per-kernel HIP-event timing after the timed region)
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
+        if rank == 0 and not args.no_kernel_profile:
+            kp = kernel_profile(model, shape, T)
+            dom = max((k for k in kp if kp[k]["alg_bytes"]), key=lambda k: kp[k]["alg_bytes"] * kp[k]["launches_per_step"])
+            roof.update({"kernel": dom, "achieved": kp[dom]["gbs"], "frac": round(kp[dom]["gbs"] / HBM_PEAK_GBS, 4),
+                         "avg_us": kp[dom]["avg_us"], "alg_bytes_per_launch": kp[dom]["alg_bytes"],
+                         "frac_of_copy_rate": round(kp[dom]["gbs"] / COPY_RATE_GBS, 4)})
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    roof["traffic"] = json.load(open(pmc)).get(dom)
+                except Exception:
+                    pass
+            result["kernels"] = kp
+        result["roofline"] = roof
+
+        if rank == 0 and N == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(args.model, T)
+            except Exception as e:   # the baseline is a report item; never let it kill the GPU number
+                result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        model.close()
+        ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

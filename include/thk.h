@@ -196,7 +196,9 @@ int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* tokens, int32_t 
 
 /* Stream-ordered decode loop (no host round trip per token; what bench.py times).
  * Device-resident per-sequence state: position, current token, generated-token log. */
-int thk_model_seq_set(thk_model* m, int32_t seq, int32_t token, int32_t pos);      /* async H2D */
+int thk_model_seq_set(thk_model* m, int32_t seq, int32_t token, int32_t pos);      /* async; clears the token log */
+/* Override only the next input token (prompt tokens fed through the decode loop). */
+int thk_model_seq_set_token(thk_model* m, int32_t seq, int32_t token);
 /* Enqueue one decode step of sequence `seq` on the stream (graph replay):
  *   embed stage: x = emb[token[seq]]  else x = *hidden_in (dev f32[E])
  *   head stage : logits -> greedy token; token[seq] = it; appended to the log

@@ -1,0 +1,245 @@
+"""GPU parity tests, model level: th_eval_gpu semantics through thk_model_* vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden.npz"))
+LOGIT_TOL = 1e-3   # north_star: logits within 1e-3
+
+
+def make_pair(thk, orc, ctx, shape_name, n_seq=1, lm_mode=0, tunables=None, **kw):
+    shape = getattr(thk, shape_name)
+    old = {}
+    for k, v in (tunables or {}).items():
+        old[k] = ctx.get_tunable(k); ctx.set_tunable(k, v)
+    try:
+        m = thk.Model(ctx, shape, n_seq=n_seq, **kw)
+        m.fill_synthetic()
+        if lm_mode:
+            m.set_lmhead_mode(lm_mode)
+        m.finalize()
+    finally:
+        for k, v in old.items():
+            ctx.set_tunable(k, v)
+    om = orc.OracleModel(getattr(orc, shape_name), n_seq=n_seq)
+    om.fill_synthetic()
+    return m, om
+
+
+@pytest.mark.parametrize("key", ["p1", "p2", "p17"])
+def test_tiny_logits_match_golden_fixture(thk, orc, ctx, key):
+    """HIP path vs the committed golden logits (prompts of 1, 2 and 17 tokens)."""
+    m = thk.Model(ctx, thk.TINY); m.fill_synthetic(); m.finalize()
+    toks = GOLD["tiny_prompt_" + key].tolist()
+    for i, t in enumerate(toks):
+        lg, _ = m.eval([t], i)
+    assert np.abs(lg - GOLD["tiny_logits_" + key]).max() < LOGIT_TOL
+    assert int(lg.argmax()) == int(GOLD["tiny_logits_" + key].argmax())
+    m.close()
+
+
+@pytest.mark.parametrize("splits", [1, 2, 4, 8])
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_tiny_model_every_token_vs_oracle(thk, orc, ctx, splits, use_graph):
+    m, om = make_pair(thk, orc, ctx, "TINY", tunables={"attn_splits": splits, "use_graph": use_graph})
+    rng = np.random.default_rng(splits)
+    toks = [1] + rng.integers(3, 2048, 40).tolist()
+    for i, t in enumerate(toks):
+        lg, hid = m.eval([t], i, want_hidden=True)
+        lo, ho = om.eval(t, i, flags=orc.FAITHFUL_ORDER)
+        assert np.abs(lg - lo).max() < LOGIT_TOL, i
+        assert np.abs(hid - ho).max() < LOGIT_TOL * max(1.0, np.abs(ho).max()), i
+        assert int(lg.argmax()) == orc.greedy(lo)
+    m.close()
+
+
+def test_multi_token_eval_equals_one_by_one(thk, orc, ctx):
+    """th_eval_gpu with n_tokens>1 == tokens fed one at a time (kAllowedSubsequentBatchSize=1)."""
+    m, om = make_pair(thk, orc, ctx, "TINY")
+    toks = [1, 50, 60, 70, 80]
+    lg, _ = m.eval(toks, 0)
+    for i, t in enumerate(toks):
+        lo, _ = om.eval(t, i)
+    assert np.abs(lg - lo).max() < LOGIT_TOL
+    m.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_q1_lmhead_modes(thk, orc, ctx, mode):
+    """faithful|correct lm-head switch at V=32000 where the defect is observable."""
+    m, om = make_pair(thk, orc, ctx, "TINY_Q1", lm_mode=mode)
+    toks = GOLD["tinyq1_prompt"].tolist()
+    for i, t in enumerate(toks):
+        lg, _ = m.eval([t], i)
+        lo, _ = om.eval(t, i, flags=orc.FAITHFUL_ORDER | (orc.LM_FAITHFUL if mode else 0))
+    assert np.abs(lg - lo).max() < LOGIT_TOL
+    gold = GOLD["tinyq1_logits_" + ("faithful" if mode else "correct")]
+    assert np.abs(lg - gold).max() < LOGIT_TOL
+    other = GOLD["tinyq1_logits_" + ("correct" if mode else "faithful")]
+    sk = GOLD["q1_skipped_V32000"]
+    assert np.abs(lg[sk] - other[sk]).max() > 10 * LOGIT_TOL   # the two modes really differ there
+    m.close()
+
+
+def test_device_decode_loop_matches_eval_path(thk, orc, ctx):
+    """Stream-ordered greedy loop (graph replay, no host round trip) == host-driven eval + oracle greedy."""
+    m, om = make_pair(thk, orc, ctx, "TINY")
+    n = 30
+    m.seq_set(0, 1, 0)
+    for _ in range(n):
+        m.decode_step(0, advance=True)
+    gen, ngen, pos = m.seq_get(0)
+    assert ngen == n and pos == n
+    tok, exp = 1, []
+    for i in range(n):
+        lo, _ = om.eval(tok, i)
+        tok = orc.greedy(lo); exp.append(tok)
+    assert gen.tolist() == exp
+    m.close()
+
+
+def test_hold_position_protocol(thk, orc, ctx):
+    """advance=0 re-evaluates the same cache slot (fixed-T benchmark protocol): idempotent logits."""
+    m, om = make_pair(thk, orc, ctx, "TINY")
+    for i, t in enumerate([1, 9, 33]):
+        m.eval([t], i); om.eval(t, i)
+    m.seq_set(0, 77, 3)
+    for _ in range(3):
+        m.decode_step(0, advance=False)
+    gen, ngen, pos = m.seq_get(0)
+    lo, _ = om.eval(77, 3)
+    t1 = orc.greedy(lo)
+    lo2, _ = om.eval(t1, 3)
+    t2 = orc.greedy(lo2)
+    assert pos == 3 and ngen == 3 and gen[0] == t1 and gen[1] == t2
+    m.close()
+
+
+def test_multiple_sequences_are_independent(thk, orc, ctx):
+    m, om = make_pair(thk, orc, ctx, "TINY", n_seq=3)
+    prompts = [[1, 5, 6], [1, 900, 3, 4], [1]]
+    for s, p in enumerate(prompts):
+        for i, t in enumerate(p):
+            lg, _ = m.eval([t], i, seq=s)
+            lo, _ = om.eval(t, i, seq=s)
+        assert np.abs(lg - lo).max() < LOGIT_TOL
+    # interleave: another token on seq 0 after touching the others
+    lg, _ = m.eval([42], 3, seq=0); lo, _ = om.eval(42, 3, seq=0)
+    assert np.abs(lg - lo).max() < LOGIT_TOL
+    m.reset_kv(1)
+    lg, _ = m.eval([1], 0, seq=1); om.reset_kv(1); lo, _ = om.eval(1, 0, seq=1)
+    assert np.abs(lg - lo).max() < LOGIT_TOL
+    m.close()
+
+
+def test_pipeline_stages_on_one_gpu(thk, orc, ctx):
+    """Layer-range stages (config C4 semantics): [0,1) + [1,2) with the hidden hand-off == full model."""
+    shape = thk.TINY
+    full, om = make_pair(thk, orc, ctx, "TINY")
+    a = thk.Model(ctx, shape, 0, 1, flags=thk.THK_STAGE_EMBED); a.fill_synthetic(); a.finalize()
+    b = thk.Model(ctx, shape, 1, 2, flags=thk.THK_STAGE_HEAD); b.fill_synthetic(); b.finalize()
+    for i, t in enumerate([1, 8, 99, 1000]):
+        lg, _ = full.eval([t], i)
+        _, h = a.eval([t], i, want_logits=False, want_hidden=True)
+        lg2, _ = b.eval(None, i, hidden=h)
+        assert np.abs(lg - lg2).max() < 1e-5, i
+    for mm in (full, a, b):
+        mm.close()
+
+
+def test_loaded_tensors_equal_synthetic_fill(thk, orc, ctx):
+    """thk_model_set_tensor (the loader's upload path) with host tensors == device-side synthetic fill."""
+    shape = thk.TINY
+    a = thk.Model(ctx, shape); a.fill_synthetic(); a.finalize()
+    b = thk.Model(ctx, shape)
+    for name, dt, shp in orc.TINY.tensor_specs():
+        n = int(np.prod(shp))
+        arr = orc.synth_f16(name, orc.TENSOR_SEED, orc.TENSOR_SIGMA, n).reshape(shp) if dt == "f16" else \
+            orc.synth_gain(name, orc.TENSOR_SEED, orc.TENSOR_SIGMA, n)
+        b.set_tensor(name, arr)
+    b.finalize()
+    for i, t in enumerate([1, 2, 3]):
+        la, _ = a.eval([t], i); lb, _ = b.eval([t], i)
+        assert (la == lb).all()
+    with pytest.raises(thk.ThkError, match="unknown tensor"):
+        b.set_tensor("layers.0.nope.weight", np.zeros(4, np.float32))
+    with pytest.raises(thk.ThkError, match="shape"):
+        b.set_tensor("norm.weight", np.zeros(7, np.float32))
+    a.close(); b.close()
+
+
+def test_error_paths(thk, ctx):
+    m = thk.Model(ctx, thk.TINY)
+    with pytest.raises(thk.ThkError, match="finalize"):
+        m.eval([1], 0)
+    m.fill_synthetic(); m.finalize()
+    with pytest.raises(thk.ThkError, match="n_ctx"):
+        m.eval([1], thk.TINY.n_ctx)
+    with pytest.raises(thk.ThkError, match="out of range"):
+        m.eval([thk.TINY.n_vocab], 0)
+    with pytest.raises(thk.ThkError):
+        thk.Model(ctx, thk.ModelShape(n_embd=500))
+    m.close()
+
+
+# ------------------------------------------------------------------ 7B / 13B dimensions
+@pytest.mark.parametrize("E,H,L,name", [(4096, 32, 2, "7B-dims"), (5120, 40, 1, "13B-dims")])
+def test_full_width_layers_vs_oracle(thk, orc, ctx, E, H, L, name):
+    """Real 7B/13B row geometry (E, F=11008/13824, V=32000, T up to 512) on a 1-2 layer model:
+    exercises every compile-time-specialised kernel against the oracle's fast flavour."""
+    shape = thk.ModelShape(n_embd=E, n_head=H, n_layer=L)
+    oshape = orc.ModelShape(n_embd=E, n_head=H, n_layer=L)
+    m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    om = orc.OracleModel(oshape); om.fill_synthetic()
+    rng = np.random.default_rng(E)
+    toks = [1] + rng.integers(3, 32000, 5).tolist()
+    for i, t in enumerate(toks):
+        lg, _ = m.eval([t], i); lo, _ = om.eval(t, i, flags=0)
+        assert np.abs(lg - lo).max() < LOGIT_TOL, (name, i)
+        assert int(lg.argmax()) == orc.greedy(lo)
+    m.close(); om.close()
+
+
+def test_7b_full_model_properties(thk, ctx):
+    """Full 7B (13.2 GB of synthetic f16 weights) at T=512 — size-independent properties:
+    determinism, hold-position idempotence, device loop == eval path greedy tokens,
+    two half-models chained == full model."""
+    shape = thk.LLAMA_7B
+    m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    rng = np.random.default_rng(511)
+    prompt = [1] + rng.integers(3, 32000, 15).tolist()
+    lg1, h1 = m.eval(prompt, 0, want_hidden=True)
+    assert np.isfinite(lg1).all() and np.isfinite(h1).all()
+    m.reset_kv(0)
+    lg2, _ = m.eval(prompt, 0)
+    assert (lg1 == lg2).all()                                    # deterministic (no atomics in the data path)
+    # greedy continuation: host-driven vs device loop
+    toks_host, lg = [], lg1
+    for i in range(4):
+        t = int(lg.argmax()); toks_host.append(t)
+        lg, _ = m.eval([t], len(prompt) + i)
+    m.reset_kv(0)
+    m.eval(prompt[:-1], 0, want_logits=False)
+    m.seq_set(0, prompt[-1], len(prompt) - 1)
+    for _ in range(4):
+        m.decode_step(0, advance=True)
+    gen, n, pos = m.seq_get(0)
+    assert gen.tolist() == toks_host and pos == len(prompt) + 3
+    # last cache slot (T=512): finite, idempotent
+    m.seq_set(0, 5, 511)
+    m.decode_step(0, advance=False); a, _, _ = m.seq_get(0)
+    m.seq_set(0, 5, 511)
+    m.decode_step(0, advance=False); b, _, _ = m.seq_get(0)
+    assert a[0] == b[0]
+    m.close()
+    # two chained half-model stages == full model
+    a = thk.Model(ctx, shape, 0, 16, flags=thk.THK_STAGE_EMBED); a.fill_synthetic(); a.finalize()
+    b = thk.Model(ctx, shape, 16, 32, flags=thk.THK_STAGE_HEAD); b.fill_synthetic(); b.finalize()
+    for i, t in enumerate(prompt):
+        _, h = a.eval([t], i, want_logits=False, want_hidden=True)
+        lgp, _ = b.eval(None, i, hidden=h)
+    assert np.abs(lgp - lg1).max() < 1e-5
+    a.close(); b.close()

@@ -286,6 +286,9 @@ class Model:
     def seq_set(self, seq: int, token: int, pos: int):
         self.ctx.check(self.ctx.lib.thk_model_seq_set(self.h, seq, token, pos), "thk_model_seq_set")
 
+    def seq_set_token(self, seq: int, token: int):
+        self.ctx.check(self.ctx.lib.thk_model_seq_set_token(self.h, seq, token), "thk_model_seq_set_token")
+
     def decode_step(self, seq: int = 0, advance: bool = True):
         self.ctx.check(self.ctx.lib.thk_model_decode_step(self.h, seq, int(advance)), "thk_model_decode_step")
 

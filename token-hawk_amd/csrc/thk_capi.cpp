@@ -670,6 +670,9 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
 __global__ void set_seq_state_kernel(SeqState* st, int token, int pos, int reset_gen) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { st->token = token; st->pos = pos; if (reset_gen) st->n_gen = 0; }
 }
+__global__ void set_seq_token_kernel(SeqState* st, int token) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) st->token = token;
+}
 static int set_seq_state(thk_model* m, int seq, int token, int pos, bool reset_gen) {
     hipLaunchKernelGGL(set_seq_state_kernel, dim3(1), dim3(64), 0, m->ctx->stream, m->seqs[seq].st, token, pos, reset_gen ? 1 : 0);
     HIPCHK(m->ctx, hipGetLastError());
@@ -803,6 +806,14 @@ extern "C" int thk_model_seq_set(thk_model* m, int32_t seq, int32_t token, int32
     REQUIRE(m->ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
     REQUIRE(m->ctx, pos >= 0 && pos < m->hp.n_ctx && token >= 0 && token < m->hp.n_vocab, "token %d / pos %d out of range", token, pos);
     return set_seq_state(m, seq, token, pos, true);
+}
+extern "C" int thk_model_seq_set_token(thk_model* m, int32_t seq, int32_t token) {
+    if (!m) return THK_ERR_INVALID;
+    REQUIRE(m->ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
+    REQUIRE(m->ctx, token >= 0 && token < m->hp.n_vocab, "token %d out of range", token);
+    hipLaunchKernelGGL(set_seq_token_kernel, dim3(1), dim3(64), 0, m->ctx->stream, m->seqs[seq].st, token);
+    HIPCHK(m->ctx, hipGetLastError());
+    return THK_OK;
 }
 extern "C" int thk_model_decode_step(thk_model* m, int32_t seq, int advance) {
     if (!m) return THK_ERR_INVALID;

@@ -1,0 +1,125 @@
+"""Layer-pipelined decode across the GPUs of one node (config C4).
+
+Rank r owns layers [r*L/N, (r+1)*L/N); rank 0 also owns the embedding table, rank N-1 the
+final norm + lm-head + greedy pick.  The only inter-rank traffic is the f32 hidden state
+(E*4 bytes) from rank r to r+1 and the 4-byte token id from rank N-1 back to rank 0:
+point-to-point over RCCL/xGMI (torch.distributed backend "nccl" == RCCL); no collective is
+in the data path.  KV caches never move.
+
+Schedule: S = N sequences are in flight.  Work item i = (step k = i // S, sequence s = i % S).
+At micro-step j rank r processes item j - r, so every stage is busy on a different sequence and
+the ring is synchronous: between micro-steps every rank posts ONE send (to r+1) and ONE receive
+(from r-1) in a single grouped batch_isend_irecv, which cannot dead-lock even if sends are
+rendezvous.  All device work is stream-ordered; the host never waits for the GPU inside the loop.
+
+The stage object is duck-typed so the N>1 logic is covered on CPU with gloo (tests/
+test_pipeline_gloo.py supplies an oracle-backed stage); the product stage is HipStage below.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+def layer_range(n_layer: int, rank: int, world: int):
+    """Contiguous split of the layers; the first n_layer % world ranks take one extra."""
+    base, extra = divmod(n_layer, world)
+    l0 = rank * base + min(rank, extra)
+    return l0, l0 + base + (1 if rank < extra else 0)
+
+
+class _CudaView:
+    """Zero-copy torch view of libthk device memory via __cuda_array_interface__."""
+
+    def __init__(self, ptr: int, shape, typestr: str):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class HipStage:
+    """One pipeline stage on one MI355X, backed by thk_model_* (libthk.so)."""
+
+    def __init__(self, thk, ctx, shape, rank: int, world: int, n_seq: int, device: torch.device):
+        l0, l1 = layer_range(shape.n_layer, rank, world)
+        flags = (thk.THK_STAGE_EMBED if rank == 0 else 0) | (thk.THK_STAGE_HEAD if rank == world - 1 else 0)
+        self.model = thk.Model(ctx, shape, l0, l1, flags=flags, n_seq=n_seq)
+        self.model.fill_synthetic()
+        self.model.finalize()
+        self.is_first, self.is_last = rank == 0, rank == world - 1
+        E = shape.n_embd
+        m = self.model
+        self.hidden_in = [torch.as_tensor(_CudaView(m.hidden_in_ptr(s), (E,), "<f4"), device=device) for s in range(n_seq)]
+        self.hidden_out = [torch.as_tensor(_CudaView(m.hidden_out_ptr(s), (E,), "<f4"), device=device) for s in range(n_seq)]
+        self.token = [torch.as_tensor(_CudaView(m.token_dev_ptr(s), (1,), "<i4"), device=device) for s in range(n_seq)]
+
+    def set_seq(self, seq: int, token: int, pos: int):
+        self.model.seq_set(seq, token, pos)
+
+    def set_token(self, seq: int, token: int):
+        self.model.seq_set_token(seq, int(token))
+
+    def step(self, seq: int, advance: bool):
+        self.model.decode_step(seq, advance)
+
+    def generated(self, seq: int):
+        return self.model.seq_get(seq)[0].tolist()
+
+
+@dataclass
+class PipelineResult:
+    items: int          # work items this rank processed
+    micro_steps: int
+
+
+class PipelineDriver:
+    def __init__(self, stage, rank: int, world: int, n_seq: int):
+        assert n_seq == world or world == 1, "the synchronous ring schedule needs one sequence per stage"
+        self.stage, self.rank, self.world, self.S = stage, rank, world, n_seq
+        self.prev, self.next = (rank - 1) % world, (rank + 1) % world
+
+    def _exchange(self, j: int, total: int):
+        """Grouped P2P after micro-step j: send item (j - rank)'s output, receive the input of item (j + 1 - rank)."""
+        st, r, N, S = self.stage, self.rank, self.world, self.S
+        ops = []
+        i_done = j - r                                   # item this rank just finished
+        if 0 <= i_done < total:
+            s = i_done % S
+            if not st.is_last:
+                ops.append(dist.P2POp(dist.isend, st.hidden_out[s], self.next))
+            else:                                        # the token feeds item i_done + S on rank 0 (the ring
+                ops.append(dist.P2POp(dist.isend, st.token[s], self.next))   # stays primed across run() calls)
+        i_prev = j - ((r - 1) % N)                       # item the previous rank just finished
+        if 0 <= i_prev < total:
+            if not st.is_first:
+                ops.append(dist.P2POp(dist.irecv, st.hidden_in[i_prev % S], self.prev))
+            else:
+                ops.append(dist.P2POp(dist.irecv, st.token[i_prev % S], self.prev))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()                                 # stream-ordered for NCCL; blocking for gloo
+
+    def run(self, steps: int, advance: bool, forced_tokens=None) -> PipelineResult:
+        """Advance every sequence by `steps` tokens.  forced_tokens[k][s] (rank 0 only) overrides
+        the fed-back token with a prompt token (prefill through the same path)."""
+        st, r, N, S = self.stage, self.rank, self.world, self.S
+        total = steps * S
+        if N == 1:
+            for i in range(total):
+                k, s = divmod(i, S)
+                if forced_tokens is not None:
+                    st.set_token(s, forced_tokens[k][s])
+                st.step(s, advance)
+            return PipelineResult(total, total)
+        done = 0
+        n_micro = total + N - 1
+        for j in range(n_micro):
+            i = j - r
+            if 0 <= i < total:
+                k, s = divmod(i, S)
+                if st.is_first and forced_tokens is not None:
+                    st.set_token(s, forced_tokens[k][s])
+                st.step(s, advance)
+                done += 1
+            self._exchange(j, total)
+        return PipelineResult(done, n_micro)
