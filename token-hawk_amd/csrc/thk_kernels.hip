@@ -100,136 +100,156 @@ __device__ __forceinline__ int xs_store_index(int i, int ns) {
 // All run with the whole block; on return xs[] holds the activation vector and a
 // __syncthreads() has been executed.
 
-// Each thread owns float4 #(tid + k*256), k < KP, of the (zero padded) vector.  With a
-// compile-time slot count the K loads are issued back to back (one L2 round trip); the
-// run-time form (NS == 0) loops.
+// Each thread owns float4 #(tid + k*256), k < KP, of the (zero padded) vector.  Prologues are
+// split in two phases so the kernel can order its memory traffic:
+//   issue()  - fire all global loads of the activation vector (L2-resident, back to back)
+//   [the kernel then fires the wave's first batch of WEIGHT loads]
+//   finish() - wait for the activation loads only (vmcnt counts in order, so they had to be
+//              issued first), reduce / combine, write LDS, __syncthreads()
+// => the prologue's latency and math hide under the HBM latency of the first weight batch.
+// With a run-time slot count (NS == 0) issue() is empty and finish() loops.
 template <int NS> struct PrologueK { static constexpr int value = NS ? (NS * 128 + kBlock - 1) / kBlock : 1; };
 
 // plain copy (th.cpp K1 with no fused producer)
 template <int NS>
-__device__ __forceinline__ void prologue_copy(float* xs, const float* __restrict__ x, int C, int ns) {
-    if (NS != 0) {
-        constexpr int KP = PrologueK<NS>::value;
-        f4 v[KP];
+struct ProCopy {
+    static constexpr int KP = PrologueK<NS>::value;
+    f4 v[KP];
+    __device__ __forceinline__ void issue(const GemvArgs& a) {
+        if (NS == 0) return;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int i = threadIdx.x + k * kBlock;
-            v[k] = *reinterpret_cast<const f4*>(x + min(i << 2, C - 4));   // branch-free: clamp, then select
-        }
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int i = threadIdx.x + k * kBlock;
-            const f4 o = ((i << 2) < C) ? v[k] : f4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = o;
-        }
-    } else {
-        for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
-            f4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((i << 2) < C) v = *reinterpret_cast<const f4*>(x + (i << 2));
-            *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = v;
-        }
+        for (int k = 0; k < KP; ++k) v[k] = *reinterpret_cast<const f4*>(a.x + min((int)(threadIdx.x + k * kBlock) << 2, a.C - 4));
     }
-    __syncthreads();
-}
+    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns) {
+        const int C = a.C;
+        if (NS != 0) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = threadIdx.x + k * kBlock;
+                const f4 o = ((i << 2) < C) ? v[k] : f4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = o;
+            }
+        } else {
+            for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
+                f4 o = {0.f, 0.f, 0.f, 0.f};
+                if ((i << 2) < C) o = *reinterpret_cast<const f4*>(a.x + (i << 2));
+                *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = o;
+            }
+        }
+        __syncthreads();
+    }
+};
 
 // RMSNorm + gain (K4 th.cpp:1169-1198, K5 :1311-1313): xs = (x * inv) * g
 template <int NS>
-__device__ __forceinline__ void prologue_rms(float* xs, float* red, const float* __restrict__ x,
-                                             const float* __restrict__ gain, int C, int ns) {
-    if (NS != 0) {
-        constexpr int KP = PrologueK<NS>::value;
-        f4 v[KP], g[KP];
+struct ProRms {
+    static constexpr int KP = PrologueK<NS>::value;
+    f4 v[KP], g[KP];
+    __device__ __forceinline__ void issue(const GemvArgs& a) {
+        if (NS == 0) return;
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            const int i = threadIdx.x + k * kBlock;
-            const int ic = min(i << 2, C - 4);                               // branch-free: clamp, then select
-            v[k] = *reinterpret_cast<const f4*>(x + ic); g[k] = *reinterpret_cast<const f4*>(gain + ic);
-        }
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int i = threadIdx.x + k * kBlock;
-            if ((i << 2) >= C) v[k] = f4{0.f, 0.f, 0.f, 0.f};
-        }
-        float ss = 0.f;
-#pragma unroll
-        for (int k = 0; k < KP; ++k) ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
-        ss = block_sum(ss, red);
-        const float inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
-#pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int i = threadIdx.x + k * kBlock;
-            f4 o;
-            o.x = (v[k].x * inv) * g[k].x; o.y = (v[k].y * inv) * g[k].y; o.z = (v[k].z * inv) * g[k].z; o.w = (v[k].w * inv) * g[k].w;
-            *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = o;
-        }
-    } else {
-        float ss = 0.f;
-        for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
-            f4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((i << 2) < C) v = *reinterpret_cast<const f4*>(x + (i << 2));
-            ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-            *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = v;   // raw copy, normalised below
-        }
-        ss = block_sum(ss, red);
-        const float inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
-        for (int i = threadIdx.x; i < (C >> 2); i += kBlock) {
-            const f4 g = *reinterpret_cast<const f4*>(gain + (i << 2));
-            f4* p = reinterpret_cast<f4*>(xs + xs_index(i << 2, ns));
-            f4 v = *p;   // same thread wrote it
-            v.x = (v.x * inv) * g.x; v.y = (v.y * inv) * g.y; v.z = (v.z * inv) * g.z; v.w = (v.w * inv) * g.w;
-            *p = v;
+            const int ic = min((int)(threadIdx.x + k * kBlock) << 2, a.C - 4);     // branch-free: clamp, select later
+            v[k] = *reinterpret_cast<const f4*>(a.x + ic); g[k] = *reinterpret_cast<const f4*>(a.gain + ic);
         }
     }
-    __syncthreads();
-}
+    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float* red, int ns) {
+        const int C = a.C;
+        if (NS != 0) {
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = threadIdx.x + k * kBlock;
+                if ((i << 2) >= C) v[k] = f4{0.f, 0.f, 0.f, 0.f};
+                ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+            }
+            ss = block_sum(ss, red);
+            const float inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = threadIdx.x + k * kBlock;
+                f4 o;
+                o.x = (v[k].x * inv) * g[k].x; o.y = (v[k].y * inv) * g[k].y; o.z = (v[k].z * inv) * g[k].z; o.w = (v[k].w * inv) * g[k].w;
+                *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = o;
+            }
+        } else {
+            float ss = 0.f;
+            for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
+                f4 t = {0.f, 0.f, 0.f, 0.f};
+                if ((i << 2) < C) t = *reinterpret_cast<const f4*>(a.x + (i << 2));
+                ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+                *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = t;   // raw copy, normalised below
+            }
+            ss = block_sum(ss, red);
+            const float inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
+            for (int i = threadIdx.x; i < (C >> 2); i += kBlock) {
+                const f4 gg = *reinterpret_cast<const f4*>(a.gain + (i << 2));
+                f4* p = reinterpret_cast<f4*>(xs + xs_index(i << 2, ns));
+                f4 t = *p;   // same thread wrote it
+                t.x = (t.x * inv) * gg.x; t.y = (t.y * inv) * gg.y; t.z = (t.z * inv) * gg.z; t.w = (t.w * inv) * gg.w;
+                *p = t;
+            }
+        }
+        __syncthreads();
+    }
+};
 
 // Attention split combine: xs[h*D+d] = sum_s o_s[d] * e^{m_s-M} / sum_s l_s * e^{m_s-M}
 // NSP = compile-time split count so all 2*NSP loads of a float4 are issued together.
 template <int NSP>
-__device__ __forceinline__ f4 attn_combine4(const float* __restrict__ part_o, const float* __restrict__ part_ml, int e, int D) {
-    const int h = e / D, d = e - h * D;
-    float ms[NSP], ls[NSP];
-    f4 ov[NSP];
-#pragma unroll
-    for (int s = 0; s < NSP; ++s) {
-        const float2 ml = *reinterpret_cast<const float2*>(part_ml + (h * NSP + s) * 2);
-        ms[s] = ml.x; ls[s] = ml.y;
-        ov[s] = *reinterpret_cast<const f4*>(part_o + (size_t)(h * NSP + s) * D + d);
-    }
+__device__ __forceinline__ f4 attn_merge(const float2 (&ml)[NSP], const f4 (&ov)[NSP]) {
     float M = -INFINITY;
 #pragma unroll
-    for (int s = 0; s < NSP; ++s) M = fmaxf(M, ms[s]);
+    for (int s = 0; s < NSP; ++s) M = fmaxf(M, ml[s].x);
     float L = 0.f; f4 o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < NSP; ++s) {
-        const float sc = (ms[s] == -INFINITY) ? 0.f : expf(ms[s] - M);
-        L += ls[s] * sc; o += ov[s] * sc;
+        const float sc = (ml[s].x == -INFINITY) ? 0.f : expf(ml[s].x - M);
+        L += ml[s].y * sc; o += ov[s] * sc;
     }
     return o * (1.0f / L);
 }
 template <int NS, int NSP>
-__device__ __forceinline__ void prologue_attn(float* xs, const float* __restrict__ part_o,
-                                              const float* __restrict__ part_ml, int H, int D, int ns) {
-    const int C = H * D;
-    if (NS != 0) {
-        constexpr int KP = PrologueK<NS>::value;
+struct ProAttn {
+    static constexpr int KP = PrologueK<NS>::value;
+    float2 ml[KP][NSP];
+    f4 ov[KP][NSP];
+    __device__ __forceinline__ void load1(const GemvArgs& a, int e, float2 (&m)[NSP], f4 (&o)[NSP]) {
+        const int h = e / a.D, d = e - h * a.D;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int i = threadIdx.x + k * kBlock, e = i << 2;
-            f4 res = attn_combine4<NSP>(part_o, part_ml, min(e, C - 4), D);
-            if (e >= C) res = f4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = res;
-        }
-    } else {
-        for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
-            const int e = i << 2;
-            f4 res = {0.f, 0.f, 0.f, 0.f};
-            if (e < C) res = attn_combine4<NSP>(part_o, part_ml, e, D);
-            *reinterpret_cast<f4*>(xs + xs_index(e, ns)) = res;
+        for (int s = 0; s < NSP; ++s) {
+            m[s] = *reinterpret_cast<const float2*>(a.part_ml + (h * NSP + s) * 2);
+            o[s] = *reinterpret_cast<const f4*>(a.part_o + (size_t)(h * NSP + s) * a.D + d);
         }
     }
-    __syncthreads();
-}
+    __device__ __forceinline__ void issue(const GemvArgs& a) {
+        if (NS == 0) return;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) load1(a, min((int)(threadIdx.x + k * kBlock) << 2, a.C - 4), ml[k], ov[k]);
+    }
+    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns) {
+        const int C = a.C;
+        if (NS != 0) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = threadIdx.x + k * kBlock;
+                f4 res = attn_merge<NSP>(ml[k], ov[k]);
+                if ((i << 2) >= C) res = f4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = res;
+            }
+        } else {
+            for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
+                f4 res = {0.f, 0.f, 0.f, 0.f};
+                if ((i << 2) < C) { float2 m[NSP]; f4 o[NSP]; load1(a, i << 2, m, o); res = attn_merge<NSP>(m, o); }
+                *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = res;
+            }
+        }
+        __syncthreads();
+    }
+};
+template <int NS, int PRO, int NSP> struct ProSelect { typedef ProCopy<NS> type; };
+template <int NS, int NSP> struct ProSelect<NS, GEMV_PRO_RMS, NSP> { typedef ProRms<NS> type; };
+template <int NS, int NSP> struct ProSelect<NS, GEMV_PRO_ATTN, NSP> { typedef ProAttn<NS, (NSP > 0 ? NSP : 1)> type; };
 
 // ---------------------------------------------------------------- GEMV core
 enum { PRO_COPY = GEMV_PRO_COPY, PRO_RMS = GEMV_PRO_RMS, PRO_ATTN = GEMV_PRO_ATTN };
@@ -273,11 +293,6 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     float* xs = smem;                 // ns*512 floats
     float* red = smem + (ns << 9);    // floats 0-3: reduction, 4-11: EPI_HEAD scratch, 12-15: dummy store slot
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    if (PRO == PRO_COPY) prologue_copy<NS>(xs, a.x, C, ns);
-    else if (PRO == PRO_RMS) prologue_rms<NS>(xs, red, a.x, a.gain, C, ns);
-    else prologue_attn<NS, (NSP > 0 ? NSP : 1)>(xs, a.part_o, a.part_ml, a.H, a.D, ns);
-
     const int wave_global = blockIdx.x * kWaves + wave;
     const int total_waves = gridDim.x * kWaves;
     const f4* xlo = reinterpret_cast<const f4*>(xs);
@@ -285,10 +300,8 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     const int half_c = C >> 1;
     const int vlast = nvec - 1;
 
-    unsigned long long best = 0ull;   // EPI_HEAD running arg-max of this wave (valid in lane 0)
-
-    for (int g = wave_global; g < a.n_groups; g += total_waves) {
-        const h8* rp[NR];
+    // row pointers of group g (wave-uniform; independent of the activation vector)
+    auto row_ptrs = [&](int g, const h8* (&rp)[NR]) {
         if (EPI == EPI_ROPE_KV) {
             const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E;
             const uint16_t* base = which == 0 ? a.W[0] : (which == 1 ? a.W[1] : a.W[2]);
@@ -304,73 +317,42 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
                 rp[r] = reinterpret_cast<const h8*>(a.W[0] + (size_t)row * C);
             }
         }
-        float acc[NR], acc_hi[NR];
+    };
+    // issue the NR*U 16-byte loads of slots [c0, c0+U) back to back (no branch, no wait)
+    auto load_batch = [&](const h8* const (&rp)[NR], int c0, h8 (&w)[NR][U]) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
-
-        if (NS != 0) {
+        for (int u = 0; u < U; ++u) {
+            const int v = (c0 + u) * 64 + lane;
+            const int vc = (NS == 0 || c0 + u == NS - 1) ? min(v, vlast) : v;   // only the last slot can overrun
 #pragma unroll
-            for (int c0 = 0; c0 < NS; c0 += U) {
-                h8 w[NR][U];
+            for (int r = 0; r < NR; ++r) w[r][u] = ldw<NT>(rp[r] + vc);
+        }
+    };
+    auto compute_batch = [&](int c0, const h8 (&w)[NR][U], float (&acc)[NR], float (&acc_hi)[NR]) {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int v = (c0 + u) * 64 + lane;
-                    const int vc = (c0 + u == NS - 1) ? min(v, vlast) : v;   // only the last slot can overrun
+        for (int u = 0; u < U; ++u) {
+            if (NS == 0 && c0 + u >= ns) break;                 // run-time slot count: wave-uniform
+            const int v = (c0 + u) * 64 + lane;
+            const f4 xl = xlo[v], xh = xhi[v];
+            if (EPI == EPI_HEAD) {
+                const bool hi = (v << 3) >= half_c;             // second K half (th.cpp:3549-3568)
 #pragma unroll
-                    for (int r = 0; r < NR; ++r) w[r][u] = ldw<NT>(rp[r] + vc);
+                for (int r = 0; r < NR; ++r) {
+                    const float p = dot8(w[r][u], xl, xh, 0.f);
+                    acc[r] += hi ? 0.f : p; acc_hi[r] += hi ? p : 0.f;
                 }
-                __builtin_amdgcn_sched_barrier(0);   // keep all NR*U loads ahead of the first use
+            } else {
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int v = (c0 + u) * 64 + lane;
-                    const f4 xl = xlo[v], xh = xhi[v];
-                    if (EPI == EPI_HEAD) {
-                        const bool hi = (v << 3) >= half_c;   // second K half (th.cpp:3549-3568)
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) {
-                            const float p = dot8(w[r][u], xl, xh, 0.f);
-                            acc[r] += hi ? 0.f : p; acc_hi[r] += hi ? p : 0.f;
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) acc[r] = dot8(w[r][u], xl, xh, acc[r]);
-                    }
-                }
-            }
-        } else {
-            for (int c0 = 0; c0 < ns; c0 += U) {
-                h8 w[NR][U];
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (c0 + u < ns) {                       // wave-uniform
-                        const int vc = min((c0 + u) * 64 + lane, vlast);
-#pragma unroll
-                        for (int r = 0; r < NR; ++r) w[r][u] = ldw<NT>(rp[r] + vc);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    if (c0 + u < ns) {
-                        const int v = (c0 + u) * 64 + lane;
-                        const f4 xl = xlo[v], xh = xhi[v];
-                        if (EPI == EPI_HEAD) {
-                            const bool hi = (v << 3) >= half_c;
-#pragma unroll
-                            for (int r = 0; r < NR; ++r) {
-                                const float p = dot8(w[r][u], xl, xh, 0.f);
-                                acc[r] += hi ? 0.f : p; acc_hi[r] += hi ? p : 0.f;
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < NR; ++r) acc[r] = dot8(w[r][u], xl, xh, acc[r]);
-                        }
-                    }
-                }
+                for (int r = 0; r < NR; ++r) acc[r] = dot8(w[r][u], xl, xh, acc[r]);
             }
         }
+    };
+
+    unsigned long long best = 0ull;   // EPI_HEAD running arg-max of this wave (valid in lane 0)
+
+    auto finish_group = [&](int g, float (&acc)[NR], float (&acc_hi)[NR]) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) { acc[r] = wave_sum(acc[r]); if (EPI == EPI_HEAD) acc_hi[r] = wave_sum(acc_hi[r]); }
-
         if (EPI == EPI_STORE) {
             if (lane == 0) {
 #pragma unroll
@@ -413,6 +395,69 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
                 }
             }
         }
+    };
+
+    // --- memory traffic is ordered: activation loads, then the wave's first weight batch (weights
+    // do not depend on the activations), then the prologue math while the weights are in flight.
+    int g = wave_global;
+    const bool has_first = g < a.n_groups;
+    const h8* rp0[NR];
+    h8 w0[NR][U];
+    row_ptrs(has_first ? g : a.n_groups - 1, rp0);   // idle waves (more waves than groups) load a valid row:
+    typename ProSelect<NS, PRO, NSP>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
+    pro.issue(a);
+    __builtin_amdgcn_sched_barrier(0);
+    load_batch(rp0, 0, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    pro.finish(a, xs, red, ns);
+
+    if (has_first) {
+        float acc[NR], acc_hi[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
+        compute_batch(0, w0, acc, acc_hi);
+        if (NS != 0) {
+#pragma unroll
+            for (int c0 = U; c0 < NS; c0 += U) {
+                h8 w[NR][U];
+                load_batch(rp0, c0, w);
+                __builtin_amdgcn_sched_barrier(0);   // keep all NR*U loads ahead of the first use
+                compute_batch(c0, w, acc, acc_hi);
+            }
+        } else {
+            for (int c0 = U; c0 < ns; c0 += U) {
+                h8 w[NR][U];
+                load_batch(rp0, c0, w);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_batch(c0, w, acc, acc_hi);
+            }
+        }
+        finish_group(g, acc, acc_hi);
+        g += total_waves;
+    }
+    for (; g < a.n_groups; g += total_waves) {
+        const h8* rp[NR];
+        row_ptrs(g, rp);
+        float acc[NR], acc_hi[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
+        if (NS != 0) {
+#pragma unroll
+            for (int c0 = 0; c0 < NS; c0 += U) {
+                h8 w[NR][U];
+                load_batch(rp, c0, w);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_batch(c0, w, acc, acc_hi);
+            }
+        } else {
+            for (int c0 = 0; c0 < ns; c0 += U) {
+                h8 w[NR][U];
+                load_batch(rp, c0, w);
+                __builtin_amdgcn_sched_barrier(0);
+                compute_batch(c0, w, acc, acc_hi);
+            }
+        }
+        finish_group(g, acc, acc_hi);
     }
     if (EPI == EPI_HEAD) {
         unsigned long long* wb = reinterpret_cast<unsigned long long*>(red + 4);   // 16-byte aligned
@@ -819,18 +864,30 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
     x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
     return x ^ (x >> 31);
 }
+// The product must be rounded to f32 BEFORE the f16 conversion / the +1 (two roundings, as on the
+// CPU).  hipcc would otherwise contract mul+add into an fma and mul+cvt into a mixed-precision op
+// (observed: 13 of 262,144 f16 values and 0.9 % of gains off by one ulp), so contraction is
+// switched off here and the product is pinned in a VGPR.
 __device__ __forceinline__ float synth_value(uint64_t key, uint64_t i, float scale) {
+#pragma clang fp contract(off)
     const uint64_t h = splitmix64(key + i);
     const int s = (int)((h & 0xFFFF) + ((h >> 16) & 0xFFFF) + ((h >> 32) & 0xFFFF) + (h >> 48));
-    return __fmul_rn((float)(s - 131070), scale);
+    float v = (float)(s - 131070) * scale;
+    asm volatile("" : "+v"(v));
+    return v;
 }
 __global__ void synth_f16_kernel(uint64_t key, float scale, size_t n, _Float16* out) {
+#pragma clang fp contract(off)
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         out[i] = (_Float16)synth_value(key, i, scale);
 }
 __global__ void synth_gain_kernel(uint64_t key, float scale, size_t n, float* out) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-        out[i] = __fadd_rn(1.0f, synth_value(key, i, scale));
+#pragma clang fp contract(off)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float g = 1.0f + synth_value(key, i, scale);
+        asm volatile("" : "+v"(g));
+        out[i] = g;
+    }
 }
 hipError_t launch_synth_f16(uint64_t key, float scale, size_t n, void* out, hipStream_t st) {
     const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);

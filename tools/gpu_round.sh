@@ -15,8 +15,8 @@ for s in $STAGES; do
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -3 gpurun_out/smoke.log ;;
     bench) timeout 900 python bench.py --steps 100 --warmup 10 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?"; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err ;;
     sweep) timeout 900 python tools/sweep.py 7b > gpurun_out/sweep.log 2>&1; echo "sweep exit $?"; tail -25 gpurun_out/sweep.log ;;
-    prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o r01 -- python "$OLDPWD/bench.py" --steps 30 --warmup 5 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err"); echo "prof exit $?"; find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -20 "$f" ;;
-    pmc) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OLDPWD/gpurun_out/pmc_fetch" -o r01 -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-profile --tunable use_graph=0 > /dev/null 2> "$OLDPWD/gpurun_out/pmc.err"); echo "pmc exit $?"; find gpurun_out/pmc_fetch -name "*.csv" | head ;;
+    prof) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o r01 -- python "$OLDPWD/bench.py" --steps 30 --warmup 5 --no-cpu-baseline > "$OLDPWD/gpurun_out/prof_bench.json" 2> "$OLDPWD/gpurun_out/prof.err"); echo "prof exit $?"; find gpurun_out/prof -name "*stats*" | head; f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -20 "$f" ;;
+    pmc) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OLDPWD/gpurun_out/pmc_fetch" -o r01 -- python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline --no-kernel-profile --tunable use_graph=0 > /dev/null 2> "$OLDPWD/gpurun_out/pmc.err"); echo "pmc exit $?"; find gpurun_out/pmc_fetch -name "*.csv" | head ;;
   esac
 done
 ls -la gpurun_out | head -30
