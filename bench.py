@@ -95,6 +95,7 @@ def kernel_profile(model, shape, T, n_steps=6):
         "norm_qkv_rope_kv": 3 * E * E * 2 + 2 * E * 4 + 2 * E * 4,
         "attn_decode": 2 * T * E * 4,
         "attn_wo_resid": E * E * 2,
+        "attn_wo_fused": 2 * T * E * 4 + E * E * 2,
         "norm_w13_swiglu": 2 * E * F * 2 + E * 4,
         "w2_resid": E * F * 2,
         "norm_lmhead": V * E * 2 + E * 4,

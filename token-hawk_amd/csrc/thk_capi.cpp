@@ -14,6 +14,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -60,6 +61,7 @@ struct SeqBuf {
 };
 
 static const int kGenLogCap = 4096;
+static const size_t kFuseStride = 1024;   // words per layer: counter line + kFuseFlags flag lines, padded
 
 struct thk_model {
     thk_ctx* ctx = nullptr;
@@ -82,6 +84,9 @@ struct thk_model {
     int var_qkv = 0, var_wo = 0, var_w13 = 0, var_w2 = 0, var_head = 0;
     int grid_qkv = 0, grid_wo = 0, grid_w13 = 0, grid_w2 = 0, grid_head = 0;
     void* prefill_ws = nullptr; size_t prefill_ws_bytes = 0;
+    // fused attention+wo launch: per-layer arrival counters (zeroed at the start of every step) + error word
+    int fuse_attn_wo = 0, fuse_initial_sleeps = 0, attn_waves = 8;
+    unsigned* fuse_counters = nullptr;   // [n_local_layers] then [1] error
 };
 
 // ---------------------------------------------------------------- helpers
@@ -104,19 +109,23 @@ static int64_t tun(thk_ctx* ctx, const char* name) {
 }
 static void default_tunables(thk_ctx* ctx) {
     ctx->tun["gemv_blocks_per_cu"] = 4;   // resident 256-thread workgroups per CU for the streaming mat-vecs
-    ctx->tun["gemv_bpc_qkv"] = 0;         // per-kernel override (0 = gemv_blocks_per_cu)
-    ctx->tun["gemv_bpc_wo"] = 0;
-    ctx->tun["gemv_bpc_w13"] = 0;
-    ctx->tun["gemv_bpc_w2"] = 0;
-    ctx->tun["gemv_bpc_head"] = 0;
+    // per-kernel overrides (0 = gemv_blocks_per_cu); defaults from tools/sweep.py on MI355X (profiles/)
+    ctx->tun["gemv_bpc_qkv"] = 4;
+    ctx->tun["gemv_bpc_wo"] = 2;
+    ctx->tun["gemv_bpc_w13"] = 8;
+    ctx->tun["gemv_bpc_w2"] = 2;
+    ctx->tun["gemv_bpc_head"] = 8;
     ctx->tun["gemv_variant_qkv"] = 0;     // (rows/iteration, slots/batch) variant, see gemv_variant()
     ctx->tun["gemv_variant_wo"] = 0;
     ctx->tun["gemv_variant_w13"] = 0;
-    ctx->tun["gemv_variant_w2"] = 0;
-    ctx->tun["gemv_variant_head"] = 0;
+    ctx->tun["gemv_variant_w2"] = 2;
+    ctx->tun["gemv_variant_head"] = 1;
     ctx->tun["gemv_nt"] = 1;              // non-temporal weight loads
     ctx->tun["attn_splits"] = 4;          // context splits per head (1,2,4,8)
+    ctx->tun["attn_waves"] = 8;           // waves per attention block (4 or 8)
     ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
+    ctx->tun["fuse_attn_wo"] = 0;         // attention splits + wo mat-vec in one launch (in-launch hand-off)
+    ctx->tun["fuse_initial_sleeps"] = 0;  // consumer s_sleep(32) repetitions (~0.85 us each) before the first poll
 }
 static int grid_for(thk_ctx* ctx, const char* specific, int n_groups) {
     int64_t bpc = tun(ctx, specific);
@@ -344,7 +353,7 @@ extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache
     AttnArgs a{};
     a.q = q; a.kcache = kcache; a.vcache = vcache; a.pos_ptr = nullptr; a.pos_val = (int)T - 1;
     a.H = (int)H; a.D = (int)D; a.nsplit = nsplit; a.tc = (int)((T + nsplit - 1) / nsplit);
-    a.scale = 1.0f / sqrtf((float)D);
+    a.scale = 1.0f / sqrtf((float)D); a.waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
     a.part_o = (float*)ctx->scratch; a.part_ml = a.part_o + (size_t)H * nsplit * D;
     a.out = nsplit == 1 ? out : nullptr;
     HIPCHK(ctx, launch_attn_decode(a, ctx->stream));
@@ -480,7 +489,7 @@ static void free_working(thk_model* m) {
     for (auto& s : m->seqs) free_seq(s);
     m->seqs.clear();
     hipFree(m->x); hipFree(m->q); hipFree(m->u); hipFree(m->attn_out); hipFree(m->part_o); hipFree(m->part_ml); hipFree(m->block_best); hipFree(m->rope_tab);
-    hipFree(m->prefill_ws);
+    hipFree(m->prefill_ws); hipFree(m->fuse_counters); m->fuse_counters = nullptr;
     m->x = m->q = m->u = m->attn_out = m->part_o = m->part_ml = nullptr; m->block_best = nullptr; m->rope_tab = nullptr;
     m->prefill_ws = nullptr; m->prefill_ws_bytes = 0;
     m->finalized = false;
@@ -593,6 +602,10 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
     const bool nt = m->nt != 0;
     const int nl = m->l1 - m->l0;
     const float* xin = sb.hidden_in;
+    if (m->fuse_attn_wo) {
+        MARK("zero_counters");
+        HIPCHK(ctx, hipMemsetAsync(m->fuse_counters, 0, (size_t)nl * kFuseStride * 4, st));   // arrival counters + flags of this step's fused launches
+    }
     if (m->flags & THK_STAGE_EMBED) {
         MARK("embed");
         HIPCHK(ctx, launch_embed(m->tok_embeddings, sb.st, 0, E, m->x, st));
@@ -611,23 +624,30 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             MARK("norm_qkv_rope_kv");
             HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_ROPE_KV, m->var_qkv, a, m->grid_qkv, nt, st));
         }
-        {   // attention over the cache in place   (steps 5-9, th-llama.cpp:341-397)
-            AttnArgs a{};
-            a.q = m->q; a.kcache = kc; a.vcache = vc; a.pos_ptr = &sb.st->pos; a.H = H; a.D = D; a.nsplit = m->nsplit; a.tc = m->tc;
-            a.scale = 1.0f / sqrtf((float)D);
-            a.out = m->nsplit == 1 ? m->attn_out : nullptr; a.part_o = m->part_o; a.part_ml = m->part_ml;
-            MARK("attn_decode");
-            HIPCHK(ctx, launch_attn_decode(a, st));
-        }
-        {   // split combine -> wo -> + residual   (steps 10-11, th-llama.cpp:401-413)
+        {   // attention over the cache in place (steps 5-9, th-llama.cpp:341-397), then
+            // split combine -> wo -> + residual (steps 10-11, th-llama.cpp:401-413)
+            AttnArgs t{};
+            t.q = m->q; t.kcache = kc; t.vcache = vc; t.pos_ptr = &sb.st->pos; t.H = H; t.D = D; t.nsplit = m->nsplit; t.tc = m->tc;
+            t.scale = 1.0f / sqrtf((float)D); t.waves = m->attn_waves;
+            t.out = m->nsplit == 1 ? m->attn_out : nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml;
             GemvArgs a{};
             a.W[0] = L.wo; a.R = E; a.C = E;
             const int NR = gemv_rows_per_group(E, GEMV_EPI_RESID, m->var_wo);
             a.n_groups = (E + NR - 1) / NR;
             a.x = m->attn_out; a.part_o = m->part_o; a.part_ml = m->part_ml; a.H = H; a.D = D; a.nsplit = m->nsplit;
             a.resid = xr_in; a.y = m->x;
-            MARK("attn_wo_resid");
-            HIPCHK(ctx, launch_gemv(m->nsplit == 1 ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, m->var_wo, a, m->grid_wo, nt, st));
+            if (m->fuse_attn_wo) {
+                a.fs.counter = m->fuse_counters + (size_t)i * kFuseStride; a.fs.flags = a.fs.counter + 32;
+                a.fs.target = (unsigned)(H * m->nsplit); a.fs.spin_limit = 1u << 20;
+                a.fs.initial_sleeps = (unsigned)m->fuse_initial_sleeps; a.fs.error = m->fuse_counters + (size_t)nl * kFuseStride;
+                MARK("attn_wo_fused");
+                HIPCHK(ctx, launch_attn_wo(t, a, m->var_wo, m->grid_wo, nt, st));
+            } else {
+                MARK("attn_decode");
+                HIPCHK(ctx, launch_attn_decode(t, st));
+                MARK("attn_wo_resid");
+                HIPCHK(ctx, launch_gemv(m->nsplit == 1 ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, m->var_wo, a, m->grid_wo, nt, st));
+            }
         }
         {   // rms_norm*gain -> w1,w3 -> silu*gate   (steps 12-14, th-llama.cpp:415-438)
             GemvArgs a{};
@@ -706,6 +726,9 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->tc = (int)((T + m->nsplit - 1) / m->nsplit);
     m->nt = tun(ctx, "gemv_nt") != 0;
     m->use_graph = tun(ctx, "use_graph") != 0;
+    m->fuse_initial_sleeps = (int)tun(ctx, "fuse_initial_sleeps");
+    m->attn_waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
+    m->fuse_attn_wo = tun(ctx, "fuse_attn_wo") != 0 && m->nsplit > 1 && (D == 64 || D == 128);
     m->var_qkv = (int)tun(ctx, "gemv_variant_qkv"); m->var_wo = (int)tun(ctx, "gemv_variant_wo");
     m->var_w13 = (int)tun(ctx, "gemv_variant_w13"); m->var_w2 = (int)tun(ctx, "gemv_variant_w2"); m->var_head = (int)tun(ctx, "gemv_variant_head");
     m->grid_qkv = grid_for(ctx, "gemv_bpc_qkv", (int)(3 * E / 2));
@@ -724,6 +747,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
     ALLOCZ(m->part_o, H * kMaxSplit * D * 4); ALLOCZ(m->part_ml, H * kMaxSplit * 2 * 4);
     ALLOCZ(m->block_best, (size_t)(m->grid_head > 0 ? m->grid_head : 1) * 8 + 4096);
     ALLOCZ(m->rope_tab, T * (D / 2) * 2 * 4);
+    ALLOCZ(m->fuse_counters, ((size_t)nl * kFuseStride + 32) * 4);
     {
         std::vector<float> tab;
         build_rope_table(tab, (int)D, 0, (int)T);
@@ -757,6 +781,17 @@ extern "C" int thk_model_finalize(thk_model* m) {
             HIPCHK(ctx, hipGraphInstantiate(&m->seqs[s].exec, m->seqs[s].graph, nullptr, nullptr, 0));
         }
     }
+    return THK_OK;
+}
+
+// Bounded in-launch waits raise a device-side error word instead of hanging; surface it.
+static int check_fuse_error(thk_model* m) {
+    if (!m->fuse_counters) return THK_OK;
+    unsigned e = 0;
+    const int nl = m->l1 - m->l0;
+    HIPCHK(m->ctx, hipMemcpyAsync(&e, m->fuse_counters + (size_t)nl * kFuseStride, 4, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    if (e) return fail(m->ctx, THK_ERR_STATE, "in-launch attention->wo hand-off timed out (device error word %u)", e);
     return THK_OK;
 }
 
@@ -798,7 +833,7 @@ extern "C" int thk_model_eval(thk_model* m, int32_t seq, const int32_t* tokens, 
     if (logits_out) HIPCHK(ctx, hipMemcpyAsync(logits_out, sb.logits, V * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (hidden_inout) HIPCHK(ctx, hipMemcpyAsync(hidden_inout, head ? m->x : sb.hidden_out, E * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return THK_OK;
+    return check_fuse_error(m);
 }
 
 extern "C" int thk_model_seq_set(thk_model* m, int32_t seq, int32_t token, int32_t pos) {
@@ -842,7 +877,7 @@ extern "C" int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out,
     }
     if (n_out) *n_out = h.n_gen;
     if (pos_out) *pos_out = h.pos;
-    return THK_OK;
+    return check_fuse_error(m);
 }
 
 extern "C" int64_t thk_model_bytes_per_token(const thk_model* m, int32_t T) {

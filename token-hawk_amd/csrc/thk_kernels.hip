@@ -96,6 +96,49 @@ __device__ __forceinline__ int xs_store_index(int i, int ns) {
     return (i < (ns << 7)) ? xs_index(i << 2, ns) : (ns << 9) + 12;
 }
 
+// In-launch producer -> consumer hand-off (guide recipe R1): producers publish with write-through
+// (sc1) stores, drain, and bump a device-scope counter; consumers issue their weight loads, poll
+// the counter relaxed (one thread, s_sleep, bounded), then read the payload with sc1 loads.
+// The last-arriving producer (ticket == target-1) raises kFuseFlags replicated flag words, one
+// per 128-byte line, so the consumers' polls are spread over several L2 channels instead of
+// hammering the arrival counter (guide: fan-in / polling-cost rows).
+__device__ __forceinline__ void fuse_signal(const FuseSync& fs) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its sc1 stores
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned ticket = 0;
+        if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(fs.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+        if (ticket == fs.target - 1 && threadIdx.x < kFuseFlags)
+            __hip_atomic_store(fs.flags + threadIdx.x * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void fuse_wait(const FuseSync& fs, int bid) {
+    if (threadIdx.x == 0) {
+        const unsigned* flag = fs.flags + (bid % kFuseFlags) * 32;
+        for (unsigned k = 0; k < fs.initial_sleeps; ++k) __builtin_amdgcn_s_sleep(32);   // producers need a few us anyway
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > fs.spin_limit) { __hip_atomic_store(fs.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ f4 load_f4_sc1(const float* p) {   // two 8-byte agent-scope (sc1) loads
+    const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    f4 r;
+    r.x = __builtin_bit_cast(float, (unsigned)a); r.y = __builtin_bit_cast(float, (unsigned)(a >> 32));
+    r.z = __builtin_bit_cast(float, (unsigned)b); r.w = __builtin_bit_cast(float, (unsigned)(b >> 32));
+    return r;
+}
+__device__ __forceinline__ float2 load_f2_sc1(const float* p) {
+    const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return float2{__builtin_bit_cast(float, (unsigned)a), __builtin_bit_cast(float, (unsigned)(a >> 32))};
+}
+
+
 // ---------------------------------------------------------------- GEMV prologues
 // All run with the whole block; on return xs[] holds the activation vector and a
 // __syncthreads() has been executed.
@@ -115,10 +158,14 @@ template <int NS>
 struct ProCopy {
     static constexpr int KP = PrologueK<NS>::value;
     f4 v[KP];
+    template <bool SC1>
     __device__ __forceinline__ void issue(const GemvArgs& a) {
         if (NS == 0) return;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) v[k] = *reinterpret_cast<const f4*>(a.x + min((int)(threadIdx.x + k * kBlock) << 2, a.C - 4));
+        for (int k = 0; k < KP; ++k) {
+            const float* p = a.x + min((int)(threadIdx.x + k * kBlock) << 2, a.C - 4);
+            v[k] = SC1 ? load_f4_sc1(p) : *reinterpret_cast<const f4*>(p);
+        }
     }
     __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns) {
         const int C = a.C;
@@ -145,12 +192,14 @@ template <int NS>
 struct ProRms {
     static constexpr int KP = PrologueK<NS>::value;
     f4 v[KP], g[KP];
+    template <bool SC1>
     __device__ __forceinline__ void issue(const GemvArgs& a) {
         if (NS == 0) return;
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
             const int ic = min((int)(threadIdx.x + k * kBlock) << 2, a.C - 4);     // branch-free: clamp, select later
-            v[k] = *reinterpret_cast<const f4*>(a.x + ic); g[k] = *reinterpret_cast<const f4*>(a.gain + ic);
+            v[k] = SC1 ? load_f4_sc1(a.x + ic) : *reinterpret_cast<const f4*>(a.x + ic);
+            g[k] = *reinterpret_cast<const f4*>(a.gain + ic);
         }
     }
     __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float* red, int ns) {
@@ -214,18 +263,22 @@ struct ProAttn {
     static constexpr int KP = PrologueK<NS>::value;
     float2 ml[KP][NSP];
     f4 ov[KP][NSP];
+    template <bool SC1>
     __device__ __forceinline__ void load1(const GemvArgs& a, int e, float2 (&m)[NSP], f4 (&o)[NSP]) {
         const int h = e / a.D, d = e - h * a.D;
 #pragma unroll
         for (int s = 0; s < NSP; ++s) {
-            m[s] = *reinterpret_cast<const float2*>(a.part_ml + (h * NSP + s) * 2);
-            o[s] = *reinterpret_cast<const f4*>(a.part_o + (size_t)(h * NSP + s) * a.D + d);
+            const float* pm = a.part_ml + (h * NSP + s) * 2;
+            const float* po = a.part_o + (size_t)(h * NSP + s) * a.D + d;
+            m[s] = SC1 ? load_f2_sc1(pm) : *reinterpret_cast<const float2*>(pm);
+            o[s] = SC1 ? load_f4_sc1(po) : *reinterpret_cast<const f4*>(po);
         }
     }
+    template <bool SC1>
     __device__ __forceinline__ void issue(const GemvArgs& a) {
         if (NS == 0) return;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) load1(a, min((int)(threadIdx.x + k * kBlock) << 2, a.C - 4), ml[k], ov[k]);
+        for (int k = 0; k < KP; ++k) load1<SC1>(a, min((int)(threadIdx.x + k * kBlock) << 2, a.C - 4), ml[k], ov[k]);
     }
     __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns) {
         const int C = a.C;
@@ -240,7 +293,7 @@ struct ProAttn {
         } else {
             for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
                 f4 res = {0.f, 0.f, 0.f, 0.f};
-                if ((i << 2) < C) { float2 m[NSP]; f4 o[NSP]; load1(a, i << 2, m, o); res = attn_merge<NSP>(m, o); }
+                if ((i << 2) < C) { float2 m[NSP]; f4 o[NSP]; load1<false>(a, i << 2, m, o); res = attn_merge<NSP>(m, o); }
                 *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = res;
             }
         }
@@ -284,8 +337,11 @@ __device__ __forceinline__ unsigned long long argmax_key(float v, unsigned idx) 
 // NS = compile-time slot count (C = NS*512 or NS*512-256), 0 = run-time (any C % 256 == 0).
 // U = slots per load batch (NS % U == 0 when NS != 0): NR*U 16-byte loads per lane are issued
 // back to back with no intervening branch or wait.
-template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP>
-__global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
+// bid / nblk: this block's index and the number of blocks working on the op (== blockIdx.x /
+// gridDim.x for a stand-alone launch; a sub-range of the grid inside a fused launch).
+// SYNC: the activation vector is produced by other blocks of the SAME launch (a.fs).
+template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool SYNC>
+__device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, const int nblk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int C = a.C;
     const int nvec = C >> 3;                                  // 16-byte vectors per row
@@ -293,8 +349,8 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     float* xs = smem;                 // ns*512 floats
     float* red = smem + (ns << 9);    // floats 0-3: reduction, 4-11: EPI_HEAD scratch, 12-15: dummy store slot
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wave_global = blockIdx.x * kWaves + wave;
-    const int total_waves = gridDim.x * kWaves;
+    const int wave_global = bid * kWaves + wave;
+    const int total_waves = nblk * kWaves;
     const f4* xlo = reinterpret_cast<const f4*>(xs);
     const f4* xhi = reinterpret_cast<const f4*>(xs + (ns << 8));
     const int half_c = C >> 1;
@@ -405,9 +461,16 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
     h8 w0[NR][U];
     row_ptrs(has_first ? g : a.n_groups - 1, rp0);   // idle waves (more waves than groups) load a valid row:
     typename ProSelect<NS, PRO, NSP>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
-    pro.issue(a);
-    __builtin_amdgcn_sched_barrier(0);
-    load_batch(rp0, 0, w0);
+    if (SYNC) {
+        load_batch(rp0, 0, w0);                      // weights stream in while the producers are still running
+        __builtin_amdgcn_sched_barrier(0);
+        fuse_wait(a.fs, bid);
+        pro.template issue<true>(a);
+    } else {
+        pro.template issue<false>(a);
+        __builtin_amdgcn_sched_barrier(0);
+        load_batch(rp0, 0, w0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     pro.finish(a, xs, red, ns);
 
@@ -467,9 +530,14 @@ __global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
         if (threadIdx.x == 0) {
             unsigned long long b = wb[0];
             for (int w = 1; w < kWaves; ++w) b = wb[w] > b ? wb[w] : b;
-            a.block_best[blockIdx.x] = b;
+            a.block_best[bid] = b;
         }
     }
+}
+
+template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP>
+__global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
+    gemv_body<NR, U, NS, PRO, EPI, NT, NSP, false>(a, blockIdx.x, gridDim.x);
 }
 
 template <int NR, int U, int NS, int PRO, int EPI, int NSP>
@@ -572,15 +640,17 @@ hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, b
 // writes (m, l, o[D]) for the split (or the normalised output when nsplit == 1).
 // Scores: S = (q.k) * 1/sqrt(D) scaled after the sum (th.cpp:527-529, th-llama.cpp:518);
 // softmax K10 th.cpp:1901-1957.
-template <int D>
-__global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnArgs a) {
+// WAVES waves per block share one (head, split): more waves = fewer positions per wave, so every
+// wave needs a single load batch (one HBM round trip) at T = 512 with 4 splits.
+template <int D, int WAVES, bool PUBLISH>
+__device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     constexpr int LPP = D / 4;          // lanes per position
     constexpr int PPW = 64 / LPP;       // positions per wave-instruction
     constexpr int UB = 8;               // wave-instructions per batch (K and V each)
-    __shared__ float sm_o[kWaves][D];
-    __shared__ float sm_ml[kWaves][2];
+    __shared__ float sm_o[WAVES][D];
+    __shared__ float sm_ml[WAVES][2];
 
-    const int h = blockIdx.x / a.nsplit, s = blockIdx.x - h * a.nsplit;
+    const int h = bid / a.nsplit, s = bid - h * a.nsplit;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPP, li = lane - grp * LPP;
     const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + 1;
@@ -593,26 +663,27 @@ __global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnArgs a) {
 
     float m = -INFINITY, l = 0.f;
     f4 o = {0.f, 0.f, 0.f, 0.f};
-    // wave w takes positions t0 + (it*kWaves + w)*PPW*UB + u*PPW + grp
-    for (int tb = t0 + wave * (PPW * UB); tb < t1; tb += kWaves * PPW * UB) {
+    // wave w takes positions t0 + (it*kWaves + w)*PPW*UB + u*PPW + grp.  Loads are branch-free:
+    // positions past the end are clamped to a valid row and masked out of the softmax.
+    for (int tb = t0 + wave * (PPW * UB); tb < t1; tb += WAVES * PPW * UB) {
         f4 kv[UB], vv[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int t = tb + u * PPW + grp;
-            if (t < t1) kv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(kb + (size_t)t * E));
+            const int t = min(tb + u * PPW + grp, t1 - 1);
+            kv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(kb + (size_t)t * E));
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int t = tb + u * PPW + grp;
-            if (t < t1) vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(vb + (size_t)t * E));
+            const int t = min(tb + u * PPW + grp, t1 - 1);
+            vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(vb + (size_t)t * E));
         }
+        __builtin_amdgcn_sched_barrier(0);
         float sc[UB];
         float bm = -INFINITY;
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int t = tb + u * PPW + grp;
-            float d = 0.f;
-            if (t < t1) d = q.x * kv[u].x + q.y * kv[u].y + q.z * kv[u].z + q.w * kv[u].w;
+            float d = q.x * kv[u].x + q.y * kv[u].y + q.z * kv[u].z + q.w * kv[u].w;
             d = group_sum<LPP>(d) * a.scale;
             sc[u] = (t < t1) ? d : -INFINITY;
             bm = fmaxf(bm, sc[u]);
@@ -623,11 +694,8 @@ __global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnArgs a) {
         l *= alpha; o *= alpha;
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            const int t = tb + u * PPW + grp;
-            if (t < t1) {
-                const float p = expf(sc[u] - mn);
-                l += p; o += vv[u] * p;
-            }
+            const float p = expf(sc[u] - mn);   // exp(-inf) == 0 for masked positions
+            l += p; o += vv[u] * p;
         }
         m = mn;
     }
@@ -640,15 +708,21 @@ __global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnArgs a) {
     if (threadIdx.x < D) {
         const int d = threadIdx.x;
         float M = -INFINITY;
-        for (int w = 0; w < kWaves; ++w) M = fmaxf(M, sm_ml[w][0]);
+        for (int w = 0; w < WAVES; ++w) M = fmaxf(M, sm_ml[w][0]);
         float L = 0.f, od = 0.f;
-        for (int w = 0; w < kWaves; ++w) {
+        for (int w = 0; w < WAVES; ++w) {
             const float mw = sm_ml[w][0];
             const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
             L += sm_ml[w][1] * f; od += sm_o[w][d] * f;
         }
         if (a.out) {                     // nsplit == 1: finished output, [H*D]
             a.out[h * D + d] = od / L;
+        } else if (PUBLISH) {            // consumed by other blocks of this launch: write-through stores
+            __hip_atomic_store(a.part_o + (size_t)(h * a.nsplit + s) * D + d, od, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == 0) {
+                __hip_atomic_store(a.part_ml + (h * a.nsplit + s) * 2, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.part_ml + (h * a.nsplit + s) * 2 + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         } else {
             a.part_o[(size_t)(h * a.nsplit + s) * D + d] = od;
             if (d == 0) { a.part_ml[(h * a.nsplit + s) * 2] = M; a.part_ml[(h * a.nsplit + s) * 2 + 1] = L; }
@@ -656,15 +730,93 @@ __global__ __launch_bounds__(kBlock) void attn_decode_kernel(const AttnArgs a) {
     }
 }
 
+template <int D, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(const AttnArgs a) {
+    attn_body<D, WAVES, false>(a, blockIdx.x);
+}
+
+// Fused launch: blocks [0, H*nsplit) run the attention splits and publish their partials; the
+// remaining blocks are the wo mat-vec (split combine prologue, + residual epilogue) whose first
+// weight batch is already in flight while the attention runs.  Producers have the LOWER block
+// ids and never wait, so the launch cannot dead-lock even when the grid is not fully resident.
+template <int D, int NR, int U, int NS, int NSP, bool NT>
+__global__ __launch_bounds__(kBlock) void attn_wo_kernel(const AttnArgs t, const GemvArgs g) {
+    const int na = t.H * t.nsplit;
+    if ((int)blockIdx.x < na) {
+        attn_body<D, kWaves, true>(t, blockIdx.x);
+        fuse_signal(g.fs);
+    } else {
+        gemv_body<NR, U, NS, GEMV_PRO_ATTN, GEMV_EPI_RESID, NT, NSP, true>(g, blockIdx.x - na, gridDim.x - na);
+    }
+}
+
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     const int grid = a.H * a.nsplit;
+    const bool w8 = a.waves == 8;
+#define THK_ATTN(d)                                                                                           \
+    case d:                                                                                                   \
+        if (w8) hipLaunchKernelGGL((attn_decode_kernel<d, 8>), dim3(grid), dim3(512), 0, st, a);              \
+        else hipLaunchKernelGGL((attn_decode_kernel<d, 4>), dim3(grid), dim3(256), 0, st, a);                 \
+        break;
     switch (a.D) {
-        case 64: hipLaunchKernelGGL(attn_decode_kernel<64>, dim3(grid), dim3(kBlock), 0, st, a); break;
-        case 128: hipLaunchKernelGGL(attn_decode_kernel<128>, dim3(grid), dim3(kBlock), 0, st, a); break;
-        case 256: hipLaunchKernelGGL(attn_decode_kernel<256>, dim3(grid), dim3(kBlock), 0, st, a); break;
+        THK_ATTN(64) THK_ATTN(128) THK_ATTN(256)
         default: return hipErrorInvalidValue;
     }
+#undef THK_ATTN
     return hipGetLastError();
+}
+
+template <int D, int NR, int U, int NS, int NSP>
+static hipError_t launch_attn_wo_k(const AttnArgs& t, const GemvArgs& g, int grid_wo, bool nt, hipStream_t st) {
+    const int ns = NS ? NS : (((g.C >> 3) + 63) >> 6);
+    const size_t smem = (size_t)ns * 512 * 4 + 128;
+    auto kn = nt ? attn_wo_kernel<D, NR, U, NS, NSP, true> : attn_wo_kernel<D, NR, U, NS, NSP, false>;
+    static size_t attr_set[2] = {0, 0};
+    if (smem > 48 * 1024 && smem > attr_set[nt ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        attr_set[nt ? 1 : 0] = smem;
+    }
+    hipLaunchKernelGGL(kn, dim3(t.H * t.nsplit + grid_wo), dim3(kBlock), smem, st, t, g);
+    return hipGetLastError();
+}
+template <int D, int NS, int NSP>
+static hipError_t launch_attn_wo_v(int NR, int U, const AttnArgs& t, const GemvArgs& g, int grid_wo, bool nt, hipStream_t st) {
+#define THK_TRY(nr, u)                                                                               \
+    if constexpr (NS == 0 || NS % (u) == 0) {                                                          \
+        if (NR == (nr) && U == (u)) return launch_attn_wo_k<D, nr, u, NS, NSP>(t, g, grid_wo, nt, st); \
+    }
+    if constexpr (NS == 8 || NS == 0) { THK_TRY(2, 8) THK_TRY(1, 8) THK_TRY(2, 4) THK_TRY(4, 4) }
+    if constexpr (NS == 10) { THK_TRY(2, 10) THK_TRY(1, 10) THK_TRY(2, 5) THK_TRY(4, 5) }
+#undef THK_TRY
+    return hipErrorInvalidValue;
+}
+template <int D, int NS>
+static hipError_t launch_attn_wo_s(int NR, int U, const AttnArgs& t, const GemvArgs& g, int grid_wo, bool nt, hipStream_t st) {
+    switch (t.nsplit) {
+        case 2: return launch_attn_wo_v<D, NS, 2>(NR, U, t, g, grid_wo, nt, st);
+        case 4: return launch_attn_wo_v<D, NS, 4>(NR, U, t, g, grid_wo, nt, st);
+        case 8: return launch_attn_wo_v<D, NS, 8>(NR, U, t, g, grid_wo, nt, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+template <int D>
+static hipError_t launch_attn_wo_d(int NR, int U, const AttnArgs& t, const GemvArgs& g, int grid_wo, bool nt, hipStream_t st) {
+    switch (ns_class(g.C)) {
+        case 8: return launch_attn_wo_s<D, 8>(NR, U, t, g, grid_wo, nt, st);
+        case 10: return launch_attn_wo_s<D, 10>(NR, U, t, g, grid_wo, nt, st);
+        case 0: return launch_attn_wo_s<D, 0>(NR, U, t, g, grid_wo, nt, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+hipError_t launch_attn_wo(const AttnArgs& t, const GemvArgs& g, int nru, int grid_wo, bool nt, hipStream_t st) {
+    if (g.C != t.H * t.D || g.C < 256 || g.C % 256 != 0 || t.out != nullptr) return hipErrorInvalidValue;
+    int NR, U; gemv_variant(g.C, GEMV_EPI_RESID, nru, &NR, &U);
+    switch (t.D) {
+        case 64: return launch_attn_wo_d<64>(NR, U, t, g, grid_wo, nt, st);
+        case 128: return launch_attn_wo_d<128>(NR, U, t, g, grid_wo, nt, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 // Stand-alone combine of split partials -> out[H*D] (used by thk_attn_decode when nsplit > 1).

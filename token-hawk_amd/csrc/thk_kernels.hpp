@@ -23,6 +23,17 @@ struct SeqState {
 enum { GEMV_PRO_COPY = 0, GEMV_PRO_RMS = 1, GEMV_PRO_ATTN = 2 };
 enum { GEMV_EPI_STORE = 0, GEMV_EPI_RESID = 1, GEMV_EPI_ROPE_KV = 2, GEMV_EPI_SWIGLU = 3, GEMV_EPI_HEAD = 4 };
 
+// In-launch producer/consumer synchronisation of a fused launch (see fuse_wait / fuse_signal).
+constexpr int kFuseFlags = 16;   // replicated "producers done" flags, 128 bytes apart
+struct FuseSync {
+    unsigned* counter;        // arrival counter, zeroed at the start of every step; producers add 1 each
+    unsigned* flags;          // kFuseFlags words at a 32-word stride, zeroed with the counter; set by the last producer
+    unsigned target;          // number of producer blocks
+    unsigned spin_limit;      // bounded polling: give up (and raise *error) after this many polls
+    unsigned initial_sleeps;  // s_sleep(32) repetitions before the first poll
+    unsigned* error;
+};
+
 struct GemvArgs {
     const uint16_t* W[3];   // f16 row-major [R,C] matrices (see gemv_kernel for their meaning per epilogue)
     int R;                  // rows of W[0] (STORE/RESID/HEAD)
@@ -38,6 +49,8 @@ struct GemvArgs {
     const float* part_o; const float* part_ml; int H; int nsplit;
     // EPI_HEAD
     int lm_faithful; int q1_split; int q1_cov; unsigned long long* block_best;
+    // fused launches only
+    FuseSync fs;
 };
 
 struct AttnArgs {
@@ -46,6 +59,7 @@ struct AttnArgs {
     const float* vcache;
     const int32_t* pos_ptr; int pos_val;   // T = pos + 1
     int H, D, nsplit, tc;      // tc = positions per split
+    int waves;                 // waves per block of the stand-alone kernel (4 or 8)
     float scale;               // 1/sqrtf(D)
     float* out;                // non-NULL only when nsplit == 1
     float* part_o;             // [H, nsplit, D]
@@ -58,6 +72,8 @@ int gemv_rows_per_group(int C, int epi, int nru);
 void gemv_variant(int C, int epi, int nru, int* NR, int* U);
 hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, bool nt, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
+// attention splits + (combine -> wo -> +residual) in ONE launch; grid_wo = number of mat-vec blocks
+hipError_t launch_attn_wo(const AttnArgs& t, const GemvArgs& g, int nru, int grid_wo, bool nt, hipStream_t st);
 hipError_t launch_attn_combine(const float* part_o, const float* part_ml, float* out, int H, int D, int nsplit, hipStream_t st);
 hipError_t launch_rms_norm(float* x, int rows, int N, hipStream_t st);
 hipError_t launch_row_mul(float* x, const float* g, int rows, int N, hipStream_t st);

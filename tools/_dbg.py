@@ -1,16 +1,23 @@
-import sys, numpy as np
+import sys, time, numpy as np
 sys.path.insert(0,'.')
 import __graft_entry__ as g
-from oracle import oracle as orc
 thk = g.load_package()
+T=512
 with thk.Context(0) as ctx:
-    n = 1<<18
-    d = ctx.alloc(n*2)
-    ctx.synth_f16("tok_embeddings.weight", n, d)
-    a = d.download(np.uint16, n); b = orc.synth_f16("tok_embeddings.weight", orc.TENSOR_SEED, orc.TENSOR_SIGMA, n)
-    bad = np.nonzero(a != b)[0]
-    print("mismatch", len(bad), "of", n)
-    print(bad[:10], a[bad[:10]], b[bad[:10]], a[bad[:10]].view(np.float16), b[bad[:10]].view(np.float16))
-    gd = ctx.alloc(4096*4); ctx.synth_gain_f32("norm.weight", 4096, gd)
-    ga = gd.download(np.float32, 4096); gb = orc.synth_gain("norm.weight", orc.TENSOR_SEED, orc.TENSOR_SIGMA, 4096)
-    print("gain mismatch", (ga != gb).sum())
+    m = thk.Model(ctx, thk.LLAMA_7B); m.fill_synthetic()
+    def run(tag, **tun):
+        for k,v in tun.items(): ctx.set_tunable(k,v)
+        m.finalize()
+        m.eval(np.arange(3,11,dtype=np.int32), 0, want_logits=False); m.seq_set(0,5,T-1)
+        agg={}
+        for _ in range(4):
+            for k,ms in m.profile_step(0): agg.setdefault(k,[]).append(ms*1e3)
+        best=0
+        for rep in range(3):
+            for _ in range(5): m.decode_step(0, False)
+            ctx.sync(); t0=time.perf_counter()
+            for _ in range(60): m.decode_step(0, False)
+            ctx.sync(); best=max(best, 60/(time.perf_counter()-t0))
+        print(tag, tun, "tok/s %.1f"%best, {k: round(float(np.mean(v)),1) for k,v in agg.items() if v and np.mean(v)>7}, flush=True)
+    for mb in (0, 8, 16, 32, 64, 0):
+        run("pf", tail_prefetch_mb=mb)

@@ -18,7 +18,7 @@ thk = graft.load_package()
 name = sys.argv[1] if len(sys.argv) > 1 else "7b"
 shape = {"7b": thk.LLAMA_7B, "13b": thk.LLAMA_13B}[name]
 T = 512
-KERN = {"norm_qkv_rope_kv": "qkv", "attn_wo_resid": "wo", "norm_w13_swiglu": "w13", "w2_resid": "w2", "norm_lmhead": "head"}
+KERN = {"norm_qkv_rope_kv": "qkv", "attn_wo_fused": "wo", "norm_w13_swiglu": "w13", "w2_resid": "w2", "norm_lmhead": "head"}
 out = {"model": name, "per_kernel": {}, "graph": []}
 
 with thk.Context(0) as ctx:
@@ -68,10 +68,10 @@ with thk.Context(0) as ctx:
     ctx.set_tunable("gemv_nt", 1)
     # attention splits
     out["attn"] = []
-    for sp in (1, 2, 4, 8):
+    for sp in (2, 4, 8):
         ctx.set_tunable("attn_splits", sp)
         prep(); p = prof()
-        out["attn"].append({"splits": sp, "attn_us": round(p["attn_decode"], 2), "wo_us": round(p["attn_wo_resid"], 2)})
+        out["attn"].append({"splits": sp, "attn_us": round(p.get("attn_decode", 0.0), 2), "wo_us": round(p.get("attn_wo_resid", p.get("attn_wo_fused", 0.0)), 2)})
         print("splits", sp, out["attn"][-1], flush=True)
     best_sp = min(out["attn"], key=lambda r: r["attn_us"] + r["wo_us"])["splits"]
     ctx.set_tunable("attn_splits", best_sp)
