@@ -1,0 +1,145 @@
+"""GPU tests of the C++ host layer: the kept GGML loader + TokenHawk host API over libthk.
+A synthetic ggjt v1 file (tiny model, toy vocabulary) is written, loaded through
+load_llama_file / the streamed capi_* path, and checked against the CPU oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import ggjt
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host(thk):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "token-hawk_amd", "host")])
+    lib = C.CDLL(os.path.join(ROOT, "token-hawk_amd", "libthk_host.so"))
+    lib.thh_last_error.restype = C.c_char_p
+    lib.capi_last_error.restype = C.c_char_p
+    lib.capi_on_human_message.restype = C.c_char_p
+    lib.thh_load_file.restype = C.c_int64
+    lib.thh_load_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.thh_eval.argtypes = [C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.thh_do_inference.argtypes = [C.c_int64, C.c_char_p, C.c_void_p, C.c_char_p, C.c_int]
+    lib.thh_set_sampler.argtypes = [C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float]
+    lib.thh_free.argtypes = [C.c_int64]; lib.thh_reset.argtypes = [C.c_int64]; lib.thh_hparams.argtypes = [C.c_int64, C.c_void_p]
+    lib.capi_model_begin_load.argtypes = [C.c_void_p]
+    lib.capi_load_model_header.argtypes = [C.c_char_p, C.c_double]
+    lib.capi_load_model_weights.argtypes = [C.c_char_p, C.c_double, C.c_double]
+    lib.capi_set_sampler.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
+    return lib
+
+
+@pytest.fixture(scope="module")
+def model_file(orc, tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("ggjt") / "tiny-f16.bin")
+    offs, words, scores = ggjt.write_synthetic_model(path, orc, orc.TINY)
+    return path, offs, words, scores
+
+
+def greedy_reference(orc, words, prompt_ids, n_ctx, max_new=500):
+    om = orc.OracleModel(orc.TINY); om.fill_synthetic()
+    pos, tok, out = 0, None, []
+    for t in prompt_ids:
+        lg, _ = om.eval(t, pos); pos += 1
+    tok = orc.greedy(lg)
+    while tok != 2 and pos < n_ctx and len(out) < max_new:
+        out.append(tok)
+        lg, _ = om.eval(tok, pos); pos += 1
+        tok = orc.greedy(lg)
+    return out, pos
+
+
+def test_load_file_and_eval_match_oracle(host, orc, ctx, model_file):
+    path, _, words, scores = model_file
+    h = host.thh_load_file(ctx.h, path.encode(), 0)
+    assert h > 0, host.thh_last_error()
+    hp = (C.c_int32 * 7)(); host.thh_hparams(h, hp)
+    s = orc.TINY
+    assert list(hp)[:5] == [s.n_vocab, s.n_embd, s.n_mult, s.n_head, s.n_layer]
+    host.thh_set_sampler(h, 40, 0.95, 0.0, 1.1)        # greedy branch of the sampler
+    om = orc.OracleModel(orc.TINY); om.fill_synthetic()
+    logits = np.empty(s.n_vocab, np.float32)
+    for i, t in enumerate([1, 300, 17, 5]):
+        ids = np.array([t], np.int32)
+        tok = host.thh_eval(h, C.c_void_p(ids.ctypes.data), 1, i, C.c_void_p(logits.ctypes.data))
+        lo, _ = om.eval(t, i)
+        assert np.abs(logits - lo).max() < 1e-3
+        assert tok == orc.greedy(lo)
+    host.thh_free(h)
+
+
+def test_do_inference_greedy_matches_oracle(host, orc, ctx, model_file):
+    path, _, words, scores = model_file
+    h = host.thh_load_file(ctx.h, path.encode(), 0)
+    assert h > 0, host.thh_last_error()
+    host.thh_set_sampler(h, 40, 0.95, 0.0, 1.1)
+    n_past = C.c_int32(); text = C.create_string_buffer(1 << 16)
+    n_new = host.thh_do_inference(h, b"hello world", C.byref(n_past), text, len(text))
+    # reference semantics: ' ' is prepended on a fresh context, BOS added (th-llama.cpp:121-125)
+    import test_host_cpu as thc
+    ids = thc.py_tokenize(words, scores, b" hello world", True)
+    exp, pos = greedy_reference(orc, words, ids, orc.TINY.n_ctx)
+    assert n_new == len(exp)
+    assert text.value == b"".join(words[t] for t in exp)
+    assert n_past.value == pos
+    # a second message continues the same context (no leading space, n_past carries on) until n_ctx
+    n2 = host.thh_do_inference(h, b"x", C.byref(n_past), text, len(text))
+    assert n_past.value <= orc.TINY.n_ctx and n2 >= 0
+    host.thh_reset(h)
+    n3 = host.thh_do_inference(h, b"hello world", C.byref(n_past), text, len(text))
+    assert n3 == len(exp) and n_past.value == pos       # reset really clears the KV state
+    host.thh_free(h)
+
+
+def test_streamed_capi_load_matches_file_load(host, orc, ctx, model_file):
+    """capi_model_begin_load / load_model_header / load_model_weights / model_end_load
+    (web/main.cpp:83-157): the file is fed header first, then one tensor record at a time."""
+    path, offs, words, scores = model_file
+    blob = open(path, "rb").read()
+    hp = (C.c_int32 * 7)(); consumed = C.c_int64(); nv = C.c_int32()
+    assert host.thh_parse_header(blob, C.c_int64(len(blob)), hp, C.byref(consumed), C.byref(nv)) == 1
+    assert host.capi_model_begin_load(ctx.h) == 1
+    assert host.capi_load_model_header(blob[:consumed.value], float(consumed.value)) == 1
+    pos = consumed.value
+    name = C.create_string_buffer(128); ty = C.c_int32(); shape = (C.c_int64 * 4)(); ne = (C.c_int64 * 2)()
+    a, b, rb = C.c_int64(), C.c_int64(), C.c_int64()
+    while pos < len(blob):
+        rec = blob[pos:]
+        assert host.thh_parse_tensor(rec, C.c_int64(len(rec)), C.c_int64(pos), name, 128, C.byref(ty), shape, ne, C.byref(a), C.byref(b), C.byref(rb)) == 1
+        assert host.capi_load_model_weights(blob[pos:pos + rb.value], float(pos), float(rb.value)) == 1, host.capi_last_error()
+        pos += rb.value
+    assert host.capi_model_end_load() == 1, host.capi_last_error()
+    host.capi_set_sampler(40, 0.95, 0.0, 1.1)
+    out = host.capi_on_human_message(b"hello world")
+    import test_host_cpu as thc
+    exp, _ = greedy_reference(orc, words, thc.py_tokenize(words, scores, b" hello world", True), orc.TINY.n_ctx)
+    assert out == b"".join(words[t] for t in exp)
+    assert host.capi_on_human_message(b"[cmd] reset") == b"context reset"
+    assert host.capi_on_human_message(b"hello world") == out
+
+
+def test_missing_tensor_is_reported(host, orc, ctx, tmp_path):
+    words, scores = ggjt.toy_vocab(orc.TINY.n_vocab)
+    s = orc.TINY
+    hp = dict(n_vocab=s.n_vocab, n_embd=s.n_embd, n_mult=s.n_mult, n_head=s.n_head, n_layer=s.n_layer, n_rot=64, ftype=1)
+    tensors = [t for t in ggjt.synthetic_model_tensors(orc, s) if t[0] != "layers.1.feed_forward.w2.weight"]
+    path = str(tmp_path / "broken.bin")
+    ggjt.write_ggjt(path, hp, words, scores, tensors)
+    assert host.thh_load_file(ctx.h, path.encode(), 0) == 0
+    assert host.thh_load_file(ctx.h, b"/nonexistent/model.bin", 0) == 0
+
+
+def test_cli_greedy(host, orc, model_file):
+    path, _, words, scores = model_file
+    exe = os.path.join(ROOT, "token-hawk_amd", "thk_cli")
+    r = subprocess.run([exe, "-m", path, "--greedy", "hello world"], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    import test_host_cpu as thc
+    exp, _ = greedy_reference(orc, words, thc.py_tokenize(words, scores, b" hello world", True), orc.TINY.n_ctx)
+    assert r.stdout == b"".join(words[t] for t in exp)
+    assert subprocess.run([exe, "-d", "dir", "x"], capture_output=True).returncode == 2

@@ -1,0 +1,291 @@
+// thk_llama.cpp — tensors, model state, token loop, tokenizer and sampler of the host layer.
+// Behavioural mirror of th.cpp:150-229 / :294-359 and th-llama.cpp:111-238, :464-727, :802-1108,
+// written against the libthk C-ABI.  See thk_host.hpp for what is intentionally different.
+#include "thk_host.hpp"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <limits>
+#include <numeric>
+#include <queue>
+
+namespace th {
+
+// ------------------------------------------------------------------ tensor types
+std::string get_TensorType_name(TensorType dt) {
+    switch (dt) { case TensorType_F16: return "f16"; case TensorType_F32: return "f32"; default: return "unknown"; }
+}
+size_t get_TensorType_size(TensorType dt) { return dt == TensorType_F16 ? 2 : dt == TensorType_F32 ? 4 : 0; }
+
+int64_t TensorShape::get_total_num_elements() const {
+    if (l == 0 && b == 0 && r == 0 && c == 0) return 0;
+    int64_t n = 1;
+    for (int64_t d : {l, b, r, c}) if (d > 0) n *= d;
+    return n;
+}
+std::string TensorShape::to_string() const {
+    return "L:" + std::to_string(l) + " B:" + std::to_string(b) + " R:" + std::to_string(r) + " C:" + std::to_string(c);
+}
+void TensorShape::canonicalize() {
+    if (l == 1) l = 0;
+    if (b == 1) b = 0;
+    if (r == 0) r = 1;
+}
+
+TensorBuffer::TensorBuffer(TensorShape s, TensorType t, thk_ctx* c) : shape(s), originalShape(s), type(t), ctx(c) {
+    if (ctx && get_size_bytes() > 0 && thk_buf_alloc(ctx, get_size_bytes(), &gpu) != THK_OK) gpu = nullptr;
+}
+TensorBuffer::TensorBuffer(const void* data, TensorShape s, TensorType t, bool backup, thk_ctx* c) : TensorBuffer(s, t, c) {
+    if (backup && data) { cpuBackup.resize(get_size_bytes()); memcpy(cpuBackup.data(), data, cpuBackup.size()); }
+    if (gpu && data) upload_data_to_gpu(data);
+}
+TensorBuffer& TensorBuffer::operator=(TensorBuffer&& o) noexcept {
+    if (this != &o) {
+        free_buffers();
+        shape = o.shape; originalShape = o.originalShape; type = o.type; ctx = o.ctx; gpu = o.gpu; cpuBackup = std::move(o.cpuBackup);
+        o.gpu = nullptr; o.shape = {}; o.originalShape = {}; o.type = TensorType_Unknown;
+    }
+    return *this;
+}
+size_t TensorBuffer::get_size_bytes() const { return (size_t)shape.get_total_num_elements() * get_TensorType_size(type); }
+bool TensorBuffer::upload_data_to_gpu(const void* data) { return gpu && thk_buf_upload(ctx, gpu, 0, data, get_size_bytes()) == THK_OK; }
+bool TensorBuffer::download(void* out) const { return gpu && thk_buf_download(ctx, gpu, 0, out, get_size_bytes()) == THK_OK; }
+void TensorBuffer::free_buffers() {
+    if (gpu) { thk_buf_free(ctx, gpu); gpu = nullptr; }
+}
+
+// ------------------------------------------------------------------ fp16 <-> fp32 (th.cpp:312-359)
+// IEEE binary16 <-> binary32 via the exponent-rebias / magic-bias construction GGML uses; exact
+// for every finite value, RNE on narrowing, NaN -> 0x7E00.
+static inline float from_bits(uint32_t w) { float f; memcpy(&f, &w, 4); return f; }
+static inline uint32_t to_bits(float f) { uint32_t w; memcpy(&w, &f, 4); return w; }
+
+float ggml_compute_fp16_to_fp32(ggml_fp16_t h) {
+    const uint32_t w = (uint32_t)h << 16, sign = w & 0x80000000u, two_w = w + w;
+    const float norm = from_bits((two_w >> 4) + (0xE0u << 23)) * 0x1.0p-112f;
+    const float denorm = from_bits((two_w >> 17) | (126u << 23)) - 0.5f;
+    return from_bits(sign | (two_w < (1u << 27) ? to_bits(denorm) : to_bits(norm)));
+}
+ggml_fp16_t ggml_compute_fp32_to_fp16(float f) {
+    float base = (fabsf(f) * 0x1.0p+112f) * 0x1.0p-110f;
+    const uint32_t w = to_bits(f), shl1 = w + w, sign = w & 0x80000000u;
+    uint32_t bias = shl1 & 0xFF000000u;
+    if (bias < 0x71000000u) bias = 0x71000000u;
+    base = from_bits((bias >> 1) + 0x07800000u) + base;
+    const uint32_t bits = to_bits(base);
+    const uint32_t nonsign = ((bits >> 13) & 0x00007C00u) + (bits & 0x00000FFFu);
+    return (ggml_fp16_t)((sign >> 16) | (shl1 > 0xFF000000u ? 0x7E00u : nonsign));
+}
+
+// ------------------------------------------------------------------ timing (th.cpp:23-87)
+double get_time_seconds() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+std::string descriptive_stats(std::vector<double> d, const std::string& unit) {
+    if (d.empty()) return "no samples";
+    std::sort(d.begin(), d.end());
+    const double n = (double)d.size(), mean = std::accumulate(d.begin(), d.end(), 0.0) / n;
+    double var = 0; for (double x : d) var += (x - mean) * (x - mean);
+    auto pct = [&](double p) { return d[(size_t)std::min(n - 1, std::max(0.0, p * (n - 1)))]; };
+    char buf[256];
+    snprintf(buf, sizeof buf, "n=%zu mean=%.3f median=%.3f stddev=%.3f p99=%.3f p95=%.3f p5=%.3f p1=%.3f%s", d.size(), mean, pct(0.5),
+             sqrt(var / n), pct(0.99), pct(0.95), pct(0.05), pct(0.01), unit.c_str());
+    return buf;
+}
+
+// ------------------------------------------------------------------ model
+LlamaModel::~LlamaModel() {
+    if (dev) thk_model_destroy(dev);
+}
+void build_pipelines_llama(thk_ctx*, std::shared_ptr<LlamaModel>) {}   // reference: runtime WGSL compilation (th-llama.cpp:66-76)
+
+static void report_error(LlamaModel& m, const std::string& msg) {
+    fprintf(stderr, "Warning: %s\n", msg.c_str());
+    if (m.onError) m.onError(msg);
+}
+
+void reset_context(std::shared_ptr<LlamaModel> m) {
+    m->n_past = 0; m->n_consumed = 0; m->embd_inp.clear(); m->generatedMessage.clear(); m->lastGeneratedToken = 0;
+    if (m->dev) thk_model_reset_kv(m->dev, 0);
+}
+
+// th_eval_gpu (th-llama.cpp:464-660) + sync_finish_compute's sampling (:662-727): evaluates
+// n_tokens tokens starting at n_past (fed one at a time on the device, as the reference does with
+// kAllowedSubsequentBatchSize = 1), reads the last token's logits back and samples.
+tk_llama_token th_eval(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, const tk_llama_token* tokens, int n_tokens, int n_past) {
+    (void)ctx;
+    if (!m || !m->dev) return 0;
+    m->logits.resize((size_t)m->n_vocab);
+    std::vector<int32_t> ids(tokens, tokens + n_tokens);
+    const int rc = thk_model_eval(m->dev, 0, ids.data(), n_tokens, n_past, nullptr, m->logits.data());
+    if (rc != THK_OK) {
+        report_error(*m, std::string("th_eval failed: ") + thk_last_error(m->ctx));
+        return 0;
+    }
+    static const std::vector<tk_llama_token> none;
+    const SamplerParams& sp = m->sampler;
+    return llama_sample_top_p_top_k(m->rng, m->n_vocab, sp.use_last_n_tokens ? m->last_n_tokens : none, sp.top_k, sp.top_p, sp.temp,
+                                    sp.repeat_penalty, m->logits);
+}
+
+// do_inference (th-llama.cpp:111-168) + sync_continue_inference (:199-238): prepend ' ' on a fresh
+// context, tokenize with BOS, feed the prompt one token per step, then feed back the sampled
+// token.  Unlike the reference the loop stops on EOS (its check reads a vector only the async
+// path fills, Q3) and errors surface through onError.
+void do_inference(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, std::string prompt) {
+    if (!m || !m->dev) return;
+    if (m->n_past >= kMaxOutputTokens) {
+        report_error(*m, "Maximum context reached (" + std::to_string(kMaxContext) + "). Please reset context by typing '[cmd] reset'");
+        return;
+    }
+    if (m->n_past == 0) prompt.insert(0, 1, ' ');
+    m->embd_inp = tk_llama_tokenize(m, prompt, true);
+    m->n_consumed = 0;
+    if ((int)m->embd_inp.size() > kMaxContext - 4) {
+        report_error(*m, "prompt is too long (" + std::to_string(m->embd_inp.size()) + " tokens, max " + std::to_string(kMaxContext - 4) + ")");
+        return;
+    }
+    if (m->last_n_tokens.empty()) m->last_n_tokens.assign(kMaxContext, 0);
+    m->generatedMessage.clear();
+    const int n_ctx = std::min<int>(m->n_ctx, kMaxContext);
+    for (int64_t step = 0; step < kMaxOutputTokens && m->n_past < n_ctx; ++step) {
+        tk_llama_token in;
+        const bool from_prompt = m->n_consumed < (int)m->embd_inp.size();
+        if (from_prompt) {
+            in = m->embd_inp[m->n_consumed++];
+            m->last_n_tokens.erase(m->last_n_tokens.begin());
+            m->last_n_tokens.push_back(in);
+        } else {
+            in = m->lastGeneratedToken;
+        }
+        m->lastGeneratedToken = th_eval(ctx, m, &in, 1, m->n_past);
+        m->n_past += 1;
+        if (m->n_consumed < (int)m->embd_inp.size()) continue;          // still consuming the prompt
+        if (m->lastGeneratedToken == tk_llama_token_eos()) break;
+        const char* str = tk_llama_token_to_str(m, m->lastGeneratedToken);
+        if (str) {
+            m->generatedMessage += str;
+            if (m->onNewToken) m->onNewToken(str, m->generatedMessage);
+        }
+        m->last_n_tokens.erase(m->last_n_tokens.begin());
+        m->last_n_tokens.push_back(m->lastGeneratedToken);
+    }
+    if (m->onInferenceComplete) m->onInferenceComplete(m->generatedMessage);
+}
+
+// ------------------------------------------------------------------ sampler (th-llama.cpp:802-907)
+tk_llama_token llama_sample_top_p_top_k(std::mt19937& rng, int n_vocab, const std::vector<tk_llama_token>& last_n_tokens, int top_k,
+                                        float top_p, float temp, float repeat_penalty, const std::vector<float>& logits) {
+    const float* pl = logits.data() + logits.size() - n_vocab;
+    if (temp <= 0) {   // greedy: first index attaining the maximum
+        int best = 0;
+        for (int i = 1; i < n_vocab; ++i) if (pl[i] > pl[best]) best = i;
+        return best;
+    }
+    std::vector<std::pair<float, tk_llama_token>> cand;
+    cand.reserve(n_vocab);
+    const float scale = 1.0f / temp;
+    for (int i = 0; i < n_vocab; ++i) {
+        float v = pl[i] * scale;
+        if (std::find(last_n_tokens.begin(), last_n_tokens.end(), i) != last_n_tokens.end())   // CTRL repetition penalty
+            v = pl[i] < 0.0f ? pl[i] * scale * repeat_penalty : pl[i] * scale / repeat_penalty;
+        cand.emplace_back(v, i);
+    }
+    if (top_k > 0 && top_k < n_vocab) {
+        std::partial_sort(cand.begin(), cand.begin() + top_k, cand.end(),
+                          [](const std::pair<float, tk_llama_token>& a, const std::pair<float, tk_llama_token>& b) { return a.first > b.first; });
+        cand.resize(top_k);
+    }
+    float maxl = -std::numeric_limits<float>::infinity();
+    for (auto& kv : cand) maxl = std::max(maxl, kv.first);
+    std::vector<float> probs;
+    probs.reserve(cand.size());
+    double sum = 0.0;
+    for (auto& kv : cand) { const float p = expf(kv.first - maxl); probs.push_back(p); sum += p; }
+    for (auto& p : probs) p /= sum;
+    if (top_p < 1.0) {
+        double cum = 0.0;
+        for (int i = 0; i < (int)probs.size(); ++i) {
+            cum += probs[i];
+            if (cum >= top_p) { probs.resize(i + 1); cand.resize(i + 1); break; }
+        }
+        cum = 1.0 / cum;
+        for (auto& p : probs) p *= cum;
+    }
+    std::discrete_distribution<> dist(probs.begin(), probs.end());
+    return cand[dist(rng)].second;
+}
+tk_llama_token llama_sample_top_p_top_k(std::shared_ptr<LlamaModel> m, const std::vector<tk_llama_token>& last_n_tokens, int top_k,
+                                        float top_p, float temp, float repeat_penalty, std::vector<float>& logits) {
+    return llama_sample_top_p_top_k(m->rng, m->n_vocab, last_n_tokens, top_k, top_p, temp, repeat_penalty, logits);
+}
+
+// ------------------------------------------------------------------ tokenizer (th-llama.cpp:910-1108)
+// SentencePiece-style BPE: split into UTF-8 characters, repeatedly merge the adjacent pair whose
+// concatenation is the best-scoring vocabulary entry (ties: leftmost), then map the surviving
+// pieces to ids, falling back to byte tokens (id = byte + 3).
+namespace {
+struct Piece { int prev, next; size_t off, len; };
+struct Merge { int left, right; float score; size_t len; };
+struct MergeOrder {
+    bool operator()(const Merge& a, const Merge& b) const { return a.score < b.score || (a.score == b.score && a.left > b.left); }
+};
+size_t utf8_char_len(unsigned char c) {
+    static const size_t t[16] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 3, 4};
+    return t[c >> 4];
+}
+}  // namespace
+
+std::vector<tk_llama_token> tk_llama_tokenize(const LlamaVocab& vocab, const std::string& text, bool add_bos) {
+    std::vector<tk_llama_token> out;
+    if (text.empty()) return out;
+    if (add_bos) out.push_back(tk_llama_token_bos());
+
+    std::vector<Piece> pcs;
+    for (size_t off = 0; off < text.size();) {
+        const size_t n = std::min(text.size() - off, utf8_char_len((unsigned char)text[off]));
+        pcs.push_back({(int)pcs.size() - 1, 0, off, n});
+        off += n;
+        pcs.back().next = off == text.size() ? -1 : (int)pcs.size();
+    }
+    std::priority_queue<Merge, std::vector<Merge>, MergeOrder> work;
+    auto propose = [&](int l, int r) {
+        if (l < 0 || r < 0) return;
+        const std::string cat = text.substr(pcs[l].off, pcs[l].len + pcs[r].len);
+        auto it = vocab.token_to_id.find(cat);
+        if (it == vocab.token_to_id.end() || (size_t)it->second >= vocab.id_to_token.size()) return;
+        work.push({l, r, vocab.id_to_token[it->second].score, cat.size()});
+    };
+    for (int i = 1; i < (int)pcs.size(); ++i) propose(i - 1, i);
+    while (!work.empty()) {
+        const Merge mg = work.top();
+        work.pop();
+        Piece& L = pcs[mg.left];
+        Piece& R = pcs[mg.right];
+        if (L.len == 0 || R.len == 0 || L.len + R.len != mg.len) continue;   // stale proposal
+        L.len += R.len; R.len = 0;
+        L.next = R.next;
+        if (R.next >= 0) pcs[R.next].prev = mg.left;
+        propose(L.prev, mg.left);
+        propose(mg.left, L.next);
+    }
+    for (int i = 0; i != -1; i = pcs[i].next) {
+        const std::string piece = text.substr(pcs[i].off, pcs[i].len);
+        auto it = vocab.token_to_id.find(piece);
+        if (it != vocab.token_to_id.end()) out.push_back(it->second);
+        else for (unsigned char ch : piece) out.push_back((tk_llama_token)ch + 3);
+    }
+    return out;
+}
+std::vector<tk_llama_token> tk_llama_tokenize(std::shared_ptr<LlamaModel> m, const std::string& text, bool add_bos) {
+    return tk_llama_tokenize(m->vocab, text, add_bos);
+}
+const char* tk_llama_token_to_str(std::shared_ptr<LlamaModel> m, tk_llama_token token) {
+    if (token < 0 || token >= (tk_llama_token)m->vocab.id_to_token.size()) return nullptr;
+    return m->vocab.id_to_token[token].tok.c_str();
+}
+
+}  // namespace th
