@@ -67,6 +67,7 @@ def cpu_baseline(shape_name, T):
     n_sample = min(4, oshape.n_layer)
     sample_shape = orc.ModelShape(oshape.n_vocab, oshape.n_embd, oshape.n_mult, oshape.n_head, n_sample, oshape.n_ctx)
     t0 = time.time()
+    orc.set_num_threads(orc.usable_cpus())          # all usable host cores (affinity mask / cgroup quota aware)
     m = orc.OracleModel(sample_shape)
     m.fill_synthetic()
     steps = 3

@@ -80,11 +80,16 @@ def lib() -> C.CDLL:
             "orc_model_eval": (C.c_int, [vp, C.c_int, i32, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]),
             "orc_model_time_decode": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
             "orc_num_threads": (C.c_int, []),
+            "orc_set_num_threads": (None, [C.c_int]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
         _lib = L
+        # Small models make thousands of tiny OpenMP regions; with one thread per visible CPU on a
+        # 128/256-thread host (or under a cgroup CPU quota) fork/join dominates.  Default to a few
+        # threads; bench.py's cpu_baseline raises it to the usable core count explicitly.
+        L.orc_set_num_threads(min(usable_cpus(), 8))
     return _lib
 
 
@@ -324,6 +329,32 @@ class OracleModel:
         if rc != 0:
             raise RuntimeError("oracle built without OpenMP")
         return a.value, b.value
+
+
+def usable_cpus() -> int:
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def set_num_threads(n: int):
+    lib().orc_set_num_threads(int(n))
 
 
 def num_threads() -> int:

@@ -666,6 +666,13 @@ ORC_API int orc_model_time_decode(orc_model* m, int n_past, int n_layers_sample,
     (void)m; (void)n_past; (void)n_layers_sample; (void)steps; (void)sec_layers; (void)sec_head; return -1;
 #endif
 }
+ORC_API void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 ORC_API int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -41,15 +41,25 @@ def model_file(orc, tmp_path_factory):
     return path, offs, words, scores
 
 
-def greedy_reference(orc, words, prompt_ids, n_ctx, max_new=500):
-    om = orc.OracleModel(orc.TINY); om.fill_synthetic()
-    pos, tok, out = 0, None, []
+def host_shape(orc):
+    """The ggjt file carries no n_ctx: the host model uses LlamaModel's default 512 (th-llama.hpp:105)."""
+    s = orc.TINY
+    return orc.ModelShape(s.n_vocab, s.n_embd, s.n_mult, s.n_head, s.n_layer, 512)
+
+
+def greedy_reference(orc, words, prompt_ids, n_ctx=512, max_steps=500, start_pos=0, om=None):
+    """do_inference semantics: <= 500 evaluations per message (prompt tokens included), stop on EOS or n_ctx."""
+    if om is None:
+        om = orc.OracleModel(host_shape(orc)); om.fill_synthetic()
+    pos, out, steps = start_pos, [], 0
     for t in prompt_ids:
-        lg, _ = om.eval(t, pos); pos += 1
+        lg, _ = om.eval(t, pos); pos += 1; steps += 1
     tok = orc.greedy(lg)
-    while tok != 2 and pos < n_ctx and len(out) < max_new:
+    while tok != 2:
         out.append(tok)
-        lg, _ = om.eval(tok, pos); pos += 1
+        if steps >= max_steps or pos >= n_ctx:
+            break
+        lg, _ = om.eval(tok, pos); pos += 1; steps += 1
         tok = orc.greedy(lg)
     return out, pos
 
@@ -62,7 +72,7 @@ def test_load_file_and_eval_match_oracle(host, orc, ctx, model_file):
     s = orc.TINY
     assert list(hp)[:5] == [s.n_vocab, s.n_embd, s.n_mult, s.n_head, s.n_layer]
     host.thh_set_sampler(h, 40, 0.95, 0.0, 1.1)        # greedy branch of the sampler
-    om = orc.OracleModel(orc.TINY); om.fill_synthetic()
+    om = orc.OracleModel(host_shape(orc)); om.fill_synthetic()
     logits = np.empty(s.n_vocab, np.float32)
     for i, t in enumerate([1, 300, 17, 5]):
         ids = np.array([t], np.int32)
@@ -83,13 +93,13 @@ def test_do_inference_greedy_matches_oracle(host, orc, ctx, model_file):
     # reference semantics: ' ' is prepended on a fresh context, BOS added (th-llama.cpp:121-125)
     import test_host_cpu as thc
     ids = thc.py_tokenize(words, scores, b" hello world", True)
-    exp, pos = greedy_reference(orc, words, ids, orc.TINY.n_ctx)
+    exp, pos = greedy_reference(orc, words, ids)
     assert n_new == len(exp)
     assert text.value == b"".join(words[t] for t in exp)
     assert n_past.value == pos
-    # a second message continues the same context (no leading space, n_past carries on) until n_ctx
+    # the context is now at the reference's 500-position guard: a further message is refused (th-llama.cpp:112-119)
     n2 = host.thh_do_inference(h, b"x", C.byref(n_past), text, len(text))
-    assert n_past.value <= orc.TINY.n_ctx and n2 >= 0
+    assert n2 == 0 and n_past.value == pos and b"Maximum context reached" in host.thh_last_error()
     host.thh_reset(h)
     n3 = host.thh_do_inference(h, b"hello world", C.byref(n_past), text, len(text))
     assert n3 == len(exp) and n_past.value == pos       # reset really clears the KV state
@@ -117,10 +127,11 @@ def test_streamed_capi_load_matches_file_load(host, orc, ctx, model_file):
     host.capi_set_sampler(40, 0.95, 0.0, 1.1)
     out = host.capi_on_human_message(b"hello world")
     import test_host_cpu as thc
-    exp, _ = greedy_reference(orc, words, thc.py_tokenize(words, scores, b" hello world", True), orc.TINY.n_ctx)
+    exp, _ = greedy_reference(orc, words, thc.py_tokenize(words, scores, b" hello world", True))
     assert out == b"".join(words[t] for t in exp)
     assert host.capi_on_human_message(b"[cmd] reset") == b"context reset"
     assert host.capi_on_human_message(b"hello world") == out
+    host.capi_model_unload()
 
 
 def test_missing_tensor_is_reported(host, orc, ctx, tmp_path):
@@ -140,6 +151,6 @@ def test_cli_greedy(host, orc, model_file):
     r = subprocess.run([exe, "-m", path, "--greedy", "hello world"], capture_output=True, timeout=120)
     assert r.returncode == 0, r.stderr
     import test_host_cpu as thc
-    exp, _ = greedy_reference(orc, words, thc.py_tokenize(words, scores, b" hello world", True), orc.TINY.n_ctx)
+    exp, _ = greedy_reference(orc, words, thc.py_tokenize(words, scores, b" hello world", True))
     assert r.stdout == b"".join(words[t] for t in exp)
     assert subprocess.run([exe, "-d", "dir", "x"], capture_output=True).returncode == 2

@@ -15,10 +15,12 @@ using namespace th;
 #define EXPORT extern "C" __attribute__((visibility("default")))
 
 namespace {
-std::shared_ptr<LlamaModel> g_model;          // one model per process, like the reference (web/main.cpp:21-28)
+std::shared_ptr<LlamaModel>& g_model = *new std::shared_ptr<LlamaModel>();   // one model per process, like the reference (web/main.cpp:21-28)
 thk_ctx* g_ctx = nullptr;
 std::string g_transcript, g_last_error;
-std::map<int64_t, std::shared_ptr<LlamaModel>> g_handles;
+// heap-allocated and never destroyed: models must not be torn down at static-destruction time,
+// when the caller's thk_ctx is already gone
+std::map<int64_t, std::shared_ptr<LlamaModel>>& g_handles = *new std::map<int64_t, std::shared_ptr<LlamaModel>>();
 int64_t g_next_handle = 1;
 }  // namespace
 
@@ -45,6 +47,7 @@ EXPORT const char* capi_on_human_message(const char* message) {
     return g_transcript.c_str();
 }
 EXPORT const char* capi_last_error() { return g_last_error.c_str(); }
+EXPORT void capi_model_unload() { g_model.reset(); }
 EXPORT void capi_set_sampler(int top_k, float top_p, float temp, float repeat_penalty) {
     if (g_model) g_model->sampler = SamplerParams{top_k, top_p, temp, repeat_penalty, false};
 }

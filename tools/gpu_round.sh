@@ -10,8 +10,8 @@ rocm-smi --showproductname 2>/dev/null | head -8 > gpurun_out/gpu.txt
 nproc > gpurun_out/host.txt; free -g >> gpurun_out/host.txt; grep -m1 "model name" /proc/cpuinfo >> gpurun_out/host.txt
 for s in $STAGES; do
   case $s in
-    tests) timeout 1500 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -40 > gpurun_out/tests.log; echo "tests exit $?"; tail -5 gpurun_out/tests.log ;;
-    testsall) timeout 1500 python -m pytest tests -m gpu -q --timeout 600 2>&1 | tail -80 > gpurun_out/tests.log; tail -30 gpurun_out/tests.log ;;
+    tests) timeout 1500 python -m pytest tests -m gpu -q -x --timeout 300 2>&1 | tail -40 > gpurun_out/tests.log; echo "tests exit $?"; tail -5 gpurun_out/tests.log ;;
+    testsall) timeout 1500 python -m pytest tests -m gpu -q --timeout 300 2>&1 | tail -80 > gpurun_out/tests.log; tail -30 gpurun_out/tests.log ;;
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -3 gpurun_out/smoke.log ;;
     bench) timeout 900 python bench.py --steps 100 --warmup 10 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?"; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err ;;
     sweep) timeout 900 python tools/sweep.py 7b > gpurun_out/sweep.log 2>&1; echo "sweep exit $?"; tail -25 gpurun_out/sweep.log ;;
