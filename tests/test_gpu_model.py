@@ -243,3 +243,41 @@ def test_7b_full_model_properties(thk, ctx):
         lgp, _ = b.eval(None, i, hidden=h)
     assert np.abs(lgp - lg1).max() < 1e-5
     a.close(); b.close()
+
+
+# ------------------------------------------------------------------ batched prefill (config C3)
+@pytest.mark.parametrize("M,n_past", [(1, 0), (5, 0), (17, 0), (33, 3), (56, 4)])
+def test_prefill_equals_token_by_token(thk, orc, ctx, M, n_past):
+    """MFMA prefill == feeding the tokens one at a time (prefill parity is defined against decode,
+    SURVEY.md Q5) == the oracle; the KV rows it appends let decode continue seamlessly."""
+    m, om = make_pair(thk, orc, ctx, "TINY")
+    rng = np.random.default_rng(M)
+    toks = [1] + rng.integers(3, 2048, n_past + M).tolist()
+    for i in range(n_past):                      # context that already exists
+        m.eval([toks[i]], i); om.eval(toks[i], i)
+    lp = m.prefill(toks[n_past:n_past + M], n_past)
+    for i in range(n_past, n_past + M):
+        lo, _ = om.eval(toks[i], i)
+    assert np.abs(lp - lo).max() < LOGIT_TOL
+    assert int(lp.argmax()) == orc.greedy(lo)
+    # decode continues from the prefilled cache
+    nxt = toks[n_past + M]
+    lg, _ = m.eval([nxt], n_past + M); lo2, _ = om.eval(nxt, n_past + M)
+    assert np.abs(lg - lo2).max() < LOGIT_TOL
+    m.close()
+
+
+def test_prefill_full_width_128_tokens(thk, orc, ctx):
+    """128-token prompt at 7B row geometry (2 layers): MFMA GEMMs at (M=128, C=4096/11008) vs token-by-token decode."""
+    shape = thk.ModelShape(n_layer=2)
+    a = thk.Model(ctx, shape); a.fill_synthetic(); a.finalize()
+    b = thk.Model(ctx, shape); b.fill_synthetic(); b.finalize()
+    rng = np.random.default_rng(128)
+    toks = np.concatenate([[1], rng.integers(3, 32000, 127)]).astype(np.int32)
+    lp = a.prefill(toks, 0)
+    ld, _ = b.eval(toks, 0)
+    assert np.abs(lp - ld).max() < LOGIT_TOL
+    assert int(lp.argmax()) == int(ld.argmax())
+    la, _ = a.eval([77], 128); lb, _ = b.eval([77], 128)
+    assert np.abs(la - lb).max() < LOGIT_TOL
+    a.close(); b.close()

@@ -283,6 +283,14 @@ class Model:
                                                    None if logits is None else logits.ctypes.data), "thk_model_eval")
         return logits, hid
 
+    def prefill(self, tokens, n_past: int = 0, *, seq: int = 0, want_logits: bool = True):
+        """Batched prompt prefill on the MFMA GEMM path (config C3); returns the last token's logits."""
+        toks = np.ascontiguousarray(tokens, np.int32)
+        logits = np.empty(self.shape.n_vocab, np.float32) if want_logits else None
+        self.ctx.check(self.ctx.lib.thk_model_prefill(self.h, seq, toks.ctypes.data, toks.size, n_past,
+                                                      None if logits is None else logits.ctypes.data), "thk_model_prefill")
+        return logits
+
     def seq_set(self, seq: int, token: int, pos: int):
         self.ctx.check(self.ctx.lib.thk_model_seq_set(self.h, seq, token, pos), "thk_model_seq_set")
 

@@ -912,8 +912,96 @@ extern "C" int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_ent
     return rc;
 }
 
+// Batched prompt prefill (config C3): the M prompt tokens go through the layers together so every
+// weight matrix is streamed ONCE and multiplied on the matrix cores (thk_prefill.hip), instead of
+// M mat-vec passes.  Semantics == feeding the tokens one at a time (the reference's own batch path
+// is disabled, th-llama.cpp:15, and its causal mask is only right at n_past == 0, Q5): causal
+// attention over the f32 cache, K/V rows appended at [n_past, n_past+M), logits of the last token.
+struct PrefillBufs { float *X, *XN, *Q, *K, *V, *ATT, *U1, *U3; int32_t* tok; void* ws; };
+static int prefill_workspace(thk_model* m, PrefillBufs* b) {
+    thk_ctx* ctx = m->ctx;
+    const size_t E = m->hp.n_embd, F = m->n_ff, T = m->hp.n_ctx;
+    const size_t per = T * E * 4, bytes = 6 * per + 2 * T * F * 4 + T * 4 + 256 + gemm_prefill_workspace_bytes(128, (int)std::max(E, F));
+    if (m->prefill_ws_bytes < bytes) {
+        if (m->prefill_ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(m->prefill_ws)); m->prefill_ws = nullptr; }
+        hipError_t e = hipMalloc(&m->prefill_ws, bytes);
+        if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? THK_ERR_OOM : THK_ERR_HIP, "prefill workspace (%zu bytes): %s", bytes, hipGetErrorString(e));
+        m->prefill_ws_bytes = bytes;
+    }
+    char* p = (char*)m->prefill_ws;
+    b->X = (float*)p; p += per; b->XN = (float*)p; p += per; b->Q = (float*)p; p += per; b->K = (float*)p; p += per;
+    b->V = (float*)p; p += per; b->ATT = (float*)p; p += per; b->U1 = (float*)p; p += T * F * 4; b->U3 = (float*)p; p += T * F * 4;
+    b->tok = (int32_t*)p; p += (T * 4 + 255) / 256 * 256; b->ws = p;
+    return THK_OK;
+}
+
 extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past, float* logits_out) {
     if (!m) return THK_ERR_INVALID;
-    (void)seq; (void)tokens; (void)n_tokens; (void)n_past; (void)logits_out;
-    return fail(m->ctx, THK_ERR_STATE, "thk_model_prefill: batched MFMA prefill is not wired into the model yet; use thk_model_eval");
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized, "thk_model_prefill before thk_model_finalize");
+    REQUIRE(ctx, (m->flags & THK_STAGE_EMBED) && (m->flags & THK_STAGE_HEAD), "thk_model_prefill needs a full-model stage (embedding + head)");
+    REQUIRE(ctx, seq >= 0 && seq < m->n_seq && tokens, "bad sequence %d / null tokens", seq);
+    REQUIRE(ctx, n_tokens >= 1 && n_past >= 0 && n_past + n_tokens <= m->hp.n_ctx, "n_past=%d + n_tokens=%d exceeds n_ctx=%d", n_past, n_tokens, m->hp.n_ctx);
+    for (int i = 0; i < n_tokens; ++i) REQUIRE(ctx, tokens[i] >= 0 && tokens[i] < m->hp.n_vocab, "token id %d out of range", tokens[i]);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PrefillBufs b{};
+    int rc = prefill_workspace(m, &b);
+    if (rc != THK_OK) return rc;
+    hipStream_t st = ctx->stream;
+    SeqBuf& sb = m->seqs[seq];
+    const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, V = m->hp.n_vocab, T = m->hp.n_ctx, M = n_tokens;
+    const size_t ME = (size_t)M * E;
+    HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));   // tokens may be a stack buffer
+    HIPCHK(ctx, launch_embed_rows(m->tok_embeddings, b.tok, M, E, b.X, st));
+    auto norm_rows = [&](const float* gain) -> int {   // XN = rms_norm(X) * gain   (K4 + K5, row-wise)
+        HIPCHK(ctx, hipMemcpyAsync(b.XN, b.X, ME * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, launch_rms_norm(b.XN, M, E, st));
+        HIPCHK(ctx, launch_row_mul(b.XN, gain, M, E, st));
+        return THK_OK;
+    };
+    for (int i = 0; i < m->l1 - m->l0; ++i) {
+        const LayerW& L = m->layers[i];
+        float* kc = sb.kv + (size_t)i * 2 * T * E;
+        float* vc = kc + (size_t)T * E;
+        if ((rc = norm_rows(L.attention_norm)) != THK_OK) return rc;
+        HIPCHK(ctx, launch_gemm_f16_prefill(L.wq, E, E, b.XN, M, b.Q, b.ws, st));
+        HIPCHK(ctx, launch_gemm_f16_prefill(L.wk, E, E, b.XN, M, b.K, b.ws, st));
+        HIPCHK(ctx, launch_gemm_f16_prefill(L.wv, E, E, b.XN, M, b.V, b.ws, st));
+        HIPCHK(ctx, launch_rope(b.Q, m->rope_tab, M, H, D, n_past, st));
+        HIPCHK(ctx, launch_rope(b.K, m->rope_tab, M, H, D, n_past, st));
+        HIPCHK(ctx, hipMemcpyAsync(kc + (size_t)n_past * E, b.K, ME * 4, hipMemcpyDeviceToDevice, st));   // rows [n_past, n_past+M)
+        HIPCHK(ctx, hipMemcpyAsync(vc + (size_t)n_past * E, b.V, ME * 4, hipMemcpyDeviceToDevice, st));
+        {
+            AttnArgs a{};
+            a.q = b.Q; a.kcache = kc; a.vcache = vc; a.pos_ptr = nullptr; a.pos_val = n_past; a.H = H; a.D = D;
+            a.nsplit = 1; a.tc = n_past + M; a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = M; a.out = b.ATT;
+            HIPCHK(ctx, launch_attn_decode(a, st));
+        }
+        HIPCHK(ctx, launch_gemm_f16_prefill(L.wo, E, E, b.ATT, M, b.Q, b.ws, st));
+        HIPCHK(ctx, launch_add(b.X, b.Q, b.X, ME, st));
+        if ((rc = norm_rows(L.ffn_norm)) != THK_OK) return rc;
+        HIPCHK(ctx, launch_gemm_f16_prefill(L.w1, F, E, b.XN, M, b.U1, b.ws, st));
+        HIPCHK(ctx, launch_gemm_f16_prefill(L.w3, F, E, b.XN, M, b.U3, b.ws, st));
+        HIPCHK(ctx, launch_silu(b.U1, (size_t)M * F, st));
+        HIPCHK(ctx, launch_mul(b.U1, b.U3, (size_t)M * F, st));
+        HIPCHK(ctx, launch_gemm_f16_prefill(L.w2, E, F, b.U1, M, b.Q, b.ws, st));
+        HIPCHK(ctx, launch_add(b.X, b.Q, b.X, ME, st));
+    }
+    {   // final norm + lm-head on the last token only (th-llama.cpp:253-262, aOffset = (r-1)*c)
+        GemvArgs a{};
+        a.W[0] = m->output; a.R = V; a.C = E;
+        const int NR = gemv_rows_per_group(E, GEMV_EPI_HEAD, m->var_head);
+        a.n_groups = (V + NR - 1) / NR;
+        a.x = b.X + (size_t)(M - 1) * E; a.gain = m->norm; a.y = sb.logits;
+        a.lm_faithful = m->lm_mode == THK_LMHEAD_FAITHFUL; q1_constants(V, &a.q1_split, &a.q1_cov);
+        a.block_best = m->block_best;
+        HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, m->nt != 0, st));
+        HIPCHK(ctx, hipMemcpyAsync(m->x, b.X + (size_t)(M - 1) * E, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+    }
+    rc = set_seq_state(m, seq, tokens[M - 1], n_past + M - 1, false);
+    if (rc != THK_OK) return rc;
+    if (logits_out) HIPCHK(ctx, hipMemcpyAsync(logits_out, sb.logits, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return THK_OK;
 }

@@ -650,14 +650,18 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     __shared__ float sm_o[WAVES][D];
     __shared__ float sm_ml[WAVES][2];
 
-    const int h = bid / a.nsplit, s = bid - h * a.nsplit;
+    // prefill: nq > 1 causal queries share one launch; query qi sits at position pos + qi
+    const int per_q = a.H * a.nsplit;
+    const int qi = a.nq > 1 ? bid / per_q : 0;
+    const int hb = bid - qi * per_q;
+    const int h = hb / a.nsplit, s = hb - h * a.nsplit;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPP, li = lane - grp * LPP;
-    const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + 1;
+    const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + qi + 1;
     const int E = a.H * D;
     const int t0 = s * a.tc, t1 = min(t0 + a.tc, T);
 
-    const f4 q = *reinterpret_cast<const f4*>(a.q + h * D + li * 4);
+    const f4 q = *reinterpret_cast<const f4*>(a.q + (size_t)qi * E + h * D + li * 4);
     const float* kb = a.kcache + h * D + li * 4;
     const float* vb = a.vcache + h * D + li * 4;
 
@@ -716,7 +720,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
             L += sm_ml[w][1] * f; od += sm_o[w][d] * f;
         }
         if (a.out) {                     // nsplit == 1: finished output, [H*D]
-            a.out[h * D + d] = od / L;
+            a.out[(size_t)qi * E + h * D + d] = od / L;
         } else if (PUBLISH) {            // consumed by other blocks of this launch: write-through stores
             __hip_atomic_store(a.part_o + (size_t)(h * a.nsplit + s) * D + d, od, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (d == 0) {
@@ -751,7 +755,7 @@ __global__ __launch_bounds__(kBlock) void attn_wo_kernel(const AttnArgs t, const
 }
 
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
-    const int grid = a.H * a.nsplit;
+    const int grid = a.H * a.nsplit * (a.nq > 1 ? a.nq : 1);
     const bool w8 = a.waves == 8;
 #define THK_ATTN(d)                                                                                           \
     case d:                                                                                                   \
@@ -941,6 +945,14 @@ __global__ __launch_bounds__(kBlock) void embed_kernel(const uint16_t* __restric
     const int token = st ? st->token : token_val;
     const _Float16* row = reinterpret_cast<const _Float16*>(table) + (size_t)token * E;
     for (int i = threadIdx.x; i < E; i += kBlock) x[i] = (float)row[i];
+}
+__global__ __launch_bounds__(kBlock) void embed_rows_kernel(const uint16_t* __restrict__ table, const int32_t* __restrict__ tokens, int E, float* x) {
+    const _Float16* row = reinterpret_cast<const _Float16*>(table) + (size_t)tokens[blockIdx.x] * E;
+    for (int i = threadIdx.x; i < E; i += kBlock) x[(size_t)blockIdx.x * E + i] = (float)row[i];
+}
+hipError_t launch_embed_rows(const uint16_t* table, const int32_t* tokens_dev, int n, int E, float* x, hipStream_t st) {
+    hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(kBlock), 0, st, table, tokens_dev, E, x);
+    return hipGetLastError();
 }
 hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token_val, int E, float* x, hipStream_t st) {
     hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(kBlock), 0, st, table, st_dev, token_val, E, x);

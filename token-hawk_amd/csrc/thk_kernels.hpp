@@ -60,6 +60,7 @@ struct AttnArgs {
     const int32_t* pos_ptr; int pos_val;   // T = pos + 1
     int H, D, nsplit, tc;      // tc = positions per split
     int waves;                 // waves per block of the stand-alone kernel (4 or 8)
+    int nq;                    // causal queries in this launch (prefill); 0/1 = single decode query
     float scale;               // 1/sqrtf(D)
     float* out;                // non-NULL only when nsplit == 1
     float* part_o;             // [H, nsplit, D]
@@ -83,6 +84,7 @@ hipError_t launch_add(const float* a, const float* b, float* c, size_t n, hipStr
 hipError_t launch_silu(float* a, size_t n, hipStream_t st);
 hipError_t launch_mul(float* a, const float* b, size_t n, hipStream_t st);
 hipError_t launch_kv_append(float* kc, float* vc, const float* k, const float* v, int pos, int E, hipStream_t st);
+hipError_t launch_embed_rows(const uint16_t* table, const int32_t* tokens_dev, int n, int E, float* x, hipStream_t st);
 hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token_val, int E, float* x, hipStream_t st);
 hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
                                const int* advance_ptr, int32_t* id_out, hipStream_t st);
