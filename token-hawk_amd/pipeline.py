@@ -73,9 +73,10 @@ class PipelineResult:
 
 
 class PipelineDriver:
-    def __init__(self, stage, rank: int, world: int, n_seq: int):
-        assert n_seq == world or world == 1, "the synchronous ring schedule needs one sequence per stage"
+    def __init__(self, stage, rank: int, world: int, n_seq: int, force_ring: bool = False):
+        assert n_seq == world or (world == 1 and not force_ring), "the synchronous ring schedule needs one sequence per stage"
         self.stage, self.rank, self.world, self.S = stage, rank, world, n_seq
+        self.force_ring = force_ring      # world == 1 only: still post the (self) send/recv pair, to exercise the P2P plumbing
         self.prev, self.next = (rank - 1) % world, (rank + 1) % world
 
     def _exchange(self, j: int, total: int):
@@ -104,7 +105,7 @@ class PipelineDriver:
         the fed-back token with a prompt token (prefill through the same path)."""
         st, r, N, S = self.stage, self.rank, self.world, self.S
         total = steps * S
-        if N == 1:
+        if N == 1 and not self.force_ring:
             for i in range(total):
                 k, s = divmod(i, S)
                 if forced_tokens is not None:
