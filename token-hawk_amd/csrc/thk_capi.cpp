@@ -435,7 +435,7 @@ extern "C" int thk_gemm_f16_prefill(thk_ctx* ctx, const void* W, int64_t R, int6
     if (!ctx) return THK_ERR_INVALID;
     REQUIRE(ctx, W && X && Y && R > 0 && M > 0, "thk_gemm_f16_prefill: bad arguments");
     REQUIRE(ctx, C >= 32 && C % 32 == 0, "thk_gemm_f16_prefill: C=%lld must be a multiple of 32", (long long)C);
-    const size_t ws = gemm_prefill_workspace_bytes((int)M, (int)C);
+    const size_t ws = gemm_prefill_workspace_bytes((int)M, (int)R, (int)C);
     int rc = ensure_scratch(ctx, ws < (1u << 20) ? (1u << 20) : ws);
     if (rc != THK_OK) return rc;
     HIPCHK(ctx, launch_gemm_f16_prefill((const uint16_t*)W, (int)R, (int)C, X, (int)M, Y, ctx->scratch, ctx->stream));
@@ -921,7 +921,7 @@ struct PrefillBufs { float *X, *XN, *Q, *K, *V, *ATT, *U1, *U3; int32_t* tok; vo
 static int prefill_workspace(thk_model* m, PrefillBufs* b) {
     thk_ctx* ctx = m->ctx;
     const size_t E = m->hp.n_embd, F = m->n_ff, T = m->hp.n_ctx;
-    const size_t per = T * E * 4, bytes = 6 * per + 2 * T * F * 4 + T * 4 + 256 + gemm_prefill_workspace_bytes(128, (int)std::max(E, F));
+    const size_t per = T * E * 4, bytes = 6 * per + 2 * T * F * 4 + T * 4 + 256 + std::max(gemm_prefill_workspace_bytes(128, (int)F, (int)E), gemm_prefill_workspace_bytes(128, (int)E, (int)F));
     if (m->prefill_ws_bytes < bytes) {
         if (m->prefill_ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(m->prefill_ws)); m->prefill_ws = nullptr; }
         hipError_t e = hipMalloc(&m->prefill_ws, bytes);

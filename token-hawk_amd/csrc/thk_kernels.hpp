@@ -95,6 +95,6 @@ hipError_t launch_synth_gain(uint64_t key, float scale, size_t n, float* out, hi
 
 // thk_prefill.hip
 hipError_t launch_gemm_f16_prefill(const uint16_t* W, int R, int C, const float* X, int M, float* Y, void* workspace, hipStream_t st);
-size_t gemm_prefill_workspace_bytes(int M, int C);
+size_t gemm_prefill_workspace_bytes(int M, int R, int C);
 
 }  // namespace thk

@@ -99,10 +99,131 @@ __global__ __launch_bounds__(64) void gemm_prefill_kernel(const uint16_t* __rest
     }
 }
 
-size_t gemm_prefill_workspace_bytes(int M, int C) {
+// ---------------------------------------------------------------- v2: LDS-staged X, 4 waves, split-K
+// Workgroup = 4 waves = 128 weight rows x (32*MT) tokens; the four waves share one X tile (hi and
+// lo, 64 columns at a time, double-buffered in LDS with a 16-byte row pad => conflict-free
+// ds_read_b128), each wave streams its own 32 weight rows straight from HBM.  K is split across
+// gridDim.y workgroups so that small matrices still fill the chip; partial tiles go to a workspace
+// and are summed in a fixed order by reduce_splits_kernel (deterministic, no atomics).
+constexpr int kKC = 32;                  // K columns per LDS stage (2 MFMA k-steps)
+constexpr int kXS = kKC + 8;             // LDS row stride in halfs (80 B = 5 x 16-byte slots: conflict-free)
+constexpr int kKSteps = kKC / 16;
+
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_prefill_v2_kernel(const uint16_t* __restrict__ Wp, int R, int C,
+                                                              const _Float16* __restrict__ Xhi, const _Float16* __restrict__ Xlo,
+                                                              int M, float* __restrict__ Yp, int chunks_per_split) {
+    __shared__ __attribute__((aligned(16))) _Float16 sh[2][2][MT * 32][kXS];   // [stage][hi/lo][token][k]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, kh = (lane >> 5) * 8;
+    const int r0 = blockIdx.x * 128 + wave * 32;
+    int wrow = r0 + li; if (wrow >= R) wrow = R - 1;
+    const _Float16* wp = reinterpret_cast<const _Float16*>(Wp) + (size_t)wrow * C + kh;
+    const int nchunks = C / kKC;
+    const int c_begin = blockIdx.y * chunks_per_split, c_end = min(nchunks, c_begin + chunks_per_split);
+
+    f16v acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+    // X tile loader: (MT*32 rows) x (kKC/8) 16-byte segments per array, spread over the 256 threads
+    constexpr int SPR = kKC / 8;                       // segments per row
+    constexpr int NSEG = MT * 32 * SPR;                // segments per array
+    constexpr int SEG = (NSEG + 255) / 256;            // per thread
+    h8 xr[2][SEG];
+    auto load_x = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+            const int idx = min(tid + i * 256, NSEG - 1), row = idx / SPR, seg = idx % SPR;
+            const size_t off = (size_t)row * C + (size_t)chunk * kKC + seg * 8;
+            xr[0][i] = *reinterpret_cast<const h8*>(Xhi + off);
+            xr[1][i] = *reinterpret_cast<const h8*>(Xlo + off);
+        }
+    };
+    auto store_x = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+            const int idx = tid + i * 256, row = idx / SPR, seg = idx % SPR;
+            if (idx < NSEG) {
+                *reinterpret_cast<h8*>(&sh[stage][0][row][seg * 8]) = xr[0][i];
+                *reinterpret_cast<h8*>(&sh[stage][1][row][seg * 8]) = xr[1][i];
+            }
+        }
+    };
+    h8 wr[kKSteps], wn[kKSteps];
+    auto load_w = [&](int chunk, h8 (&w)[kKSteps]) {
+#pragma unroll
+        for (int ks = 0; ks < kKSteps; ++ks) w[ks] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(wp + (size_t)chunk * kKC + ks * 16));
+    };
+
+    if (c_begin < c_end) {
+        load_x(c_begin); load_w(c_begin, wr);
+        store_x(0);
+        __syncthreads();
+        for (int c = c_begin; c < c_end; ++c) {
+            const int stage = (c - c_begin) & 1;
+            const bool more = c + 1 < c_end;
+            if (more) { load_x(c + 1); load_w(c + 1, wn); }      // next stage in flight during the MFMAs
+#pragma unroll
+            for (int ks = 0; ks < kKSteps; ++ks) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const h8 bh = *reinterpret_cast<const h8*>(&sh[stage][0][t * 32 + li][ks * 16 + kh]);
+                    const h8 bl = *reinterpret_cast<const h8*>(&sh[stage][1][t * 32 + li][ks * 16 + kh]);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ks], bh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ks], bl, acc[t], 0, 0, 0);
+                }
+            }
+            if (more) {
+                store_x(stage ^ 1);                              // the other buffer was last read one iteration ago
+#pragma unroll
+                for (int ks = 0; ks < kKSteps; ++ks) wr[ks] = wn[ks];
+            }
+            __syncthreads();
+        }
+    }
+    float* Y = Yp + (size_t)blockIdx.y * M * R;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const int tok = t * 32 + li;
+        if (tok < M) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = r0 + 8 * g + 4 * (lane >> 5);
+                float* dst = Y + (size_t)tok * R + r;
+                if (r + 3 < R) {
+                    *reinterpret_cast<f4*>(dst) = f4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                } else {
+                    for (int e = 0; e < 4; ++e) if (r + e < R) dst[e] = acc[t][4 * g + e];
+                }
+            }
+        }
+    }
+}
+
+__global__ void reduce_splits_kernel(const float* __restrict__ part, int ks, size_t n4, float* __restrict__ Y) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f4 s = reinterpret_cast<const f4*>(part)[i];
+    for (int k = 1; k < ks; ++k) s += reinterpret_cast<const f4*>(part)[(size_t)k * n4 + i];
+    reinterpret_cast<f4*>(Y)[i] = s;
+}
+
+static int prefill_splits(int R, int C) {
+    const int rb = (R + 127) / 128, nchunks = C / kKC;
+    int ks = 1;
+    while (ks < 8 && rb * ks < 256 && nchunks / (ks * 2) >= 8) ks *= 2;
+    return ks;
+}
+
+size_t gemm_prefill_workspace_bytes(int M, int R, int C) {
     const int mc = M < 128 ? M : 128;
     const int Mpad = (mc + 31) / 32 * 32;
-    return (size_t)Mpad * C * 2 * 2;
+    size_t b = ((size_t)Mpad * C * 2 * 2 + 255) / 256 * 256;
+    if (C % kKC == 0) b += (size_t)prefill_splits(R, C) * mc * R * 4;
+    return b;
 }
 
 hipError_t launch_gemm_f16_prefill(const uint16_t* W, int R, int C, const float* X, int M, float* Y, void* workspace, hipStream_t st) {
@@ -115,13 +236,30 @@ hipError_t launch_gemm_f16_prefill(const uint16_t* W, int R, int C, const float*
         const size_t n = (size_t)Mpad * C;
         const unsigned sgrid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
         hipLaunchKernelGGL(split_hi_lo_kernel, dim3(sgrid), dim3(256), 0, st, X + (size_t)m0 * C, mc, Mpad, C, hi, lo);
-        const int grid = (R + 31) / 32;
         float* Yc = Y + (size_t)m0 * R;
-        switch (MT) {
-            case 1: hipLaunchKernelGGL(gemm_prefill_kernel<1>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
-            case 2: hipLaunchKernelGGL(gemm_prefill_kernel<2>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
-            case 3: hipLaunchKernelGGL(gemm_prefill_kernel<3>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
-            default: hipLaunchKernelGGL(gemm_prefill_kernel<4>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
+        if (C % kKC == 0) {
+            const int ks = prefill_splits(R, C), nchunks = C / kKC, cps = (nchunks + ks - 1) / ks;
+            float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((size_t)Mpad * C * 2 * 2 + 255) / 256 * 256);
+            float* dst = ks == 1 ? Yc : part;
+            const dim3 grid((R + 127) / 128, ks);
+            switch (MT) {
+                case 1: hipLaunchKernelGGL(gemm_prefill_v2_kernel<1>, grid, dim3(256), 0, st, W, R, C, hi, lo, mc, dst, cps); break;
+                case 2: hipLaunchKernelGGL(gemm_prefill_v2_kernel<2>, grid, dim3(256), 0, st, W, R, C, hi, lo, mc, dst, cps); break;
+                case 3: hipLaunchKernelGGL(gemm_prefill_v2_kernel<3>, grid, dim3(256), 0, st, W, R, C, hi, lo, mc, dst, cps); break;
+                default: hipLaunchKernelGGL(gemm_prefill_v2_kernel<4>, grid, dim3(256), 0, st, W, R, C, hi, lo, mc, dst, cps); break;
+            }
+            if (ks > 1) {
+                const size_t n4 = (size_t)mc * R / 4;
+                hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, ks, n4, Yc);
+            }
+        } else {                                                // odd K: v1 kernel (one wave per workgroup)
+            const int grid = (R + 31) / 32;
+            switch (MT) {
+                case 1: hipLaunchKernelGGL(gemm_prefill_kernel<1>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
+                case 2: hipLaunchKernelGGL(gemm_prefill_kernel<2>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
+                case 3: hipLaunchKernelGGL(gemm_prefill_kernel<3>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
+                default: hipLaunchKernelGGL(gemm_prefill_kernel<4>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
+            }
         }
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
