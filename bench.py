@@ -235,12 +235,16 @@ def main():
             roof.update({"kernel": dom, "achieved": kp[dom]["gbs"], "frac": round(kp[dom]["gbs"] / HBM_PEAK_GBS, 4),
                          "avg_us": kp[dom]["avg_us"], "alg_bytes_per_launch": kp[dom]["alg_bytes"],
                          "frac_of_copy_rate": round(kp[dom]["gbs"] / COPY_RATE_GBS, 4)})
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    roof["traffic"] = json.load(open(pmc)).get(dom)
-                except Exception:
-                    pass
+            roof["timing"] = "HIP events around eager launches on the libthk stream (includes the ~1.5-2.5 us launch gap)"
+            for key, fname in (("traffic", "pmc_traffic.json"), ("rocprof_avg_us", "kernel_durations.json")):
+                path = os.path.join(ROOT, "profiles", fname)     # committed rocprofv3 summaries of this same command
+                if os.path.exists(path):
+                    try:
+                        roof[key] = json.load(open(path)).get(dom)
+                    except Exception:
+                        pass
+            if roof.get("rocprof_avg_us"):
+                roof["rocprof_frac"] = round(kp[dom]["alg_bytes"] / (roof["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
             result["kernels"] = kp
         result["roofline"] = roof
 
