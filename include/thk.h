@@ -165,6 +165,7 @@ int thk_model_create(thk_ctx* ctx, const thk_hparams* hp, int32_t layer_begin, i
                      uint32_t stage_flags, int32_t n_seq, thk_model** out);
 int thk_model_destroy(thk_model* m);
 int32_t thk_model_n_ff(const thk_model* m);
+int32_t thk_model_n_embd(const thk_model* m);
 
 /* Called by the GGML loader in file order (replaces load_weights' TensorBuffer
  * upload, th-llama-loader.cpp:121-265).  name is the ggjt tensor name; ne0 = columns
@@ -219,6 +220,28 @@ int64_t thk_model_bytes_per_token(const thk_model* m, int32_t T);
 /* Time the last `n` kernels of interest: enables per-kernel hipEvent timing of one
  * decode step outside graph replay; fills names/ms arrays (diagnostics for bench.py). */
 int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_entries, char (*names)[48], float* ms, int32_t* n_out);
+
+/* ---------------------------------------------------------------- pipeline hand-off (config C4)
+ * Point-to-point RCCL over xGMI between pipeline stages (one process per GPU).  New functionality:
+ * the reference is single-device.  The 128-byte id comes from thk_pp_get_unique_id
+ * on rank 0 and is distributed by the host out of band (file, socket, torch.distributed ...).
+ * All transfers are enqueued on the context's stream; wrap a ring step (one send + one receive) in
+ * thk_pp_group_begin/end so it cannot dead-lock. */
+typedef struct thk_pp thk_pp;
+#define THK_PP_UNIQUE_ID_BYTES 128
+int thk_pp_get_unique_id(void* out128);
+int thk_pp_create(thk_ctx* ctx, int n_ranks, int rank, const void* unique_id128, thk_pp** out);
+int thk_pp_destroy(thk_pp* pp);
+int thk_pp_rank(const thk_pp* pp);
+int thk_pp_size(const thk_pp* pp);
+int thk_pp_group_begin(thk_pp* pp);
+int thk_pp_group_end(thk_pp* pp);
+int thk_pp_send(thk_pp* pp, const void* dev_buf, size_t bytes, int peer);
+int thk_pp_recv(thk_pp* pp, void* dev_buf, size_t bytes, int peer);
+int thk_pp_send_hidden(thk_pp* pp, thk_model* m, int32_t seq, int peer);   /* thk_model_hidden_out(m,seq), n_embd*4 bytes */
+int thk_pp_recv_hidden(thk_pp* pp, thk_model* m, int32_t seq, int peer);   /* into thk_model_hidden_in(m,seq) */
+int thk_pp_send_token(thk_pp* pp, thk_model* m, int32_t seq, int peer);    /* last stage -> stage 0: 4-byte greedy token */
+int thk_pp_recv_token(thk_pp* pp, thk_model* m, int32_t seq, int peer);
 
 /* Tuning knobs (integers, by name) so the bench can sweep launch geometry without
  * rebuilding: e.g. "gemv_blocks_per_cu", "attn_splits", "use_graph".  Must be set

@@ -62,3 +62,48 @@ def test_single_rank_ring_over_rccl(thk, orc):
             stage.model.close(); ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_native_rccl_hand_off_between_two_stages(thk, orc, ctx):
+    """thk_pp_* (the C-ABI's own RCCL point-to-point path, no torch): two layer-range stages on one
+    GPU, the hidden state travels stage A -> stage B through a grouped ncclSend/ncclRecv to self,
+    the greedy token travels back the same way; logits must equal the un-split model's."""
+    import ctypes as C
+    lib = ctx.lib
+    uid = C.create_string_buffer(128)
+    assert lib.thk_pp_get_unique_id(uid) == 0
+    pp = C.c_void_p()
+    ctx.check(lib.thk_pp_create(ctx.h, 1, 0, uid, C.byref(pp)), "thk_pp_create")
+    assert lib.thk_pp_size(pp) == 1 and lib.thk_pp_rank(pp) == 0
+    # raw buffers
+    a, b = ctx.from_numpy(np.arange(4096, dtype=np.float32)), ctx.alloc(4096 * 4)
+    ctx.check(lib.thk_pp_group_begin(pp), "group_begin")
+    ctx.check(lib.thk_pp_send(pp, C.c_void_p(a.ptr), 4096 * 4, 0), "send")
+    ctx.check(lib.thk_pp_recv(pp, C.c_void_p(b.ptr), 4096 * 4, 0), "recv")
+    ctx.check(lib.thk_pp_group_end(pp), "group_end")
+    ctx.sync()
+    assert (b.download(np.float32, 4096) == np.arange(4096, dtype=np.float32)).all()
+    # two stages + full model
+    shape = thk.TINY
+    full = thk.Model(ctx, shape); full.fill_synthetic(); full.finalize()
+    sa = thk.Model(ctx, shape, 0, 1, flags=thk.THK_STAGE_EMBED); sa.fill_synthetic(); sa.finalize()
+    sb = thk.Model(ctx, shape, 1, 2, flags=thk.THK_STAGE_HEAD); sb.fill_synthetic(); sb.finalize()
+    full.seq_set(0, 1, 0); sa.seq_set(0, 1, 0); sb.seq_set(0, 1, 0)
+    for step in range(6):
+        full.decode_step(0, True)
+        sa.decode_step(0, True)
+        ctx.check(lib.thk_pp_group_begin(pp), "group_begin")
+        ctx.check(lib.thk_pp_send_hidden(pp, sa.h, 0, 0), "send_hidden")
+        ctx.check(lib.thk_pp_recv_hidden(pp, sb.h, 0, 0), "recv_hidden")
+        ctx.check(lib.thk_pp_group_end(pp), "group_end")
+        sb.decode_step(0, True)
+        ctx.check(lib.thk_pp_group_begin(pp), "group_begin")       # token ring: last stage -> first stage
+        ctx.check(lib.thk_pp_send_token(pp, sb.h, 0, 0), "send_token")
+        ctx.check(lib.thk_pp_recv_token(pp, sa.h, 0, 0), "recv_token")
+        ctx.check(lib.thk_pp_group_end(pp), "group_end")
+    gf, nf, pf = full.seq_get(0)
+    gb, nb, pb = sb.seq_get(0)
+    assert nf == nb == 6 and pf == pb == 6 and gf.tolist() == gb.tolist()
+    assert lib.thk_pp_destroy(pp) == 0
+    for m in (full, sa, sb):
+        m.close()

@@ -79,6 +79,20 @@ SIGNATURES = {
     "thk_model_seq_get": (C.c_int, [vp, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]),
     "thk_model_bytes_per_token": (i64, [vp, i32]),
     "thk_model_profile_step": (C.c_int, [vp, i32, i32, vp, vp, C.POINTER(i32)]),
+    "thk_model_n_embd": (i32, [vp]),
+    "thk_pp_get_unique_id": (C.c_int, [vp]),
+    "thk_pp_create": (C.c_int, [vp, C.c_int, C.c_int, vp, pp]),
+    "thk_pp_destroy": (C.c_int, [vp]),
+    "thk_pp_rank": (C.c_int, [vp]),
+    "thk_pp_size": (C.c_int, [vp]),
+    "thk_pp_group_begin": (C.c_int, [vp]),
+    "thk_pp_group_end": (C.c_int, [vp]),
+    "thk_pp_send": (C.c_int, [vp, vp, C.c_size_t, C.c_int]),
+    "thk_pp_recv": (C.c_int, [vp, vp, C.c_size_t, C.c_int]),
+    "thk_pp_send_hidden": (C.c_int, [vp, vp, i32, C.c_int]),
+    "thk_pp_recv_hidden": (C.c_int, [vp, vp, i32, C.c_int]),
+    "thk_pp_send_token": (C.c_int, [vp, vp, i32, C.c_int]),
+    "thk_pp_recv_token": (C.c_int, [vp, vp, i32, C.c_int]),
     "thk_set_tunable": (C.c_int, [vp, C.c_char_p, i64]),
     "thk_get_tunable": (C.c_int, [vp, C.c_char_p, C.POINTER(i64)]),
 }

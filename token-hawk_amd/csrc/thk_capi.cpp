@@ -170,6 +170,12 @@ static uint64_t synth_key(const char* name, uint64_t seed) {
 }
 static float synth_scale(float sigma) { return (float)((double)sigma / 37837.2275); }
 
+// hooks for thk_pp.cpp (same library, different translation unit)
+namespace thk {
+int ctx_fail(thk_ctx* ctx, int code, const char* msg) { return fail(ctx, code, "%s", msg); }
+int ctx_device(thk_ctx* ctx) { return ctx ? ctx->device : 0; }
+}
+
 // ---------------------------------------------------------------- context
 extern "C" int thk_abi_version(void) { return THK_ABI_VERSION; }
 
@@ -505,6 +511,7 @@ extern "C" int thk_model_destroy(thk_model* m) {
     return THK_OK;
 }
 extern "C" int32_t thk_model_n_ff(const thk_model* m) { return m ? m->n_ff : 0; }
+extern "C" int32_t thk_model_n_embd(const thk_model* m) { return m ? m->hp.n_embd : 0; }
 
 // name -> device slot; returns 0 ok, 1 = tensor belongs to another stage (ignored), <0 error
 static int tensor_slot(thk_model* m, const char* name, void** dst, int64_t* ne0, int64_t* ne1, int* dtype) {
