@@ -47,6 +47,8 @@ def parse():
     p.add_argument("--no-kernel-profile", action="store_true")
     p.add_argument("--tunable", action="append", default=[], help="name=value (libthk launch-geometry knob)")
     p.add_argument("--lmhead", default="correct", choices=["correct", "faithful"])
+    p.add_argument("--transport", default="torch", choices=["torch", "native"],
+                   help="N>1 hidden-state hand-off: torch.distributed P2P ops (backend nccl = RCCL) or libthk's thk_pp_* (RCCL directly)")
     return p.parse_args()
 
 
@@ -151,6 +153,16 @@ def main():
         else:
             stage = HipStage(thk, ctx, shape, rank, N, S, dev)
             model = stage.model
+            if args.transport == "native":
+                import ctypes as C
+                uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    buf = C.create_string_buffer(128)
+                    assert ctx.lib.thk_pp_get_unique_id(buf) == 0
+                    uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                torch.cuda.synchronize(dev)
+                stage.attach_native_transport(rank, N, bytes(uid.cpu().numpy().tobytes()))
         l0, l1 = layer_range(shape.n_layer, rank, N)
         ctx.sync()
         log(f"[bench r{rank}] {info['name']} cus={info['n_cu']} layers [{l0},{l1}) model ready in {time.time() - t_setup:.1f}s")
@@ -214,7 +226,7 @@ def main():
             "data": "synthetic (seeded Irwin-Hall~N(0,0.02^2) f16 weights, seeded prompt ids)",
             "config": {"workload": f"LLaMA-{args.model.upper()} f16, {T}-ctx single-token greedy decode (n_past={T - 1}), "
                                    f"{'1 sequence' if N == 1 else f'{S} sequences in flight, layers pipelined over {N} GPUs (RCCL p2p)'}",
-                       "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single",
+                       "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single", "transport": args.transport if N > 1 else None,
                        "lmhead_mode": args.lmhead,
                        "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "gemv_nt", "use_graph")}},
             "bytes_per_token": b_tok,

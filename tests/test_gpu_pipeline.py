@@ -107,3 +107,32 @@ def test_native_rccl_hand_off_between_two_stages(thk, orc, ctx):
     assert lib.thk_pp_destroy(pp) == 0
     for m in (full, sa, sb):
         m.close()
+
+
+def test_driver_with_native_transport_single_rank_ring(thk, orc):
+    """PipelineDriver on the native thk_pp_* transport (world 1, forced ring): same tokens as the oracle."""
+    import ctypes as C
+    import torch
+    from token_hawk_amd.pipeline import HipStage, PipelineDriver
+    dev = torch.device("cuda", 0)
+    ctx = thk.Context(0)
+    stage = HipStage(thk, ctx, thk.TINY, 0, 1, 1, dev)
+    uid = C.create_string_buffer(128)
+    assert ctx.lib.thk_pp_get_unique_id(uid) == 0
+    stage.attach_native_transport(0, 1, uid.raw)
+    drv = PipelineDriver(stage, 0, 1, 1, force_ring=True)
+    prompt = np.array([[1], [40], [900]], np.int32)
+    stage.set_seq(0, 1, 0)
+    drv.run(3, advance=True, forced_tokens=prompt)
+    drv.run(5, advance=True)
+    got = stage.generated(0)
+    om = orc.OracleModel(orc.TINY); om.fill_synthetic()
+    for i, t in enumerate(prompt[:, 0].tolist()):
+        lg, _ = om.eval(t, i)
+    tok, exp = orc.greedy(lg), []
+    exp.append(tok)
+    for i in range(5):
+        lg, _ = om.eval(tok, 3 + i); tok = orc.greedy(lg); exp.append(tok)
+    assert got[2:] == exp
+    ctx.lib.thk_pp_destroy(stage.pp)
+    stage.model.close(); ctx.close()

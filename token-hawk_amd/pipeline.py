@@ -53,6 +53,24 @@ class HipStage:
         self.hidden_out = [torch.as_tensor(_CudaView(m.hidden_out_ptr(s), (E,), "<f4"), device=device) for s in range(n_seq)]
         self.token = [torch.as_tensor(_CudaView(m.token_dev_ptr(s), (1,), "<i4"), device=device) for s in range(n_seq)]
 
+    def attach_native_transport(self, rank: int, world: int, unique_id: bytes):
+        """Use libthk's own RCCL point-to-point path (thk_pp_*) instead of torch.distributed P2P ops."""
+        import ctypes as C
+        ctx = self.model.ctx
+        pp = C.c_void_p()
+        ctx.check(ctx.lib.thk_pp_create(ctx.h, world, rank, unique_id, C.byref(pp)), "thk_pp_create")
+        self.pp = pp
+
+    def native_exchange(self, sends, recvs):
+        """sends/recvs: lists of (kind, seq, peer), kind in {'hidden','token'}; one grouped RCCL step."""
+        ctx, lib, pp, h = self.model.ctx, self.model.ctx.lib, self.pp, self.model.h
+        ctx.check(lib.thk_pp_group_begin(pp), "thk_pp_group_begin")
+        for kind, seq, peer in sends:
+            ctx.check((lib.thk_pp_send_hidden if kind == "hidden" else lib.thk_pp_send_token)(pp, h, seq, peer), "thk_pp_send")
+        for kind, seq, peer in recvs:
+            ctx.check((lib.thk_pp_recv_hidden if kind == "hidden" else lib.thk_pp_recv_token)(pp, h, seq, peer), "thk_pp_recv")
+        ctx.check(lib.thk_pp_group_end(pp), "thk_pp_group_end")
+
     def set_seq(self, seq: int, token: int, pos: int):
         self.model.seq_set(seq, token, pos)
 
@@ -82,6 +100,17 @@ class PipelineDriver:
     def _exchange(self, j: int, total: int):
         """Grouped P2P after micro-step j: send item (j - rank)'s output, receive the input of item (j + 1 - rank)."""
         st, r, N, S = self.stage, self.rank, self.world, self.S
+        if getattr(st, "pp", None) is not None:          # native RCCL transport (thk_pp_*), same schedule
+            sends, recvs = [], []
+            i_done = j - r
+            if 0 <= i_done < total:
+                sends.append(("token" if st.is_last else "hidden", i_done % S, self.next))
+            i_prev = j - ((r - 1) % N)
+            if 0 <= i_prev < total:
+                recvs.append(("token" if st.is_first else "hidden", i_prev % S, self.prev))
+            if sends or recvs:
+                st.native_exchange(sends, recvs)
+            return
         ops = []
         i_done = j - r                                   # item this rank just finished
         if 0 <= i_done < total:
