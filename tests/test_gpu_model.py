@@ -56,6 +56,29 @@ def test_tiny_model_every_token_vs_oracle(thk, orc, ctx, splits, use_graph):
     m.close()
 
 
+@pytest.mark.parametrize("tunables", [{"fuse_attn_wo": 1, "attn_splits": 2}, {"fuse_attn_wo": 1, "attn_splits": 4}, {"fuse_attn_wo": 1, "attn_splits": 8},
+                                      {"attn_combine": 1, "attn_splits": 2}, {"attn_combine": 1, "attn_splits": 4}, {"attn_combine": 1, "attn_splits": 8},
+                                      {"attn_waves": 4}, {"gemv_nt": 0}])
+def test_optional_paths_vs_oracle(thk, orc, ctx, tunables):
+    """The off-by-default experiments stay correct: fused attention+wo launch with the
+    in-launch hand-off, last-arriver split combine, 4-wave attention blocks, default-policy weight loads."""
+    m, om = make_pair(thk, orc, ctx, "TINY", tunables=tunables)
+    rng = np.random.default_rng(5)
+    toks = [1] + rng.integers(3, 2048, 30).tolist()
+    for i, t in enumerate(toks):
+        lg, _ = m.eval([t], i); lo, _ = om.eval(t, i)
+        assert np.abs(lg - lo).max() < LOGIT_TOL, i
+    m.seq_set(0, 7, len(toks))
+    for _ in range(6):
+        m.decode_step(0, advance=True)
+    gen, n, pos = m.seq_get(0)
+    tok, exp = 7, []
+    for i in range(6):
+        lo, _ = om.eval(tok, len(toks) + i); tok = orc.greedy(lo); exp.append(tok)
+    assert gen.tolist() == exp
+    m.close()
+
+
 def test_multi_token_eval_equals_one_by_one(thk, orc, ctx):
     """th_eval_gpu with n_tokens>1 == tokens fed one at a time (kAllowedSubsequentBatchSize=1)."""
     m, om = make_pair(thk, orc, ctx, "TINY")

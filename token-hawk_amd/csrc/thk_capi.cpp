@@ -85,7 +85,8 @@ struct thk_model {
     int grid_qkv = 0, grid_wo = 0, grid_w13 = 0, grid_w2 = 0, grid_head = 0;
     void* prefill_ws = nullptr; size_t prefill_ws_bytes = 0;
     // fused attention+wo launch: per-layer arrival counters (zeroed at the start of every step) + error word
-    int fuse_attn_wo = 0, fuse_initial_sleeps = 0, attn_waves = 8;
+    int fuse_attn_wo = 0, fuse_initial_sleeps = 0, attn_waves = 8, attn_combine = 0;
+    unsigned* head_ticket = nullptr;   // [H] counters of the in-launch split combine
     unsigned* fuse_counters = nullptr;   // [n_local_layers] then [1] error
 };
 
@@ -123,6 +124,7 @@ static void default_tunables(thk_ctx* ctx) {
     ctx->tun["gemv_nt"] = 1;              // non-temporal weight loads
     ctx->tun["attn_splits"] = 4;          // context splits per head (1,2,4,8)
     ctx->tun["attn_waves"] = 8;           // waves per attention block (4 or 8)
+    ctx->tun["attn_combine"] = 0;         // last-arriving split block of a head merges the partials inside the attention launch (measured: slower)
     ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
     ctx->tun["fuse_attn_wo"] = 0;         // attention splits + wo mat-vec in one launch (in-launch hand-off)
     ctx->tun["fuse_initial_sleeps"] = 0;  // consumer s_sleep(32) repetitions (~0.85 us each) before the first poll
@@ -495,7 +497,7 @@ static void free_working(thk_model* m) {
     for (auto& s : m->seqs) free_seq(s);
     m->seqs.clear();
     hipFree(m->x); hipFree(m->q); hipFree(m->u); hipFree(m->attn_out); hipFree(m->part_o); hipFree(m->part_ml); hipFree(m->block_best); hipFree(m->rope_tab);
-    hipFree(m->prefill_ws); hipFree(m->fuse_counters); m->fuse_counters = nullptr;
+    hipFree(m->prefill_ws); hipFree(m->fuse_counters); m->fuse_counters = nullptr; hipFree(m->head_ticket); m->head_ticket = nullptr;
     m->x = m->q = m->u = m->attn_out = m->part_o = m->part_ml = nullptr; m->block_best = nullptr; m->rope_tab = nullptr;
     m->prefill_ws = nullptr; m->prefill_ws_bytes = 0;
     m->finalized = false;
@@ -636,7 +638,9 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             AttnArgs t{};
             t.q = m->q; t.kcache = kc; t.vcache = vc; t.pos_ptr = &sb.st->pos; t.H = H; t.D = D; t.nsplit = m->nsplit; t.tc = m->tc;
             t.scale = 1.0f / sqrtf((float)D); t.waves = m->attn_waves;
-            t.out = m->nsplit == 1 ? m->attn_out : nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml;
+            const bool combined = m->attn_combine && !m->fuse_attn_wo;      // attention writes the finished vector itself
+            t.out = (m->nsplit == 1 || combined) ? m->attn_out : nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml;
+            t.head_ticket = combined ? m->head_ticket : nullptr;
             GemvArgs a{};
             a.W[0] = L.wo; a.R = E; a.C = E;
             const int NR = gemv_rows_per_group(E, GEMV_EPI_RESID, m->var_wo);
@@ -653,7 +657,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
                 MARK("attn_decode");
                 HIPCHK(ctx, launch_attn_decode(t, st));
                 MARK("attn_wo_resid");
-                HIPCHK(ctx, launch_gemv(m->nsplit == 1 ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, m->var_wo, a, m->grid_wo, nt, st));
+                HIPCHK(ctx, launch_gemv((m->nsplit == 1 || combined) ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, m->var_wo, a, m->grid_wo, nt, st));
             }
         }
         {   // rms_norm*gain -> w1,w3 -> silu*gate   (steps 12-14, th-llama.cpp:415-438)
@@ -735,6 +739,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->use_graph = tun(ctx, "use_graph") != 0;
     m->fuse_initial_sleeps = (int)tun(ctx, "fuse_initial_sleeps");
     m->attn_waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
+    m->attn_combine = tun(ctx, "attn_combine") != 0 && m->nsplit > 1;
     m->fuse_attn_wo = tun(ctx, "fuse_attn_wo") != 0 && m->nsplit > 1 && (D == 64 || D == 128);
     m->var_qkv = (int)tun(ctx, "gemv_variant_qkv"); m->var_wo = (int)tun(ctx, "gemv_variant_wo");
     m->var_w13 = (int)tun(ctx, "gemv_variant_w13"); m->var_w2 = (int)tun(ctx, "gemv_variant_w2"); m->var_head = (int)tun(ctx, "gemv_variant_head");
@@ -755,6 +760,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
     ALLOCZ(m->block_best, (size_t)(m->grid_head > 0 ? m->grid_head : 1) * 8 + 4096);
     ALLOCZ(m->rope_tab, T * (D / 2) * 2 * 4);
     ALLOCZ(m->fuse_counters, ((size_t)nl * kFuseStride + 32) * 4);
+    ALLOCZ(m->head_ticket, (size_t)H * 4);
     {
         std::vector<float> tab;
         build_rope_table(tab, (int)D, 0, (int)T);

@@ -719,9 +719,9 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
             const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
             L += sm_ml[w][1] * f; od += sm_o[w][d] * f;
         }
-        if (a.out) {                     // nsplit == 1: finished output, [H*D]
+        if (a.out && !a.head_ticket) {   // nsplit == 1: finished output, [H*D]
             a.out[(size_t)qi * E + h * D + d] = od / L;
-        } else if (PUBLISH) {            // consumed by other blocks of this launch: write-through stores
+        } else if (PUBLISH || a.head_ticket) {   // consumed by other blocks of this launch: write-through stores
             __hip_atomic_store(a.part_o + (size_t)(h * a.nsplit + s) * D + d, od, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (d == 0) {
                 __hip_atomic_store(a.part_ml + (h * a.nsplit + s) * 2, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -734,9 +734,53 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     }
 }
 
+// Split combine inside the attention launch: every (head, split) block publishes its partial with
+// write-through stores and takes a ticket on a per-head counter; the LAST arriver of a head merges
+// the nsplit partials and writes the finished [D] slice, so the wo mat-vec that follows needs no
+// combine prologue.  Counters reset themselves (next use is in a later launch).  No block ever
+// waits, so this cannot dead-lock; summation order is by split index => deterministic.
+template <int D>
+__device__ __forceinline__ void attn_last_arriver_combine(const AttnArgs& a, const int bid) {
+    __shared__ unsigned sm_last;
+    const int per_q = a.H * a.nsplit;
+    const int hb = bid % per_q, h = hb / a.nsplit;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its sc1 stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(a.head_ticket + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sm_last = (t == (unsigned)a.nsplit - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!sm_last) return;
+    if (threadIdx.x < D) {
+        const int d = threadIdx.x;
+        float M = -INFINITY;
+        float ms[kMaxSplit], ls[kMaxSplit], os[kMaxSplit];
+#pragma unroll
+        for (int s = 0; s < kMaxSplit; ++s) {
+            ms[s] = -INFINITY; ls[s] = 0.f; os[s] = 0.f;
+            if (s < a.nsplit) {
+                const float2 ml = load_f2_sc1(a.part_ml + (h * a.nsplit + s) * 2);
+                ms[s] = ml.x; ls[s] = ml.y;
+                os[s] = __hip_atomic_load(a.part_o + (size_t)(h * a.nsplit + s) * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            M = fmaxf(M, ms[s]);
+        }
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int s = 0; s < kMaxSplit; ++s) {
+            const float f = (ms[s] == -INFINITY) ? 0.f : expf(ms[s] - M);
+            L += ls[s] * f; o += os[s] * f;
+        }
+        a.out[h * D + d] = o / L;
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(a.head_ticket + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int D, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(const AttnArgs a) {
     attn_body<D, WAVES, false>(a, blockIdx.x);
+    if (a.head_ticket) attn_last_arriver_combine<D>(a, blockIdx.x);
 }
 
 // Fused launch: blocks [0, H*nsplit) run the attention splits and publish their partials; the

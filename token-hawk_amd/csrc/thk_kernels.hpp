@@ -62,7 +62,8 @@ struct AttnArgs {
     int waves;                 // waves per block of the stand-alone kernel (4 or 8)
     int nq;                    // causal queries in this launch (prefill); 0/1 = single decode query
     float scale;               // 1/sqrtf(D)
-    float* out;                // non-NULL only when nsplit == 1
+    float* out;                // finished output [H*D]: nsplit == 1, or the last-arriver combine (head_ticket != NULL)
+    unsigned* head_ticket;     // [H] arrival counters for the in-launch split combine (NULL = partials only)
     float* part_o;             // [H, nsplit, D]
     float* part_ml;            // [H, nsplit, 2]
 };

@@ -18,6 +18,8 @@ with thk.Context(0) as ctx:
             ctx.sync(); t0=time.perf_counter()
             for _ in range(60): m.decode_step(0, False)
             ctx.sync(); best=max(best, 60/(time.perf_counter()-t0))
-        print(tag, tun, "tok/s %.1f"%best, {k: round(float(np.mean(v)),1) for k,v in agg.items() if v and np.mean(v)>7}, flush=True)
-    for mb in (0, 8, 16, 32, 64, 0):
-        run("pf", tail_prefetch_mb=mb)
+        print(tag, tun, "tok/s %.1f"%best, {k: round(float(np.mean(v)),1) for k,v in agg.items() if 'attn' in k or 'wo' in k}, flush=True)
+    run("base", attn_combine=0, attn_splits=4)
+    for sp in (2,4,8):
+        for bpc,var in ((2,0),(1,3),(4,0),(2,1)):
+            run("combine", attn_combine=1, attn_splits=sp, gemv_bpc_wo=bpc, gemv_variant_wo=var)
