@@ -189,8 +189,7 @@ def main():
 
         def run_steps(k):
             if N == 1:
-                for _ in range(k):
-                    model.decode_step(0, advance=False)
+                model.decode_steps(k, 0, advance=False)       # multi-step graph replays (8 steps per launch)
             else:
                 drv.run(k, advance=False)
 

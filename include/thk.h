@@ -207,6 +207,9 @@ int thk_model_seq_set_token(thk_model* m, int32_t seq, int32_t token);
  *   advance != 0: pos[seq] += 1 afterwards (0 = keep re-evaluating the same slot,
  *                 the fixed-T=512 benchmark protocol of BASELINE.md) */
 int thk_model_decode_step(thk_model* m, int32_t seq, int advance);
+/* n_steps back-to-back decode steps; replays a captured multi-step graph (8 steps per launch) when it
+ * can, which amortises the inter-graph launch latency (~8 us) of the single-step form. */
+int thk_model_decode_steps(thk_model* m, int32_t seq, int32_t n_steps, int advance);
 void* thk_model_hidden_in(thk_model* m, int32_t seq);   /* dev f32[E], RCCL recv target */
 void* thk_model_hidden_out(thk_model* m, int32_t seq);  /* dev f32[E], RCCL send source */
 void* thk_model_token_dev(thk_model* m, int32_t seq);   /* dev int32: current/next token id */

@@ -124,6 +124,21 @@ def test_device_decode_loop_matches_eval_path(thk, orc, ctx):
     m.close()
 
 
+def test_multi_step_graph_matches_single_steps(thk, orc, ctx):
+    """thk_model_decode_steps (8 steps per captured graph + remainder) == repeated thk_model_decode_step."""
+    a, om = make_pair(thk, orc, ctx, "TINY")
+    b = thk.Model(ctx, thk.TINY); b.fill_synthetic(); b.finalize()
+    a.seq_set(0, 1, 0); b.seq_set(0, 1, 0)
+    a.decode_steps(27, 0, advance=True)
+    for _ in range(27):
+        b.decode_step(0, advance=True)
+    ga, na, pa = a.seq_get(0); gb, nb, pb = b.seq_get(0)
+    assert na == nb == 27 and pa == pb == 27 and ga.tolist() == gb.tolist()
+    a.decode_steps(3, 0, advance=True)           # fewer than one multi-step graph
+    assert a.seq_get(0)[2] == 30
+    a.close(); b.close()
+
+
 def test_hold_position_protocol(thk, orc, ctx):
     """advance=0 re-evaluates the same cache slot (fixed-T benchmark protocol): idempotent logits."""
     m, om = make_pair(thk, orc, ctx, "TINY")

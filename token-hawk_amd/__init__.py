@@ -300,6 +300,9 @@ class Model:
     def decode_step(self, seq: int = 0, advance: bool = True):
         self.ctx.check(self.ctx.lib.thk_model_decode_step(self.h, seq, int(advance)), "thk_model_decode_step")
 
+    def decode_steps(self, n_steps: int, seq: int = 0, advance: bool = True):
+        self.ctx.check(self.ctx.lib.thk_model_decode_steps(self.h, seq, n_steps, int(advance)), "thk_model_decode_steps")
+
     def seq_get(self, seq: int = 0, cap: int = 4096):
         out = np.empty(cap, np.int32)
         n, pos = C.c_int32(), C.c_int32()

@@ -58,9 +58,12 @@ struct SeqBuf {
     int advance_host = -1;           // last value written
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipGraph_t graph_multi = nullptr;        // kMultiStep decode steps in one graph (captured on first use)
+    hipGraphExec_t exec_multi = nullptr;
 };
 
 static const int kGenLogCap = 4096;
+static const int kMultiStep = 8;
 static const size_t kFuseStride = 1024;   // words per layer: counter line + kFuseFlags flag lines, padded
 
 struct thk_model {
@@ -111,7 +114,7 @@ static int64_t tun(thk_ctx* ctx, const char* name) {
 static void default_tunables(thk_ctx* ctx) {
     ctx->tun["gemv_blocks_per_cu"] = 4;   // resident 256-thread workgroups per CU for the streaming mat-vecs
     // per-kernel overrides (0 = gemv_blocks_per_cu); defaults from tools/sweep.py on MI355X (profiles/)
-    ctx->tun["gemv_bpc_qkv"] = 4;
+    ctx->tun["gemv_bpc_qkv"] = 3;
     ctx->tun["gemv_bpc_wo"] = 2;
     ctx->tun["gemv_bpc_w13"] = 8;
     ctx->tun["gemv_bpc_w2"] = 2;
@@ -490,6 +493,8 @@ extern "C" int thk_model_create(thk_ctx* ctx, const thk_hparams* hp, int32_t lay
 static void free_seq(SeqBuf& s) {
     if (s.exec) hipGraphExecDestroy(s.exec);
     if (s.graph) hipGraphDestroy(s.graph);
+    if (s.exec_multi) hipGraphExecDestroy(s.exec_multi);
+    if (s.graph_multi) hipGraphDestroy(s.graph_multi);
     hipFree(s.kv); hipFree(s.st); hipFree(s.gen_log); hipFree(s.hidden_in); hipFree(s.hidden_out); hipFree(s.logits); hipFree(s.advance);
     s = SeqBuf();
 }
@@ -869,6 +874,26 @@ extern "C" int thk_model_decode_step(thk_model* m, int32_t seq, int advance) {
     int rc = set_advance(m, seq, advance);
     if (rc != THK_OK) return rc;
     return run_step(m, seq);
+}
+extern "C" int thk_model_decode_steps(thk_model* m, int32_t seq, int32_t n_steps, int advance) {
+    if (!m) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq && n_steps >= 0, "bad sequence %d / step count %d (or model not finalized)", seq, n_steps);
+    int rc = set_advance(m, seq, advance);
+    if (rc != THK_OK) return rc;
+    SeqBuf& sb = m->seqs[seq];
+    if (m->use_graph && n_steps >= kMultiStep && !sb.exec_multi) {       // capture kMultiStep steps once
+        HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        for (int k = 0; k < kMultiStep && rc == THK_OK; ++k) rc = enqueue_step(m, seq, nullptr);
+        hipError_t e = hipStreamEndCapture(ctx->stream, &sb.graph_multi);
+        if (rc != THK_OK) return rc;
+        if (e != hipSuccess) return fail(ctx, THK_ERR_HIP, "hipStreamEndCapture (multi-step): %s", hipGetErrorString(e));
+        HIPCHK(ctx, hipGraphInstantiate(&sb.exec_multi, sb.graph_multi, nullptr, nullptr, 0));
+    }
+    int left = n_steps;
+    while (m->use_graph && sb.exec_multi && left >= kMultiStep) { HIPCHK(ctx, hipGraphLaunch(sb.exec_multi, ctx->stream)); left -= kMultiStep; }
+    while (left-- > 0) { rc = run_step(m, seq); if (rc != THK_OK) return rc; }
+    return THK_OK;
 }
 extern "C" void* thk_model_hidden_in(thk_model* m, int32_t seq) { return (m && m->finalized && seq >= 0 && seq < m->n_seq) ? m->seqs[seq].hidden_in : nullptr; }
 extern "C" void* thk_model_hidden_out(thk_model* m, int32_t seq) { return (m && m->finalized && seq >= 0 && seq < m->n_seq) ? m->seqs[seq].hidden_out : nullptr; }
