@@ -221,13 +221,13 @@ def main():
             "metric": "decode tokens/sec, LLaMA-7B f16, 512-ctx, 1/2/4/8 MI355X; % HBM roofline",
             "value": round(value, 2), "unit": "tokens/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 weights x f32 activations, f32 accumulate, f32 KV",
+            "dtype": "f32",
             "data": "synthetic (seeded Irwin-Hall~N(0,0.02^2) f16 weights, seeded prompt ids)",
             "config": {"workload": f"LLaMA-{args.model.upper()} f16, {T}-ctx single-token greedy decode (n_past={T - 1}), "
                                    f"{'1 sequence' if N == 1 else f'{S} sequences in flight, layers pipelined over {N} GPUs (RCCL p2p)'}",
                        "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single", "transport": args.transport if N > 1 else None,
-                       "lmhead_mode": args.lmhead,
-                       "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "gemv_nt", "use_graph")}},
+                       "lmhead_mode": args.lmhead, "numerics": "f16 GGML weights x f32 activations, f32 accumulate, f32 KV cache (as the reference)",
+                       "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "attn_waves", "use_graph")}},
             "bytes_per_token": b_tok,
             "step_roofline": {"achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                               "frac_of_copy_rate": round(step_gbs / COPY_RATE_GBS, 4), "event_ms_per_step": round(ev_ms / args.steps, 4)},

@@ -58,10 +58,10 @@ def test_tiny_model_every_token_vs_oracle(thk, orc, ctx, splits, use_graph):
 
 @pytest.mark.parametrize("tunables", [{"fuse_attn_wo": 1, "attn_splits": 2}, {"fuse_attn_wo": 1, "attn_splits": 4}, {"fuse_attn_wo": 1, "attn_splits": 8},
                                       {"attn_combine": 1, "attn_splits": 2}, {"attn_combine": 1, "attn_splits": 4}, {"attn_combine": 1, "attn_splits": 8},
-                                      {"attn_waves": 4}, {"gemv_nt": 0}])
+                                      {"attn_waves": 4}])
 def test_optional_paths_vs_oracle(thk, orc, ctx, tunables):
     """The off-by-default experiments stay correct: fused attention+wo launch with the
-    in-launch hand-off, last-arriver split combine, 4-wave attention blocks, default-policy weight loads."""
+    in-launch hand-off, last-arriver split combine, 4-wave attention blocks."""
     m, om = make_pair(thk, orc, ctx, "TINY", tunables=tunables)
     rng = np.random.default_rng(5)
     toks = [1] + rng.integers(3, 2048, 30).tolist()

@@ -124,7 +124,6 @@ static void default_tunables(thk_ctx* ctx) {
     ctx->tun["gemv_variant_w13"] = 0;
     ctx->tun["gemv_variant_w2"] = 2;
     ctx->tun["gemv_variant_head"] = 1;
-    ctx->tun["gemv_nt"] = 1;              // non-temporal weight loads
     ctx->tun["attn_splits"] = 4;          // context splits per head (1,2,4,8)
     ctx->tun["attn_waves"] = 8;           // waves per attention block (4 or 8)
     ctx->tun["attn_combine"] = 0;         // last-arriving split block of a head merges the partials inside the attention launch (measured: slower)
@@ -302,7 +301,7 @@ static int gemv_simple(thk_ctx* ctx, int pro, int epi, const char* var_name, con
     const int NR = gemv_rows_per_group(a.C, epi, nru);
     a.n_groups = (rows + NR - 1) / NR;
     const int grid = grid_for(ctx, bpc_name, a.n_groups);
-    HIPCHK(ctx, launch_gemv(pro, epi, nru, a, grid, tun(ctx, "gemv_nt") != 0, ctx->stream));
+    HIPCHK(ctx, launch_gemv(pro, epi, nru, a, grid, true, ctx->stream));
     return grid;
 }
 
@@ -648,7 +647,8 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             t.head_ticket = combined ? m->head_ticket : nullptr;
             GemvArgs a{};
             a.W[0] = L.wo; a.R = E; a.C = E;
-            const int NR = gemv_rows_per_group(E, GEMV_EPI_RESID, m->var_wo);
+            const int wo_var = m->fuse_attn_wo ? 0 : m->var_wo;             // the fused experiment only has the default variant
+            const int NR = gemv_rows_per_group(E, GEMV_EPI_RESID, wo_var);
             a.n_groups = (E + NR - 1) / NR;
             a.x = m->attn_out; a.part_o = m->part_o; a.part_ml = m->part_ml; a.H = H; a.D = D; a.nsplit = m->nsplit;
             a.resid = xr_in; a.y = m->x;
@@ -657,12 +657,12 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
                 a.fs.target = (unsigned)(H * m->nsplit); a.fs.spin_limit = 1u << 20;
                 a.fs.initial_sleeps = (unsigned)m->fuse_initial_sleeps; a.fs.error = m->fuse_counters + (size_t)nl * kFuseStride;
                 MARK("attn_wo_fused");
-                HIPCHK(ctx, launch_attn_wo(t, a, m->var_wo, m->grid_wo, nt, st));
+                HIPCHK(ctx, launch_attn_wo(t, a, 0 /* default variant */, m->grid_wo, nt, st));
             } else {
                 MARK("attn_decode");
                 HIPCHK(ctx, launch_attn_decode(t, st));
                 MARK("attn_wo_resid");
-                HIPCHK(ctx, launch_gemv((m->nsplit == 1 || combined) ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, m->var_wo, a, m->grid_wo, nt, st));
+                HIPCHK(ctx, launch_gemv((m->nsplit == 1 || combined) ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, wo_var, a, m->grid_wo, nt, st));
             }
         }
         {   // rms_norm*gain -> w1,w3 -> silu*gate   (steps 12-14, th-llama.cpp:415-438)
@@ -740,7 +740,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->nsplit = (int)tun(ctx, "attn_splits");
     REQUIRE(ctx, valid_splits(m->nsplit), "attn_splits must be 1, 2, 4 or 8");
     m->tc = (int)((T + m->nsplit - 1) / m->nsplit);
-    m->nt = tun(ctx, "gemv_nt") != 0;
+    m->nt = true;
     m->use_graph = tun(ctx, "use_graph") != 0;
     m->fuse_initial_sleeps = (int)tun(ctx, "fuse_initial_sleeps");
     m->attn_waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;

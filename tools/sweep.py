@@ -48,12 +48,9 @@ with thk.Context(0) as ctx:
         return steps / (time.perf_counter() - t0)
 
     t_start = time.time()
-    for nt in (1, 0):
-        ctx.set_tunable("gemv_nt", nt)
+    for nt in (1,):
         for bpc in (1, 2, 3, 4, 5, 6, 8):
             for var in (0, 1, 2, 3):
-                if nt == 0 and (var != 0 or bpc not in (2, 4)):
-                    continue
                 ctx.set_tunable("gemv_blocks_per_cu", bpc)
                 for k in KERN.values():
                     ctx.set_tunable("gemv_variant_" + k, var); ctx.set_tunable("gemv_bpc_" + k, 0)
@@ -65,7 +62,6 @@ with thk.Context(0) as ctx:
                     if kern in p:
                         out["per_kernel"].setdefault(short, []).append({"nt": nt, "bpc": bpc, "var": var, "us": round(p[kern], 2)})
                 print(f"nt={nt} bpc={bpc} var={var} " + " ".join(f"{KERN[k]}={p[k]:.1f}" for k in KERN if k in p), flush=True)
-    ctx.set_tunable("gemv_nt", 1)
     # attention splits
     out["attn"] = []
     for sp in (2, 4, 8):
