@@ -47,7 +47,9 @@ def parse():
     p.add_argument("--no-kernel-profile", action="store_true")
     p.add_argument("--tunable", action="append", default=[], help="name=value (libthk launch-geometry knob)")
     p.add_argument("--lmhead", default="correct", choices=["correct", "faithful"])
-    p.add_argument("--transport", default="torch", choices=["torch", "native"],
+    p.add_argument("--force-pipeline", action="store_true",
+                   help="run the N>1 code path (process group, HipStage, ring driver with a self send/recv) even with one rank; plumbing check")
+    p.add_argument("--transport", default="native", choices=["torch", "native"],
                    help="N>1 hidden-state hand-off: torch.distributed P2P ops (backend nccl = RCCL) or libthk's thk_pp_* (RCCL directly)")
     return p.parse_args()
 
@@ -120,6 +122,7 @@ def main():
     if world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
     N = world
+    PIPE = N > 1 or args.force_pipeline          # pipeline driver path
     thk = graft.load_package()
     graft.build_libthk()
     shape = model_shape(thk, args.model)
@@ -127,8 +130,9 @@ def main():
 
     import torch
     dist = None
-    if N > 1:
+    if PIPE:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
@@ -143,7 +147,7 @@ def main():
         from token_hawk_amd.pipeline import HipStage, PipelineDriver, layer_range
         S = N
         t_setup = time.time()
-        if N == 1:
+        if not PIPE:
             model = thk.Model(ctx, shape, n_seq=1)
             model.fill_synthetic()
             if args.lmhead == "faithful":
@@ -154,15 +158,34 @@ def main():
             stage = HipStage(thk, ctx, shape, rank, N, S, dev)
             model = stage.model
             if args.transport == "native":
+                # libthk's own RCCL path (measured ~15 us per hand-off vs ~190 us through torch P2P ops); every rank
+                # must agree, so success is all-reduced and the torch transport is the fallback.
                 import ctypes as C
                 uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-                if rank == 0:
-                    buf = C.create_string_buffer(128)
-                    assert ctx.lib.thk_pp_get_unique_id(buf) == 0
-                    uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+                ok = 1
+                try:
+                    if rank == 0:
+                        buf = C.create_string_buffer(128)
+                        if ctx.lib.thk_pp_get_unique_id(buf) != 0:
+                            raise RuntimeError("thk_pp_get_unique_id failed")
+                        uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+                except Exception as e:
+                    log(f"[bench r{rank}] native transport unavailable: {e}"); ok = 0
                 dist.broadcast(uid, 0)
                 torch.cuda.synchronize(dev)
-                stage.attach_native_transport(rank, N, bytes(uid.cpu().numpy().tobytes()))
+                if ok:
+                    try:
+                        stage.attach_native_transport(rank, N, bytes(uid.cpu().numpy().tobytes()))
+                    except Exception as e:
+                        log(f"[bench r{rank}] thk_pp_create failed: {e}"); ok = 0
+                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    if getattr(stage, "pp", None) is not None:
+                        ctx.lib.thk_pp_destroy(stage.pp)
+                    stage.pp = None
+                    args.transport = "torch"
+                    log(f"[bench r{rank}] falling back to the torch.distributed transport")
         l0, l1 = layer_range(shape.n_layer, rank, N)
         ctx.sync()
         log(f"[bench r{rank}] {info['name']} cus={info['n_cu']} layers [{l0},{l1}) model ready in {time.time() - t_setup:.1f}s")
@@ -170,13 +193,13 @@ def main():
         # ---- fill the KV caches: run the (T-1)-token synthetic prompts through the decode path
         prompts = np.stack([synthetic_prompt(shape, T, s) for s in range(S)], axis=1)     # [T, S]
         t_fill = time.time()
-        if N == 1:
+        if not PIPE:
             if T > 1:
                 model.eval(prompts[:T - 1, 0], 0, want_logits=False)
             model.seq_set(0, int(prompts[T - 1, 0]), T - 1)
             drv = None
         else:
-            drv = PipelineDriver(stage, rank, N, S)
+            drv = PipelineDriver(stage, rank, N, S, force_ring=(N == 1))
             for s in range(S):
                 stage.set_seq(s, int(prompts[0, s]), 0)
             if T > 1:
@@ -188,7 +211,7 @@ def main():
         log(f"[bench r{rank}] KV filled to n_past={T - 1} in {time.time() - t_fill:.2f}s")
 
         def run_steps(k):
-            if N == 1:
+            if not PIPE:
                 model.decode_steps(k, 0, advance=False)       # multi-step graph replays (8 steps per launch)
             else:
                 drv.run(k, advance=False)
@@ -225,7 +248,7 @@ def main():
             "data": "synthetic (seeded Irwin-Hall~N(0,0.02^2) f16 weights, seeded prompt ids)",
             "config": {"workload": f"LLaMA-{args.model.upper()} f16, {T}-ctx single-token greedy decode (n_past={T - 1}), "
                                    f"{'1 sequence' if N == 1 else f'{S} sequences in flight, layers pipelined over {N} GPUs (RCCL p2p)'}",
-                       "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single", "transport": args.transport if N > 1 else None,
+                       "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single", "transport": args.transport if PIPE else None,
                        "lmhead_mode": args.lmhead, "numerics": "f16 GGML weights x f32 activations, f32 accumulate, f32 KV cache (as the reference)",
                        "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "attn_waves", "use_graph")}},
             "bytes_per_token": b_tok,
@@ -233,8 +256,8 @@ def main():
                               "frac_of_copy_rate": round(step_gbs / COPY_RATE_GBS, 4), "event_ms_per_step": round(ev_ms / args.steps, 4)},
         }
         if rank == 0:
-            gen, ngen, pos = (model.seq_get(0) if (N == 1) else ([], 0, 0))
-            if N == 1:
+            gen, ngen, pos = (model.seq_get(0) if not PIPE else ([], 0, 0))
+            if not PIPE:
                 result["config"]["greedy_tokens_tail"] = [int(t) for t in gen[-4:]]
                 assert pos == T - 1, "hold-position protocol violated"
 
@@ -266,6 +289,8 @@ def main():
                 result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if rank == 0:
             print(json.dumps(result), flush=True)
+        if stage is not None and getattr(stage, "pp", None) is not None:
+            ctx.lib.thk_pp_destroy(stage.pp)
         model.close()
         ctx.close()
     if dist is not None:
