@@ -123,8 +123,13 @@ def main():
         log(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
     N = world
     PIPE = N > 1 or args.force_pipeline          # pipeline driver path
+    if not os.path.exists(graft.LIB):          # the prebuilt .so travels with the tree; never rebuild concurrently from N ranks
+        if local_rank == 0:
+            graft.build_libthk()
+        else:
+            while not os.path.exists(graft.LIB):
+                time.sleep(1.0)
     thk = graft.load_package()
-    graft.build_libthk()
     shape = model_shape(thk, args.model)
     T = min(args.ctx, shape.n_ctx)
 
