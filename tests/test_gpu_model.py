@@ -305,6 +305,27 @@ def test_prefill_equals_token_by_token(thk, orc, ctx, M, n_past):
     m.close()
 
 
+@pytest.mark.parametrize("M,n_past", [(129, 0), (200, 7), (256, 0)])
+def test_prefill_in_slabs_of_128(thk, ctx, M, n_past):
+    """Prompts longer than 128 tokens go through the layers in slabs; later slabs attend to the rows the earlier
+    ones cached.  Compared with token-by-token decode of the same prompt on a second model instance."""
+    shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=320)
+    a = thk.Model(ctx, shape); a.fill_synthetic(); a.finalize()
+    b = thk.Model(ctx, shape); b.fill_synthetic(); b.finalize()
+    rng = np.random.default_rng(M)
+    toks = np.concatenate([[1], rng.integers(3, 2048, n_past + M)]).astype(np.int32)
+    if n_past:
+        a.eval(toks[:n_past], 0)
+    lp = a.prefill(toks[n_past:n_past + M], n_past)
+    ld, _ = b.eval(toks[:n_past + M], 0)
+    assert np.abs(lp - ld).max() < LOGIT_TOL
+    assert int(lp.argmax()) == int(ld.argmax())
+    nxt = int(toks[n_past + M])
+    la, _ = a.eval([nxt], n_past + M); lb, _ = b.eval([nxt], n_past + M)
+    assert np.abs(la - lb).max() < LOGIT_TOL
+    a.close(); b.close()
+
+
 def test_prefill_full_width_128_tokens(thk, orc, ctx):
     """128-token prompt at 7B row geometry (2 layers): MFMA GEMMs at (M=128, C=4096/11008) vs token-by-token decode."""
     shape = thk.ModelShape(n_layer=2)

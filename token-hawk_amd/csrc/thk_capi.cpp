@@ -113,17 +113,12 @@ static int64_t tun(thk_ctx* ctx, const char* name) {
 }
 static void default_tunables(thk_ctx* ctx) {
     ctx->tun["gemv_blocks_per_cu"] = 4;   // resident 256-thread workgroups per CU for the streaming mat-vecs
-    // per-kernel overrides (0 = gemv_blocks_per_cu); defaults from tools/sweep.py on MI355X (profiles/)
-    ctx->tun["gemv_bpc_qkv"] = 3;
-    ctx->tun["gemv_bpc_wo"] = 2;
-    ctx->tun["gemv_bpc_w13"] = 8;
-    ctx->tun["gemv_bpc_w2"] = 2;
-    ctx->tun["gemv_bpc_head"] = 8;
-    ctx->tun["gemv_variant_qkv"] = 0;     // (rows/iteration, slots/batch) variant, see gemv_variant()
-    ctx->tun["gemv_variant_wo"] = 0;
-    ctx->tun["gemv_variant_w13"] = 0;
-    ctx->tun["gemv_variant_w2"] = 2;
-    ctx->tun["gemv_variant_head"] = 1;
+    // per-kernel launch geometry: -1 = auto (table below, from tools/sweep.py on MI355X, profiles/r01_sweep_*.json),
+    // 0 = gemv_blocks_per_cu / variant 0, > 0 = explicit
+    for (const char* k : {"qkv", "wo", "w13", "w2", "head"}) {
+        ctx->tun[std::string("gemv_bpc_") + k] = -1;
+        ctx->tun[std::string("gemv_variant_") + k] = -1;   // (rows/iteration, slots/batch) variant, see gemv_variant()
+    }
     ctx->tun["attn_splits"] = 4;          // context splits per head (1,2,4,8)
     ctx->tun["attn_waves"] = 8;           // waves per attention block (4 or 8)
     ctx->tun["attn_combine"] = 0;         // last-arriving split block of a head merges the partials inside the attention launch (measured: slower)
@@ -131,8 +126,25 @@ static void default_tunables(thk_ctx* ctx) {
     ctx->tun["fuse_attn_wo"] = 0;         // attention splits + wo mat-vec in one launch (in-launch hand-off)
     ctx->tun["fuse_initial_sleeps"] = 0;  // consumer s_sleep(32) repetitions (~0.85 us each) before the first poll
 }
-static int grid_for(thk_ctx* ctx, const char* specific, int n_groups) {
+// Auto launch geometry per (kernel, n_embd): {blocks per CU, variant}.  7B and 13B rows are swept values; other
+// widths take the 7B row.
+struct Geo { int bpc, var; };
+static Geo auto_geometry(const char* kernel, int n_embd) {
+    const bool w13b = n_embd == 5120;
+    if (!strcmp(kernel, "qkv")) return w13b ? Geo{3, 3} : Geo{3, 0};
+    if (!strcmp(kernel, "wo")) return Geo{2, 0};
+    if (!strcmp(kernel, "w13")) return w13b ? Geo{8, 1} : Geo{8, 0};
+    if (!strcmp(kernel, "w2")) return Geo{2, 2};
+    if (!strcmp(kernel, "head")) return w13b ? Geo{8, 2} : Geo{8, 1};
+    return Geo{4, 0};
+}
+static int resolve_variant(thk_ctx* ctx, const char* kernel, int n_embd) {
+    const int64_t v = tun(ctx, (std::string("gemv_variant_") + kernel).c_str());
+    return v < 0 ? auto_geometry(kernel, n_embd).var : (int)v;
+}
+static int grid_for(thk_ctx* ctx, const char* specific, int n_groups, int n_embd = 4096) {
     int64_t bpc = tun(ctx, specific);
+    if (bpc < 0 && !strncmp(specific, "gemv_bpc_", 9)) bpc = auto_geometry(specific + 9, n_embd).bpc;
     if (bpc <= 0) bpc = tun(ctx, "gemv_blocks_per_cu");
     if (bpc <= 0) bpc = 4;
     int64_t g = (int64_t)ctx->n_cu * bpc;
@@ -297,10 +309,11 @@ extern "C" int thk_buf_copy(thk_ctx* ctx, thk_buf* dst, size_t dst_off, thk_buf*
 
 // ---------------------------------------------------------------- operators
 static int gemv_simple(thk_ctx* ctx, int pro, int epi, const char* var_name, const char* bpc_name, GemvArgs& a, int rows) {
-    const int nru = (int)tun(ctx, var_name);
+    int nru = (int)tun(ctx, var_name);
+    if (nru < 0) nru = auto_geometry(var_name + 13 /* past "gemv_variant_" */, a.C == 5120 ? 5120 : 4096).var;
     const int NR = gemv_rows_per_group(a.C, epi, nru);
     a.n_groups = (rows + NR - 1) / NR;
-    const int grid = grid_for(ctx, bpc_name, a.n_groups);
+    const int grid = grid_for(ctx, bpc_name, a.n_groups, a.C == 5120 ? 5120 : 4096);
     HIPCHK(ctx, launch_gemv(pro, epi, nru, a, grid, true, ctx->stream));
     return grid;
 }
@@ -746,13 +759,13 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->attn_waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
     m->attn_combine = tun(ctx, "attn_combine") != 0 && m->nsplit > 1;
     m->fuse_attn_wo = tun(ctx, "fuse_attn_wo") != 0 && m->nsplit > 1 && (D == 64 || D == 128);
-    m->var_qkv = (int)tun(ctx, "gemv_variant_qkv"); m->var_wo = (int)tun(ctx, "gemv_variant_wo");
-    m->var_w13 = (int)tun(ctx, "gemv_variant_w13"); m->var_w2 = (int)tun(ctx, "gemv_variant_w2"); m->var_head = (int)tun(ctx, "gemv_variant_head");
-    m->grid_qkv = grid_for(ctx, "gemv_bpc_qkv", (int)(3 * E / 2));
-    m->grid_wo = grid_for(ctx, "gemv_bpc_wo", (int)((E + gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo) - 1) / gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo)));
-    m->grid_w13 = grid_for(ctx, "gemv_bpc_w13", (int)F);
-    m->grid_w2 = grid_for(ctx, "gemv_bpc_w2", (int)((E + gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2) - 1) / gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2)));
-    m->grid_head = grid_for(ctx, "gemv_bpc_head", (int)((V + gemv_rows_per_group((int)E, GEMV_EPI_HEAD, m->var_head) - 1) / gemv_rows_per_group((int)E, GEMV_EPI_HEAD, m->var_head)));
+    m->var_qkv = resolve_variant(ctx, "qkv", (int)E); m->var_wo = resolve_variant(ctx, "wo", (int)E);
+    m->var_w13 = resolve_variant(ctx, "w13", (int)E); m->var_w2 = resolve_variant(ctx, "w2", (int)E); m->var_head = resolve_variant(ctx, "head", (int)E);
+    m->grid_qkv = grid_for(ctx, "gemv_bpc_qkv", (int)(3 * E / 2), (int)E);
+    m->grid_wo = grid_for(ctx, "gemv_bpc_wo", (int)((E + gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo) - 1) / gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo)), (int)E);
+    m->grid_w13 = grid_for(ctx, "gemv_bpc_w13", (int)F, (int)E);
+    m->grid_w2 = grid_for(ctx, "gemv_bpc_w2", (int)((E + gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2) - 1) / gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2)), (int)E);
+    m->grid_head = grid_for(ctx, "gemv_bpc_head", (int)((V + gemv_rows_per_group((int)E, GEMV_EPI_HEAD, m->var_head) - 1) / gemv_rows_per_group((int)E, GEMV_EPI_HEAD, m->var_head)), (int)E);
     // working buffers
 #define ALLOCZ(ptr, bytes)                                                                                              \
     do {                                                                                                                \
@@ -804,7 +817,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
 
 // Bounded in-launch waits raise a device-side error word instead of hanging; surface it.
 static int check_fuse_error(thk_model* m) {
-    if (!m->fuse_counters) return THK_OK;
+    if (!m->fuse_counters || !m->fuse_attn_wo) return THK_OK;   // only the fused experiment has in-launch waits
     unsigned e = 0;
     const int nl = m->l1 - m->l0;
     HIPCHK(m->ctx, hipMemcpyAsync(&e, m->fuse_counters + (size_t)nl * kFuseStride, 4, hipMemcpyDeviceToHost, m->ctx->stream));
@@ -955,11 +968,20 @@ extern "C" int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_ent
 // M mat-vec passes.  Semantics == feeding the tokens one at a time (the reference's own batch path
 // is disabled, th-llama.cpp:15, and its causal mask is only right at n_past == 0, Q5): causal
 // attention over the f32 cache, K/V rows appended at [n_past, n_past+M), logits of the last token.
-struct PrefillBufs { float *X, *XN, *Q, *K, *V, *ATT, *U1, *U3; int32_t* tok; void* ws; };
+//
+// Per 128-token slab and layer, 12 launches: norm->X image | wq,wk,wv GEMM | reduce + RoPE + KV write | causal
+// attention | X image | wo GEMM | reduce + residual | norm->X image | w1,w3 GEMM | reduce + SwiGLU -> X image |
+// w2 GEMM | reduce + residual.  (thk_prefill.hip explains the GEMM: LDS-DMA pipeline, stream-K, hi/lo split.)
+struct PrefillBufs { float *X, *Q, *ATT; int32_t* tok; char *imgE, *imgF; float* part; };
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 static int prefill_workspace(thk_model* m, PrefillBufs* b) {
     thk_ctx* ctx = m->ctx;
-    const size_t E = m->hp.n_embd, F = m->n_ff, T = m->hp.n_ctx;
-    const size_t per = T * E * 4, bytes = 6 * per + 2 * T * F * 4 + T * 4 + 256 + std::max(gemm_prefill_workspace_bytes(128, (int)F, (int)E), gemm_prefill_workspace_bytes(128, (int)E, (int)F));
+    const int E = m->hp.n_embd, F = m->n_ff;
+    const size_t per = align256((size_t)128 * E * 4);
+    const PrefillPlan pq = prefill_plan(128, E, 3, E), po = prefill_plan(128, E, 1, E), p13 = prefill_plan(128, F, 2, E), p2 = prefill_plan(128, E, 1, F);
+    const size_t imgE = align256(pq.ximg_bytes), imgF = align256(p2.ximg_bytes);
+    const size_t part = align256(4 * std::max(std::max(pq.part_floats, po.part_floats), std::max(p13.part_floats, p2.part_floats)));
+    const size_t bytes = 3 * per + 1024 + imgE + imgF + part;
     if (m->prefill_ws_bytes < bytes) {
         if (m->prefill_ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(m->prefill_ws)); m->prefill_ws = nullptr; }
         hipError_t e = hipMalloc(&m->prefill_ws, bytes);
@@ -967,9 +989,44 @@ static int prefill_workspace(thk_model* m, PrefillBufs* b) {
         m->prefill_ws_bytes = bytes;
     }
     char* p = (char*)m->prefill_ws;
-    b->X = (float*)p; p += per; b->XN = (float*)p; p += per; b->Q = (float*)p; p += per; b->K = (float*)p; p += per;
-    b->V = (float*)p; p += per; b->ATT = (float*)p; p += per; b->U1 = (float*)p; p += T * F * 4; b->U3 = (float*)p; p += T * F * 4;
-    b->tok = (int32_t*)p; p += (T * 4 + 255) / 256 * 256; b->ws = p;
+    b->X = (float*)p; p += per; b->Q = (float*)p; p += per; b->ATT = (float*)p; p += per;
+    b->tok = (int32_t*)p; p += 1024; b->imgE = p; p += imgE; b->imgF = p; p += imgF; b->part = (float*)p;
+    return THK_OK;
+}
+
+// one slab of M <= 128 prompt tokens at positions [n_past, n_past + M) through every layer
+static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const int32_t* tokens, int M, int n_past) {
+    thk_ctx* ctx = m->ctx;
+    hipStream_t st = ctx->stream;
+    const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, T = m->hp.n_ctx;
+    const PrefillPlan pq = prefill_plan(M, E, 3, E), po = prefill_plan(M, E, 1, E), p13 = prefill_plan(M, F, 2, E), p2 = prefill_plan(M, E, 1, F);
+    HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));   // tokens may be a stack buffer
+    HIPCHK(ctx, launch_embed_rows(m->tok_embeddings, b.tok, M, E, b.X, st));
+    for (int i = 0; i < m->l1 - m->l0; ++i) {
+        const LayerW& L = m->layers[i];
+        float* kc = sb.kv + (size_t)i * 2 * T * E;
+        float* vc = kc + (size_t)T * E;
+        const uint16_t* wqkv[3] = {L.wq, L.wk, L.wv};
+        const uint16_t* w13[2] = {L.w1, L.w3};
+        HIPCHK(ctx, launch_prefill_ximg(b.X, L.attention_norm, M, E, b.imgE, st));
+        HIPCHK(ctx, launch_prefill_gemm(wqkv, pq, b.imgE, b.part, st));
+        HIPCHK(ctx, launch_prefill_reduce_qkv(b.part, pq, m->rope_tab, n_past, D, b.Q, kc, vc, st));
+        {
+            AttnArgs a{};
+            a.q = b.Q; a.kcache = kc; a.vcache = vc; a.pos_ptr = nullptr; a.pos_val = n_past; a.H = H; a.D = D;
+            a.nsplit = 1; a.tc = n_past + M; a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = M; a.out = b.ATT;
+            HIPCHK(ctx, launch_attn_decode(a, st));
+        }
+        HIPCHK(ctx, launch_prefill_ximg(b.ATT, nullptr, M, E, b.imgE, st));
+        HIPCHK(ctx, launch_prefill_gemm(&L.wo, po, b.imgE, b.part, st));
+        HIPCHK(ctx, launch_prefill_reduce_store(b.part, po, b.X, true, st));
+        HIPCHK(ctx, launch_prefill_ximg(b.X, L.ffn_norm, M, E, b.imgE, st));
+        HIPCHK(ctx, launch_prefill_gemm(w13, p13, b.imgE, b.part, st));
+        HIPCHK(ctx, launch_prefill_reduce_swiglu(b.part, p13, b.imgF, st));
+        HIPCHK(ctx, launch_prefill_gemm(&L.w2, p2, b.imgF, b.part, st));
+        HIPCHK(ctx, launch_prefill_reduce_store(b.part, p2, b.X, true, st));
+    }
     return THK_OK;
 }
 
@@ -980,6 +1037,7 @@ extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* token
     REQUIRE(ctx, (m->flags & THK_STAGE_EMBED) && (m->flags & THK_STAGE_HEAD), "thk_model_prefill needs a full-model stage (embedding + head)");
     REQUIRE(ctx, seq >= 0 && seq < m->n_seq && tokens, "bad sequence %d / null tokens", seq);
     REQUIRE(ctx, n_tokens >= 1 && n_past >= 0 && n_past + n_tokens <= m->hp.n_ctx, "n_past=%d + n_tokens=%d exceeds n_ctx=%d", n_past, n_tokens, m->hp.n_ctx);
+    REQUIRE(ctx, m->hp.n_embd % 32 == 0 && m->n_ff % 32 == 0, "thk_model_prefill needs n_embd and n_ff to be multiples of 32");
     for (int i = 0; i < n_tokens; ++i) REQUIRE(ctx, tokens[i] >= 0 && tokens[i] < m->hp.n_vocab, "token id %d out of range", tokens[i]);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PrefillBufs b{};
@@ -987,55 +1045,22 @@ extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* token
     if (rc != THK_OK) return rc;
     hipStream_t st = ctx->stream;
     SeqBuf& sb = m->seqs[seq];
-    const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, V = m->hp.n_vocab, T = m->hp.n_ctx, M = n_tokens;
-    const size_t ME = (size_t)M * E;
-    HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));   // tokens may be a stack buffer
-    HIPCHK(ctx, launch_embed_rows(m->tok_embeddings, b.tok, M, E, b.X, st));
-    auto norm_rows = [&](const float* gain) -> int {   // XN = rms_norm(X) * gain   (K4 + K5, row-wise)
-        HIPCHK(ctx, hipMemcpyAsync(b.XN, b.X, ME * 4, hipMemcpyDeviceToDevice, st));
-        HIPCHK(ctx, launch_rms_norm(b.XN, M, E, st));
-        HIPCHK(ctx, launch_row_mul(b.XN, gain, M, E, st));
-        return THK_OK;
-    };
-    for (int i = 0; i < m->l1 - m->l0; ++i) {
-        const LayerW& L = m->layers[i];
-        float* kc = sb.kv + (size_t)i * 2 * T * E;
-        float* vc = kc + (size_t)T * E;
-        if ((rc = norm_rows(L.attention_norm)) != THK_OK) return rc;
-        HIPCHK(ctx, launch_gemm_f16_prefill(L.wq, E, E, b.XN, M, b.Q, b.ws, st));
-        HIPCHK(ctx, launch_gemm_f16_prefill(L.wk, E, E, b.XN, M, b.K, b.ws, st));
-        HIPCHK(ctx, launch_gemm_f16_prefill(L.wv, E, E, b.XN, M, b.V, b.ws, st));
-        HIPCHK(ctx, launch_rope(b.Q, m->rope_tab, M, H, D, n_past, st));
-        HIPCHK(ctx, launch_rope(b.K, m->rope_tab, M, H, D, n_past, st));
-        HIPCHK(ctx, hipMemcpyAsync(kc + (size_t)n_past * E, b.K, ME * 4, hipMemcpyDeviceToDevice, st));   // rows [n_past, n_past+M)
-        HIPCHK(ctx, hipMemcpyAsync(vc + (size_t)n_past * E, b.V, ME * 4, hipMemcpyDeviceToDevice, st));
-        {
-            AttnArgs a{};
-            a.q = b.Q; a.kcache = kc; a.vcache = vc; a.pos_ptr = nullptr; a.pos_val = n_past; a.H = H; a.D = D;
-            a.nsplit = 1; a.tc = n_past + M; a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = M; a.out = b.ATT;
-            HIPCHK(ctx, launch_attn_decode(a, st));
-        }
-        HIPCHK(ctx, launch_gemm_f16_prefill(L.wo, E, E, b.ATT, M, b.Q, b.ws, st));
-        HIPCHK(ctx, launch_add(b.X, b.Q, b.X, ME, st));
-        if ((rc = norm_rows(L.ffn_norm)) != THK_OK) return rc;
-        HIPCHK(ctx, launch_gemm_f16_prefill(L.w1, F, E, b.XN, M, b.U1, b.ws, st));
-        HIPCHK(ctx, launch_gemm_f16_prefill(L.w3, F, E, b.XN, M, b.U3, b.ws, st));
-        HIPCHK(ctx, launch_silu(b.U1, (size_t)M * F, st));
-        HIPCHK(ctx, launch_mul(b.U1, b.U3, (size_t)M * F, st));
-        HIPCHK(ctx, launch_gemm_f16_prefill(L.w2, E, F, b.U1, M, b.Q, b.ws, st));
-        HIPCHK(ctx, launch_add(b.X, b.Q, b.X, ME, st));
+    const int E = m->hp.n_embd, V = m->hp.n_vocab, M = n_tokens;
+    int last = 0;
+    for (int m0 = 0; m0 < M; m0 += 128) {     // slabs of <= 128 tokens; later slabs attend to the rows earlier ones cached
+        last = std::min(128, M - m0);
+        if ((rc = prefill_slab(m, sb, b, tokens + m0, last, n_past + m0)) != THK_OK) return rc;
     }
     {   // final norm + lm-head on the last token only (th-llama.cpp:253-262, aOffset = (r-1)*c)
         GemvArgs a{};
         a.W[0] = m->output; a.R = V; a.C = E;
         const int NR = gemv_rows_per_group(E, GEMV_EPI_HEAD, m->var_head);
         a.n_groups = (V + NR - 1) / NR;
-        a.x = b.X + (size_t)(M - 1) * E; a.gain = m->norm; a.y = sb.logits;
+        a.x = b.X + (size_t)(last - 1) * E; a.gain = m->norm; a.y = sb.logits;
         a.lm_faithful = m->lm_mode == THK_LMHEAD_FAITHFUL; q1_constants(V, &a.q1_split, &a.q1_cov);
         a.block_best = m->block_best;
         HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, m->nt != 0, st));
-        HIPCHK(ctx, hipMemcpyAsync(m->x, b.X + (size_t)(M - 1) * E, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(m->x, b.X + (size_t)(last - 1) * E, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
     }
     rc = set_seq_state(m, seq, tokens[M - 1], n_past + M - 1, false);
     if (rc != THK_OK) return rc;

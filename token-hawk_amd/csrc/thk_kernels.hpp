@@ -97,5 +97,18 @@ hipError_t launch_synth_gain(uint64_t key, float scale, size_t n, float* out, hi
 // thk_prefill.hip
 hipError_t launch_gemm_f16_prefill(const uint16_t* W, int R, int C, const float* X, int M, float* Y, void* workspace, hipStream_t st);
 size_t gemm_prefill_workspace_bytes(int M, int R, int C);
+// v3 (LDS-DMA pipeline + stream-K): activations are staged once as an "X image" (hi/lo f16, the LDS layout of
+// the MFMA loop), up to 3 matrices sharing the operand run in one launch, partial tiles are reduced by a
+// kernel that carries the fused epilogue.  M <= 128 tokens per call.
+struct PrefillPlan {
+    int M, MT, Mpad, R, Rpad, nmat, C, nchunks, rb_per_mat, rb_total, per, maxseg;
+    size_t ximg_bytes, slot_floats, part_floats;
+};
+PrefillPlan prefill_plan(int M, int R, int nmat, int C);
+hipError_t launch_prefill_ximg(const float* X, const float* gain_or_null, int M, int C, void* ximg, hipStream_t st);
+hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, const void* ximg, float* part, hipStream_t st);
+hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st);
+hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, float* kcache, float* vcache, hipStream_t st);
+hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st);
 
 }  // namespace thk

@@ -17,10 +17,9 @@
 // loads along K straight from row-major memory (no transposes), and each lane ends up
 // with 4 consecutive output features of one token => float4 stores.
 //
-// v1 structure (round 1): one wave per workgroup, tile = 32 weight rows x (32*MT) tokens,
-// W fragments streamed from HBM (each element read exactly once), X fragments served by
-// L1/L2 (X hi/lo is <= 5.6 MB and shared by all workgroups).  LDS staging of X and a
-// split-K / multi-wave schedule are the next steps.
+// Structure: see the block comment above gemm_prefill_v3_kernel (LDS-DMA pipeline, stream-K, fused reducers).
+// Two earlier kernels (one wave per workgroup; 4 waves with register-staged X and split-K) ran at the memory
+// latency -- 46 us per launch, 2.4x fetch amplification -- and were removed; profiles/ keeps their numbers.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "thk_kernels.hpp"
@@ -31,237 +30,369 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
-// X f32 [M,C] -> hi,lo f16 [Mpad,C] (rows >= M zero-filled so MFMA tiles need no masking)
-__global__ void split_hi_lo_kernel(const float* __restrict__ X, int M, int Mpad, int C, _Float16* __restrict__ hi, _Float16* __restrict__ lo) {
-    const size_t n = (size_t)Mpad * C;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const size_t row = i / C;
-        float x = row < (size_t)M ? X[i] : 0.f;
-        const _Float16 h = (_Float16)x;
-        hi[i] = h;
-        lo[i] = (_Float16)(x - (float)h);
-    }
+__device__ __forceinline__ float wave_sum_prefill(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
 }
 
-// One wave: rows [r0, r0+32) of W, tokens [0, 32*MT).
-template <int MT>
-__global__ __launch_bounds__(64) void gemm_prefill_kernel(const uint16_t* __restrict__ Wp, int R, int C,
-                                                          const _Float16* __restrict__ Xhi, const _Float16* __restrict__ Xlo,
-                                                          int M, float* __restrict__ Y) {
-    const int lane = threadIdx.x;
-    const int r0 = blockIdx.x * 32;
-    const int li = lane & 31, kh = (lane >> 5) * 8;
-    int wrow = r0 + li; if (wrow >= R) wrow = R - 1;          // clamp (results of clamped rows are not stored)
-    const _Float16* wp = reinterpret_cast<const _Float16*>(Wp) + (size_t)wrow * C + kh;
-    const _Float16* xh = Xhi + (size_t)li * C + kh;
-    const _Float16* xl = Xlo + (size_t)li * C + kh;
-
-    f16v acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-    for (int k0 = 0; k0 < C; k0 += 32) {       // two K=16 steps per iteration
-        const h8 a0 = __builtin_nontemporal_load(reinterpret_cast<const h8*>(wp + k0));
-        const h8 a1 = __builtin_nontemporal_load(reinterpret_cast<const h8*>(wp + k0 + 16));
-        h8 bh0[MT], bl0[MT], bh1[MT], bl1[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const size_t off = (size_t)t * 32 * C + k0;
-            bh0[t] = *reinterpret_cast<const h8*>(xh + off); bl0[t] = *reinterpret_cast<const h8*>(xl + off);
-            bh1[t] = *reinterpret_cast<const h8*>(xh + off + 16); bl1[t] = *reinterpret_cast<const h8*>(xl + off + 16);
-        }
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bh0[t], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bl0[t], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bh1[t], acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bl1[t], acc[t], 0, 0, 0);
-        }
-    }
-    // D[row -> weight row][col -> token]; lane holds token (lane&31), 4 groups of 4 consecutive rows
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const int tok = t * 32 + li;
-        if (tok < M) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r = r0 + 8 * g + 4 * (lane >> 5);
-                float* dst = Y + (size_t)tok * R + r;
-                if (r + 3 < R) {
-                    *reinterpret_cast<f4*>(dst) = f4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-                } else {
-                    for (int e = 0; e < 4; ++e) if (r + e < R) dst[e] = acc[t][4 * g + e];
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------- v2: LDS-staged X, 4 waves, split-K
-// Workgroup = 4 waves = 128 weight rows x (32*MT) tokens; the four waves share one X tile (hi and
-// lo, 64 columns at a time, double-buffered in LDS with a 16-byte row pad => conflict-free
-// ds_read_b128), each wave streams its own 32 weight rows straight from HBM.  K is split across
-// gridDim.y workgroups so that small matrices still fill the chip; partial tiles go to a workspace
-// and are summed in a fixed order by reduce_splits_kernel (deterministic, no atomics).
 constexpr int kKC = 32;                  // K columns per LDS stage (2 MFMA k-steps)
-constexpr int kXS = kKC + 8;             // LDS row stride in halfs (80 B = 5 x 16-byte slots: conflict-free)
-constexpr int kKSteps = kKC / 16;
+
+// ---------------------------------------------------------------- LDS-DMA pipeline, stream-K
+// A kernel that keeps one K-chunk of loads in flight per wave runs, at one workgroup per CU, at the memory
+// LATENCY (measured: 46 us per launch, 2.4 TB/s of fetch for 1.3 TB/s of weights).  This one is built
+// around memory-level parallelism instead:
+//   * activations are written ONCE per operand into the exact LDS image the MFMA loop reads
+//     ("X image": per 32-column K-chunk, [hi|lo][token][64 B], XOR-swizzled pieces => conflict-free
+//     ds_read_b128), so a stage is a linear 1 KiB-per-instruction global_load_lds copy;
+//   * weights also arrive by global_load_lds (quad-coalesced, same swizzle), so no VGPR is tied up
+//     by data in flight and hipcc's waitcnt bookkeeping is out of the picture: completion is counted
+//     by hand (s_waitcnt vmcnt(N), loads retire in order);
+//   * kNST LDS stages of 32 KB => (kNST-1) chunks = 96 KB per CU in flight across a raw s_barrier;
+//   * a wave owns 64 weight rows (two A fragments share every B fragment read), a workgroup 256 rows x 128 tokens;
+//   * stream-K: the (row-block, K-chunk) space of up to three matrices that share the operand
+//     (wq|wk|wv, w1|w3) is flattened and cut into kG equal contiguous shares, one per workgroup, so
+//     every CU streams the same number of bytes whatever the shape.  A workgroup's share spans at
+//     most `maxseg` row-blocks; each span goes to its own partial slot and the reducers below sum
+//     the slots of a row-block in workgroup order (deterministic, no atomics) and apply the fused
+//     epilogue (store | residual add | RoPE + KV-cache write | SwiGLU + hi/lo image for w2).
+constexpr int kV3Rows = 256;       // weight rows per workgroup (4 waves x 64)
+constexpr int kNST = 4;            // LDS stages
+constexpr int kG = 256;            // workgroups per launch: a constant, so results do not depend on the CU count
+
+static __host__ __device__ inline size_t ximg_stage_bytes(int MT) { return (size_t)MT * 32 * 64 * 2; }
+
+PrefillPlan prefill_plan(int M, int R, int nmat, int C) {
+    PrefillPlan p{};
+    p.M = M; p.MT = (M + 31) / 32; p.Mpad = p.MT * 32; p.R = R; p.nmat = nmat; p.C = C;
+    p.nchunks = C / kKC;
+    p.rb_per_mat = (R + kV3Rows - 1) / kV3Rows; p.Rpad = p.rb_per_mat * kV3Rows; p.rb_total = p.rb_per_mat * nmat;
+    const long total = (long)p.rb_total * p.nchunks;
+    p.per = (int)((total + kG - 1) / kG);
+    p.maxseg = (p.per - 1 + p.nchunks - 1) / p.nchunks + 1;
+    p.ximg_bytes = (size_t)p.nchunks * ximg_stage_bytes(p.MT);
+    p.slot_floats = (size_t)p.Mpad * kV3Rows;
+    p.part_floats = (size_t)kG * p.maxseg * p.slot_floats;
+    return p;
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Both operand tiles use one LDS layout: rows (tokens / weight rows) of 64 bytes = the chunk's 32 columns as four
+// 16-byte pieces, piece p of row r stored at position p ^ ((r >> 2) & 3).  That XOR makes the MFMA fragment read
+// (32 consecutive rows, one piece each) hit 16 different 16-byte bank groups per 16 lanes (SQ_LDS_BANK_CONFLICT = 0)
+// without row padding, and it lets the LOADER run quad-coalesced: lanes 4r..4r+3 fetch the four pieces of row r,
+// i.e. one 64-byte segment per quad, which the texture-address unit takes at 1 quad/clk.  The obvious
+// "each lane fetches its own fragment" pattern (32 rows x 2x16 B per instruction) runs at 1 LANE per clock:
+// 16 B/clk/CU instead of 55-64 (tools/probes/glds_rate_probe.hip, profiles/r01_glds_rate_probe.txt).
+__device__ __forceinline__ int swz_pos(int row, int piece) { return piece ^ ((row >> 2) & 3); }
+
+// The loads of one K-chunk (LPS = MT + 4 per wave) into LDS stage `sb`: this wave's share of the X image (already
+// in the layout above, so a linear copy) and its own 64 weight rows (16 rows x 64 B per instruction).
+// A plain function with by-value arguments: as a by-reference lambda the closure (and every captured local)
+// ended up in scratch.
+template <int MT>
+__device__ __forceinline__ void v3_issue_chunk(char* sb, const char* xs /* image of the chunk + lane*16 */, const _Float16* wcol /* matrix + chunk column + this lane's piece */,
+                                               int row0 /* loader row of instruction 0 */, int R, int C, int wave) {
+    constexpr int XI = MT * 32 * 64 * 2;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) glds16(xs + (wave + 4 * i) * 1024, sb + (wave + 4 * i) * 1024);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int row = row0 + 16 * j; row = row < R ? row : R - 1;      // rows past the matrix repeat the last one (their outputs are never read)
+        glds16(wcol + (size_t)row * C, sb + XI + (wave * 4 + j) * 1024);
+    }
+}
 
 template <int MT>
-__global__ __launch_bounds__(256) void gemm_prefill_v2_kernel(const uint16_t* __restrict__ Wp, int R, int C,
-                                                              const _Float16* __restrict__ Xhi, const _Float16* __restrict__ Xlo,
-                                                              int M, float* __restrict__ Yp, int chunks_per_split) {
-    __shared__ __attribute__((aligned(16))) _Float16 sh[2][2][MT * 32][kXS];   // [stage][hi/lo][token][k]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, kh = (lane >> 5) * 8;
-    const int r0 = blockIdx.x * 128 + wave * 32;
-    int wrow = r0 + li; if (wrow >= R) wrow = R - 1;
-    const _Float16* wp = reinterpret_cast<const _Float16*>(Wp) + (size_t)wrow * C + kh;
-    const int nchunks = C / kKC;
-    const int c_begin = blockIdx.y * chunks_per_split, c_end = min(nchunks, c_begin + chunks_per_split);
+__global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16* __restrict__ w0, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
+                                                                 const char* __restrict__ ximg, float* __restrict__ part, const PrefillPlan plan) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    constexpr int XI = MT * 32 * 64 * 2;               // X image bytes per stage (hi rows, then lo rows)
+    constexpr int WI = 4 * 64 * 64;                    // W image: 4 waves x 64 rows x 64 B
+    constexpr int ST = XI + WI;
+    constexpr int LPS = MT + 4;                        // loads per wave per stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    // plain scalars (lambdas capturing the kernarg struct by reference push it to scratch)
+    const int nchunks = plan.nchunks, rb_per_mat = plan.rb_per_mat, R = plan.R, C = plan.C, maxseg = plan.maxseg, per = plan.per;
+    const size_t slot_floats = plan.slot_floats;
+    const int total = plan.rb_total * nchunks;          // <= a few 10^4
+    const int g0 = blockIdx.x * per;
+    const int g1 = g0 + per < total ? g0 + per : total;
+    if (g0 >= g1) return;
 
-    f16v acc[MT];
+    // loader: lane -> (row lane>>2 of each 16-row group, position lane&3); the piece stored at that position
+    const int ld_piece = swz_pos(lane >> 2, lane & 3);   // (row>>2)&3 is the same for rows r and r+16k
+    // reader: fragment row li, piece 2*ks + (lane>>5)
+    const int rd0 = li * 64 + swz_pos(li, lane >> 5) * 16, rd1 = li * 64 + swz_pos(li, 2 + (lane >> 5)) * 16;
+    // issue cursor: (matrix, row-block in matrix, chunk) of the next flattened chunk to load
+    const int rbk_first = g0 / nchunks;
+    int i_mat = rbk_first / rb_per_mat, i_rbl = rbk_first % rb_per_mat, i_ch = g0 % nchunks, i_buf = 0;
+#define THK_ISSUE_NEXT()                                                                         \
+    {                                                                                            \
+        const _Float16* wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);                           \
+        v3_issue_chunk<MT>(lds + i_buf * ST, ximg + (size_t)i_ch * XI + lane * 16, wm + (size_t)i_ch * kKC + ld_piece * 8, \
+                           i_rbl * kV3Rows + wave * 64 + (lane >> 2), R, C, wave);                                      \
+        ++issued;                                                                                \
+        i_buf = i_buf + 1 == kNST ? 0 : i_buf + 1;                                               \
+        if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }  \
+    }
+    auto flush = [&](f16v (&acc)[2][MT], int seg) __attribute__((always_inline)) {    // accumulators -> partial slot [token][256 rows]
+        float* slot = part + ((size_t)blockIdx.x * maxseg + seg) * slot_floats;
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-    // X tile loader: (MT*32 rows) x (kKC/8) 16-byte segments per array, spread over the 256 threads
-    constexpr int SPR = kKC / 8;                       // segments per row
-    constexpr int NSEG = MT * 32 * SPR;                // segments per array
-    constexpr int SEG = (NSEG + 255) / 256;            // per thread
-    h8 xr[2][SEG];
-    auto load_x = [&](int chunk) {
+            for (int t = 0; t < MT; ++t)
 #pragma unroll
-        for (int i = 0; i < SEG; ++i) {
-            const int idx = min(tid + i * 256, NSEG - 1), row = idx / SPR, seg = idx % SPR;
-            const size_t off = (size_t)row * C + (size_t)chunk * kKC + seg * 8;
-            xr[0][i] = *reinterpret_cast<const h8*>(Xhi + off);
-            xr[1][i] = *reinterpret_cast<const h8*>(Xlo + off);
-        }
-    };
-    auto store_x = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < SEG; ++i) {
-            const int idx = tid + i * 256, row = idx / SPR, seg = idx % SPR;
-            if (idx < NSEG) {
-                *reinterpret_cast<h8*>(&sh[stage][0][row][seg * 8]) = xr[0][i];
-                *reinterpret_cast<h8*>(&sh[stage][1][row][seg * 8]) = xr[1][i];
-            }
-        }
-    };
-    h8 wr[kKSteps], wn[kKSteps];
-    auto load_w = [&](int chunk, h8 (&w)[kKSteps]) {
-#pragma unroll
-        for (int ks = 0; ks < kKSteps; ++ks) w[ks] = __builtin_nontemporal_load(reinterpret_cast<const h8*>(wp + (size_t)chunk * kKC + ks * 16));
+                for (int g = 0; g < 4; ++g) {
+                    float* dst = slot + (size_t)(t * 32 + li) * kV3Rows + wave * 64 + f * 32 + 8 * g + 4 * (lane >> 5);
+                    *reinterpret_cast<f4*>(dst) = f4{acc[f][t][4 * g], acc[f][t][4 * g + 1], acc[f][t][4 * g + 2], acc[f][t][4 * g + 3]};
+                }
     };
 
-    if (c_begin < c_end) {
-        load_x(c_begin); load_w(c_begin, wr);
-        store_x(0);
-        __syncthreads();
-        for (int c = c_begin; c < c_end; ++c) {
-            const int stage = (c - c_begin) & 1;
-            const bool more = c + 1 < c_end;
-            if (more) { load_x(c + 1); load_w(c + 1, wn); }      // next stage in flight during the MFMAs
+    int issued = g0;
 #pragma unroll
-            for (int ks = 0; ks < kKSteps; ++ks) {
+    for (int s = 0; s < kNST - 1; ++s)
+        if (issued < g1) THK_ISSUE_NEXT()
+    int buf = 0, rbk = rbk_first;
+    for (int s0 = g0; s0 < g1; ++rbk) {                // one pass per row-block this share touches
+        const int rb_end = (rbk + 1) * nchunks, s1 = rb_end < g1 ? rb_end : g1;
+        f16v acc[2][MT];
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[f][t][i] = 0.f;
+        for (int g = s0; g < s1; ++g) {
+            const int rem = g1 - 1 - g;                // chunks issued after g: min(rem, kNST-2)
+            if (rem >= 2) wait_vmcnt<2 * LPS>(); else if (rem == 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();              // every wave's loads of chunk g have landed; stage (buf-1) is free
+            if (issued < g1) THK_ISSUE_NEXT()
+            const char* sb = lds + buf * ST;
+            // Fragment reads of k-step 1 are issued right behind the first MFMA of k-step 0 and land under the other
+            // fifteen; hipcc only ever waits lgkmcnt(0) here, so the order is pinned by hand.
+            h8 af[2][2], bh[2][MT], bl[2][MT];
+            auto read_frags = [&](const int ks) __attribute__((always_inline)) {
+                const char* rp = sb + (ks == 0 ? rd0 : rd1);
+                af[ks][0] = *reinterpret_cast<const h8*>(rp + XI + wave * 4096);
+                af[ks][1] = *reinterpret_cast<const h8*>(rp + XI + wave * 4096 + 2048);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
-                    const h8 bh = *reinterpret_cast<const h8*>(&sh[stage][0][t * 32 + li][ks * 16 + kh]);
-                    const h8 bl = *reinterpret_cast<const h8*>(&sh[stage][1][t * 32 + li][ks * 16 + kh]);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ks], bh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wr[ks], bl, acc[t], 0, 0, 0);
+                    bh[ks][t] = *reinterpret_cast<const h8*>(rp + t * 2048);
+                    bl[ks][t] = *reinterpret_cast<const h8*>(rp + XI / 2 + t * 2048);
                 }
-            }
-            if (more) {
-                store_x(stage ^ 1);                              // the other buffer was last read one iteration ago
+            };
+            read_frags(0);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bh[0][0], acc[0][0], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bh[0][0], acc[1][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bl[0][0], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bl[0][0], acc[1][0], 0, 0, 0);
 #pragma unroll
-                for (int ks = 0; ks < kKSteps; ++ks) wr[ks] = wn[ks];
+            for (int t = 1; t < MT; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bh[0][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bh[0][t], acc[1][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bl[0][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bl[0][t], acc[1][t], 0, 0, 0);
             }
-            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bh[1][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][1], bh[1][t], acc[1][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bl[1][t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][1], bl[1][t], acc[1][t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            buf = buf + 1 == kNST ? 0 : buf + 1;
         }
+        flush(acc, rbk - rbk_first);                   // end of the row-block (or of this share): spill the tile
+        wait_vmcnt<0>();                               // stores share the counter with the DMA queue: drain, then count afresh
+        s0 = s1;
     }
-    float* Y = Yp + (size_t)blockIdx.y * M * R;
+#undef THK_ISSUE_NEXT
+}
+
+// ---- X-image writers -------------------------------------------------------------------------
+// byte offset of the 16-byte piece (token, 8 columns starting at col) inside the image
+__device__ __forceinline__ size_t ximg_off(int MT, int arr, int tok, int col) {
+    return (size_t)(col >> 5) * ximg_stage_bytes(MT) + (size_t)arr * MT * 32 * 64 + (size_t)tok * 64 + (size_t)(((col >> 3) & 3) ^ ((tok >> 2) & 3)) * 16;
+}
+__device__ __forceinline__ void ximg_store8(char* img, int MT, int tok, int col, const float (&v)[8]) {
+    h8 hi, lo;
 #pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const int tok = t * 32 + li;
+    for (int e = 0; e < 8; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+    *reinterpret_cast<h8*>(img + ximg_off(MT, 0, tok, col)) = hi;
+    *reinterpret_cast<h8*>(img + ximg_off(MT, 1, tok, col)) = lo;
+}
+// one workgroup per token row (pad rows are written as zeros).  NORM: v = (x * rsqrt(mean(x^2)+eps)) * gain  (K4+K5)
+template <bool NORM>
+__global__ __launch_bounds__(256) void ximg_from_rows_kernel(const float* __restrict__ X, const float* __restrict__ gain, int M, int MT, int C, char* __restrict__ img) {
+    __shared__ float red[4];
+    const int tok = blockIdx.x;
+    const float* row = X + (size_t)tok * C;
+    float inv = 1.f;
+    if (NORM) {
+        float ss = 0.f;
+        if (tok < M) for (int i = threadIdx.x; i < C; i += 256) ss += row[i] * row[i];
+        ss = wave_sum_prefill(ss);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        ss = (red[0] + red[1]) + (red[2] + red[3]);
+        inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
+    }
+    for (int col = threadIdx.x * 8; col < C; col += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
         if (tok < M) {
+            const f4 x0 = *reinterpret_cast<const f4*>(row + col), x1 = *reinterpret_cast<const f4*>(row + col + 4);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r = r0 + 8 * g + 4 * (lane >> 5);
-                float* dst = Y + (size_t)tok * R + r;
-                if (r + 3 < R) {
-                    *reinterpret_cast<f4*>(dst) = f4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-                } else {
-                    for (int e = 0; e < 4; ++e) if (r + e < R) dst[e] = acc[t][4 * g + e];
-                }
+            for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+            if (NORM) {
+                const f4 g0 = *reinterpret_cast<const f4*>(gain + col), g1 = *reinterpret_cast<const f4*>(gain + col + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = (v[e] * inv) * g0[e]; v[4 + e] = (v[4 + e] * inv) * g1[e]; }
             }
         }
+        ximg_store8(img, MT, tok, col, v);
     }
 }
 
-__global__ void reduce_splits_kernel(const float* __restrict__ part, int ks, size_t n4, float* __restrict__ Y) {
+// ---- reducers ----------------------------------------------------------------------------------
+// sum of the partial slots that hold rows [vr, vr+4) (virtual row = matrix * Rpad + row) of token tok
+__device__ __forceinline__ f4 sum_partials(const float* __restrict__ part, const PrefillPlan& p, int vr, int tok) {
+    const int rbk = vr / kV3Rows, within = vr % kV3Rows;
+    const long lo = (long)rbk * p.nchunks, hi = lo + p.nchunks - 1;
+    const int b0 = (int)(lo / p.per), b1 = (int)(hi / p.per);
+    f4 s = f4{0.f, 0.f, 0.f, 0.f};
+    for (int b = b0; b <= b1; ++b) {
+        const int seg = rbk - (int)(((long)b * p.per) / p.nchunks);
+        const float* slot = part + ((size_t)b * p.maxseg + seg) * p.slot_floats + (size_t)tok * kV3Rows + within;
+        const f4 v = *reinterpret_cast<const f4*>(slot);
+        s = b == b0 ? v : s + v;
+    }
+    return s;
+}
+// Y[tok][r] = sum  (mode 0)   |   Y[tok][r] += sum  (mode 1: residual)
+__global__ void reduce_store_kernel(const float* __restrict__ part, PrefillPlan p, float* __restrict__ Y, int mode) {
+    const int r4 = p.R / 4;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    f4 s = reinterpret_cast<const f4*>(part)[i];
-    for (int k = 1; k < ks; ++k) s += reinterpret_cast<const f4*>(part)[(size_t)k * n4 + i];
-    reinterpret_cast<f4*>(Y)[i] = s;
+    if (i >= (size_t)p.M * r4) return;
+    const int tok = (int)(i / r4), r = (int)(i % r4) * 4;
+    f4 s = sum_partials(part, p, r, tok);
+    f4* dst = reinterpret_cast<f4*>(Y + (size_t)tok * p.R + r);
+    if (mode == 1) s = *dst + s;
+    *dst = s;
+}
+// q -> RoPE -> Q[tok];  k -> RoPE -> K-cache row n_past+tok;  v -> V-cache row  (K6, th-llama.cpp:318-339)
+__global__ void reduce_qkv_kernel(const float* __restrict__ part, PrefillPlan p, const float* __restrict__ tab, int n_past, int D,
+                                  float* __restrict__ Q, float* __restrict__ kc, float* __restrict__ vc) {
+    const int r4 = p.R / 4;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)p.M * 3 * r4) return;
+    const int tok = (int)(i / (3 * r4)), rem = (int)(i % (3 * r4)), mat = rem / r4, r = (rem % r4) * 4;
+    f4 s = sum_partials(part, p, mat * p.Rpad + r, tok);
+    const int pos = n_past + tok;
+    if (mat < 2) {
+        const int half = D >> 1, jp = (r % D) >> 1;
+        const f4 cs = *reinterpret_cast<const f4*>(tab + ((size_t)pos * half + jp) * 2);     // cos0 sin0 cos1 sin1
+        s = f4{s[0] * cs[0] - s[1] * cs[1], s[0] * cs[1] + s[1] * cs[0], s[2] * cs[2] - s[3] * cs[3], s[2] * cs[3] + s[3] * cs[2]};
+    }
+    float* dst = mat == 0 ? Q + (size_t)tok * p.R + r : (mat == 1 ? kc : vc) + (size_t)pos * p.R + r;
+    *reinterpret_cast<f4*>(dst) = s;
+}
+// hidden = silu(w1 x) * (w3 x)  (K10, K11) written straight into the X image of the w2 GEMM (C = R of this plan)
+__global__ void reduce_swiglu_ximg_kernel(const float* __restrict__ part, PrefillPlan p, char* __restrict__ img) {
+    const int r8 = p.R / 8;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)p.Mpad * r8) return;
+    const int tok = (int)(i / r8), r = (int)(i % r8) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (tok < p.M) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const f4 u1 = sum_partials(part, p, r + 4 * h, tok), u3 = sum_partials(part, p, p.Rpad + r + 4 * h, tok);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float sl = u1[e] / (1.0f + expf(-u1[e])); v[4 * h + e] = sl * u3[e]; }
+        }
+    }
+    ximg_store8(img, p.MT, tok, r, v);
 }
 
-static int prefill_splits(int R, int C) {
-    const int rb = (R + 127) / 128, nchunks = C / kKC;
-    int ks = 1;
-    while (ks < 8 && rb * ks < 256 && nchunks / (ks * 2) >= 8) ks *= 2;
-    return ks;
+hipError_t launch_prefill_ximg(const float* X, const float* gain, int M, int C, void* ximg, hipStream_t st) {
+    const int MT = (M + 31) / 32;
+    if (M < 1 || M > 128 || C % kKC != 0) return hipErrorInvalidValue;
+    if (gain) hipLaunchKernelGGL(ximg_from_rows_kernel<true>, dim3(MT * 32), dim3(256), 0, st, X, gain, M, MT, C, (char*)ximg);
+    else hipLaunchKernelGGL(ximg_from_rows_kernel<false>, dim3(MT * 32), dim3(256), 0, st, X, gain, M, MT, C, (char*)ximg);
+    return hipGetLastError();
+}
+hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, const void* ximg, float* part, hipStream_t st) {
+    if (p.M < 1 || p.M > 128 || p.C % kKC != 0 || p.R % 4 != 0 || p.nmat < 1 || p.nmat > 3) return hipErrorInvalidValue;
+    const _Float16* w0 = reinterpret_cast<const _Float16*>(W[0]);
+    const _Float16* w1 = reinterpret_cast<const _Float16*>(W[p.nmat > 1 ? 1 : 0]);
+    const _Float16* w2 = reinterpret_cast<const _Float16*>(W[p.nmat > 2 ? 2 : 0]);
+    const size_t lds = (ximg_stage_bytes(p.MT) + 16384) * kNST;
+    hipError_t e = hipSuccess;
+#define THK_V3(MTV)                                                                                                      \
+    {                                                                                                                    \
+        static bool attr_done = false;                                                                                   \
+        if (!attr_done) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3_kernel<MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = (e == hipSuccess); } \
+        if (e == hipSuccess) hipLaunchKernelGGL(gemm_prefill_v3_kernel<MTV>, dim3(kG), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, part, p);          \
+    }
+    switch (p.MT) {
+        case 1: THK_V3(1) break;
+        case 2: THK_V3(2) break;
+        case 3: THK_V3(3) break;
+        default: THK_V3(4) break;
+    }
+#undef THK_V3
+    return e != hipSuccess ? e : hipGetLastError();
+}
+hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st) {
+    const size_t n = (size_t)p.M * (p.R / 4);
+    hipLaunchKernelGGL(reduce_store_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, p, Y, residual ? 1 : 0);
+    return hipGetLastError();
+}
+hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, float* kcache, float* vcache, hipStream_t st) {
+    const size_t n = (size_t)p.M * 3 * (p.R / 4);
+    hipLaunchKernelGGL(reduce_qkv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache);
+    return hipGetLastError();
+}
+hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st) {
+    const size_t n = (size_t)p.Mpad * (p.R / 8);
+    hipLaunchKernelGGL(reduce_swiglu_ximg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, p, (char*)ximg_out);
+    return hipGetLastError();
 }
 
 size_t gemm_prefill_workspace_bytes(int M, int R, int C) {
-    const int mc = M < 128 ? M : 128;
-    const int Mpad = (mc + 31) / 32 * 32;
-    size_t b = ((size_t)Mpad * C * 2 * 2 + 255) / 256 * 256;
-    if (C % kKC == 0) b += (size_t)prefill_splits(R, C) * mc * R * 4;
-    return b;
+    const PrefillPlan p = prefill_plan(M < 128 ? M : 128, R, 1, C);
+    return (p.ximg_bytes + 255) / 256 * 256 + p.part_floats * 4;
 }
 
+// Y[M,R] = X[M,C] * W[R,C]^T for one matrix (the thk_gemm_f16_prefill operator): image -> GEMM -> reduce, 128 tokens at a time
 hipError_t launch_gemm_f16_prefill(const uint16_t* W, int R, int C, const float* X, int M, float* Y, void* workspace, hipStream_t st) {
-    if (C % 32 != 0 || R % 4 != 0) return hipErrorInvalidValue;
-    for (int m0 = 0; m0 < M; m0 += 128) {                       // token chunks of <= 128
+    if (C % kKC != 0 || R % 4 != 0) return hipErrorInvalidValue;
+    for (int m0 = 0; m0 < M; m0 += 128) {
         const int mc = (M - m0) < 128 ? (M - m0) : 128;
-        const int MT = (mc + 31) / 32, Mpad = MT * 32;
-        _Float16* hi = reinterpret_cast<_Float16*>(workspace);
-        _Float16* lo = hi + (size_t)Mpad * C;
-        const size_t n = (size_t)Mpad * C;
-        const unsigned sgrid = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-        hipLaunchKernelGGL(split_hi_lo_kernel, dim3(sgrid), dim3(256), 0, st, X + (size_t)m0 * C, mc, Mpad, C, hi, lo);
-        float* Yc = Y + (size_t)m0 * R;
-        if (C % kKC == 0) {
-            const int ks = prefill_splits(R, C), nchunks = C / kKC, cps = (nchunks + ks - 1) / ks;
-            float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ((size_t)Mpad * C * 2 * 2 + 255) / 256 * 256);
-            float* dst = ks == 1 ? Yc : part;
-            const dim3 grid((R + 127) / 128, ks);
-            switch (MT) {
-                case 1: hipLaunchKernelGGL(gemm_prefill_v2_kernel<1>, grid, dim3(256), 0, st, W, R, C, hi, lo, mc, dst, cps); break;
-                case 2: hipLaunchKernelGGL(gemm_prefill_v2_kernel<2>, grid, dim3(256), 0, st, W, R, C, hi, lo, mc, dst, cps); break;
-                case 3: hipLaunchKernelGGL(gemm_prefill_v2_kernel<3>, grid, dim3(256), 0, st, W, R, C, hi, lo, mc, dst, cps); break;
-                default: hipLaunchKernelGGL(gemm_prefill_v2_kernel<4>, grid, dim3(256), 0, st, W, R, C, hi, lo, mc, dst, cps); break;
-            }
-            if (ks > 1) {
-                const size_t n4 = (size_t)mc * R / 4;
-                hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, part, ks, n4, Yc);
-            }
-        } else {                                                // odd K: v1 kernel (one wave per workgroup)
-            const int grid = (R + 31) / 32;
-            switch (MT) {
-                case 1: hipLaunchKernelGGL(gemm_prefill_kernel<1>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
-                case 2: hipLaunchKernelGGL(gemm_prefill_kernel<2>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
-                case 3: hipLaunchKernelGGL(gemm_prefill_kernel<3>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
-                default: hipLaunchKernelGGL(gemm_prefill_kernel<4>, dim3(grid), dim3(64), 0, st, W, R, C, hi, lo, mc, Yc); break;
-            }
-        }
-        hipError_t e = hipGetLastError();
+        const PrefillPlan p = prefill_plan(mc, R, 1, C);
+        char* img = reinterpret_cast<char*>(workspace);
+        float* part = reinterpret_cast<float*>(img + (p.ximg_bytes + 255) / 256 * 256);
+        hipError_t e = launch_prefill_ximg(X + (size_t)m0 * C, nullptr, mc, C, img, st);
+        if (e == hipSuccess) e = launch_prefill_gemm(&W, p, img, part, st);
+        if (e == hipSuccess) e = launch_prefill_reduce_store(part, p, Y + (size_t)m0 * R, false, st);
         if (e != hipSuccess) return e;
     }
     return hipSuccess;

@@ -26,8 +26,11 @@ with thk.Context(0) as ctx:
     for _ in range(5):
         m.reset_kv(0); ctx.sync()
         t0 = time.perf_counter(); lp = m.prefill(toks, 0); ts.append(time.perf_counter() - t0)
-    m.reset_kv(0); ctx.sync()
-    t0 = time.perf_counter(); ld, _ = m.eval(toks, 0); t_dec = time.perf_counter() - t0
+    if len(sys.argv) > 3 and sys.argv[3] == "prefill-only":      # profiling runs: only the prefill kernels
+        ld, t_dec = lp, float("nan")
+    else:
+        m.reset_kv(0); ctx.sync()
+        t0 = time.perf_counter(); ld, _ = m.eval(toks, 0); t_dec = time.perf_counter() - t0
     t = float(np.median(ts))
     flops = 2.0 * (shape.weight_bytes(head=False) / 2) * M + 2.0 * shape.n_vocab * shape.n_embd
     print(json.dumps({"workload": f"LLaMA-{name.upper()} f16, {M}-token prompt prefill, 1 GPU", "prefill_ms": round(t * 1e3, 3),
