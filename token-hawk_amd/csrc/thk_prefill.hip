@@ -58,27 +58,32 @@ constexpr int kKC = 32;                  // K columns per LDS stage (2 MFMA k-st
 //     epilogue (store | residual add | RoPE + KV-cache write | SwiGLU + hi/lo image for w2).
 constexpr int kV3Rows = 256;       // weight rows per workgroup (4 waves x 64)
 constexpr int kNST = 4;            // LDS stages
-constexpr int kG = 256;            // workgroups per launch: a constant, so results do not depend on the CU count
+constexpr int kG = 256;            // default workgroups per launch: a constant, so results do not depend on the CU count
 
 static __host__ __device__ inline size_t ximg_stage_bytes(int MT) { return (size_t)MT * 32 * 64 * 2; }
 
-PrefillPlan prefill_plan(int M, int R, int nmat, int C) {
+PrefillPlan prefill_plan(int M, int R, int nmat, int C, int G) {
     PrefillPlan p{};
+    if (G <= 0) G = kG;
+    p.G = G;
     p.M = M; p.MT = (M + 31) / 32; p.Mpad = p.MT * 32; p.R = R; p.nmat = nmat; p.C = C;
     p.nchunks = C / kKC;
     p.rb_per_mat = (R + kV3Rows - 1) / kV3Rows; p.Rpad = p.rb_per_mat * kV3Rows; p.rb_total = p.rb_per_mat * nmat;
     const long total = (long)p.rb_total * p.nchunks;
-    p.per = (int)((total + kG - 1) / kG);
+    p.per = (int)((total + G - 1) / G);
     p.maxseg = (p.per - 1 + p.nchunks - 1) / p.nchunks + 1;
     p.ximg_bytes = (size_t)p.nchunks * ximg_stage_bytes(p.MT);
     p.slot_floats = (size_t)p.Mpad * kV3Rows;
-    p.part_floats = (size_t)kG * p.maxseg * p.slot_floats;
+    p.part_floats = (size_t)G * p.maxseg * p.slot_floats;
     return p;
 }
 
+// AUX = cache-policy bits (2 = nt).  Weights are NOT loaded nt: a 128-byte line is consumed as two 64-byte halves one
+// chunk apart, and with nt the second half is fetched again (measured: +30 % FETCH_SIZE, 7.05 -> 7.7 ms).
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, AUX);
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -108,7 +113,7 @@ __device__ __forceinline__ void v3_issue_chunk(char* sb, const char* xs /* image
     }
 }
 
-template <int MT>
+template <int MT, int NST = kNST>
 __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16* __restrict__ w0, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
                                                                  const char* __restrict__ ximg, float* __restrict__ part, const PrefillPlan plan) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -140,25 +145,24 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
         v3_issue_chunk<MT>(lds + i_buf * ST, ximg + (size_t)i_ch * XI + lane * 16, wm + (size_t)i_ch * kKC + ld_piece * 8, \
                            i_rbl * kV3Rows + wave * 64 + (lane >> 2), R, C, wave);                                      \
         ++issued;                                                                                \
-        i_buf = i_buf + 1 == kNST ? 0 : i_buf + 1;                                               \
+        i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;                                                \
         if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }  \
     }
-    auto flush = [&](f16v (&acc)[2][MT], int seg) __attribute__((always_inline)) {    // accumulators -> partial slot [token][256 rows]
+    auto flush = [&](f16v (&acc)[2][MT], int seg) __attribute__((always_inline)) {    // accumulators -> partial slot
         float* slot = part + ((size_t)blockIdx.x * maxseg + seg) * slot_floats;
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float* dst = slot + (size_t)(t * 32 + li) * kV3Rows + wave * 64 + f * 32 + 8 * g + 4 * (lane >> 5);
-                    *reinterpret_cast<f4*>(dst) = f4{acc[f][t][4 * g], acc[f][t][4 * g + 1], acc[f][t][4 * g + 2], acc[f][t][4 * g + 3]};
-                }
+                for (int g = 0; g < 4; ++g)         // fragment order: one contiguous 1 KiB store per (f, t, g); frag_decode() below is the inverse
+                    *reinterpret_cast<f4*>(slot + (size_t)(((((wave * 2 + f) * MT + t) * 4 + g) * 64 + lane) * 4)) =
+                        f4{acc[f][t][4 * g], acc[f][t][4 * g + 1], acc[f][t][4 * g + 2], acc[f][t][4 * g + 3]};
     };
 
     int issued = g0;
 #pragma unroll
-    for (int s = 0; s < kNST - 1; ++s)
+    for (int s = 0; s < NST - 1; ++s)
         if (issued < g1) THK_ISSUE_NEXT()
     int buf = 0, rbk = rbk_first;
     for (int s0 = g0; s0 < g1; ++rbk) {                // one pass per row-block this share touches
@@ -171,8 +175,11 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
 #pragma unroll
                 for (int i = 0; i < 16; ++i) acc[f][t][i] = 0.f;
         for (int g = s0; g < s1; ++g) {
-            const int rem = g1 - 1 - g;                // chunks issued after g: min(rem, kNST-2)
-            if (rem >= 2) wait_vmcnt<2 * LPS>(); else if (rem == 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+            const int rem = g1 - 1 - g;                // chunks issued after g: min(rem, NST-2)
+            if (NST >= 5 && rem >= 3) wait_vmcnt<3 * LPS>();
+            else if (NST >= 4 && rem >= 2) wait_vmcnt<2 * LPS>();
+            else if (NST >= 3 && rem >= 1) wait_vmcnt<LPS>();
+            else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();              // every wave's loads of chunk g have landed; stage (buf-1) is free
             if (issued < g1) THK_ISSUE_NEXT()
             const char* sb = lds + buf * ST;
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
                 acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][1], bl[1][t], acc[1][t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            buf = buf + 1 == kNST ? 0 : buf + 1;
+            buf = buf + 1 == NST ? 0 : buf + 1;
         }
         flush(acc, rbk - rbk_first);                   // end of the row-block (or of this share): spill the tile
         wait_vmcnt<0>();                               // stores share the counter with the DMA queue: drain, then count afresh
@@ -270,39 +277,47 @@ __global__ __launch_bounds__(256) void ximg_from_rows_kernel(const float* __rest
 }
 
 // ---- reducers ----------------------------------------------------------------------------------
-// sum of the partial slots that hold rows [vr, vr+4) (virtual row = matrix * Rpad + row) of token tok
-__device__ __forceinline__ f4 sum_partials(const float* __restrict__ part, const PrefillPlan& p, int vr, int tok) {
-    const int rbk = vr / kV3Rows, within = vr % kV3Rows;
-    const long lo = (long)rbk * p.nchunks, hi = lo + p.nchunks - 1;
-    const int b0 = (int)(lo / p.per), b1 = (int)(hi / p.per);
+// A partial slot holds one 256-row x Mpad-token tile in the MFMA accumulator's own order ("fragment order"), so the
+// GEMM's spill is a sequence of contiguous 1 KiB stores and the reducers' reads are contiguous too: float4 number
+// q = (((wave*2 + f)*MT + t)*4 + g)*64 + lane  holds rows [wave*64 + f*32 + 8g + 4*(lane>>5), +4) of token t*32 + (lane&31).
+// (Token-major slots made every spill instruction touch 32 different lines: the spill cost 58 us per layer.)
+struct FragPos { int tok, row; };
+__device__ __forceinline__ FragPos frag_decode(int q, int MT) {
+    const int lane = q & 63, g = (q >> 6) & 3, rest = q >> 8, t = rest % MT, wf = rest / MT;
+    return FragPos{t * 32 + (lane & 31), wf * 32 + 8 * g + 4 * (lane >> 5)};
+}
+// sum over the workgroups that worked on row-block rbk, in workgroup order (deterministic)
+__device__ __forceinline__ f4 sum_partials(const float* __restrict__ part, const PrefillPlan& p, int rbk, int q) {
+    const int lo = rbk * p.nchunks, hi = lo + p.nchunks - 1;
+    const int b0 = lo / p.per, b1 = hi / p.per;
     f4 s = f4{0.f, 0.f, 0.f, 0.f};
     for (int b = b0; b <= b1; ++b) {
-        const int seg = rbk - (int)(((long)b * p.per) / p.nchunks);
-        const float* slot = part + ((size_t)b * p.maxseg + seg) * p.slot_floats + (size_t)tok * kV3Rows + within;
-        const f4 v = *reinterpret_cast<const f4*>(slot);
+        const int seg = rbk - (b * p.per) / p.nchunks;
+        const f4 v = *reinterpret_cast<const f4*>(part + ((size_t)b * p.maxseg + seg) * p.slot_floats + (size_t)q * 4);
         s = b == b0 ? v : s + v;
     }
     return s;
 }
+// one thread per float4 of every tile: grid = row-blocks x (MT * 2048)
 // Y[tok][r] = sum  (mode 0)   |   Y[tok][r] += sum  (mode 1: residual)
-__global__ void reduce_store_kernel(const float* __restrict__ part, PrefillPlan p, float* __restrict__ Y, int mode) {
-    const int r4 = p.R / 4;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)p.M * r4) return;
-    const int tok = (int)(i / r4), r = (int)(i % r4) * 4;
-    f4 s = sum_partials(part, p, r, tok);
-    f4* dst = reinterpret_cast<f4*>(Y + (size_t)tok * p.R + r);
+__global__ __launch_bounds__(256) void reduce_store_kernel(const float* __restrict__ part, PrefillPlan p, float* __restrict__ Y, int mode) {
+    const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;
+    const FragPos fp = frag_decode(q, p.MT);
+    const int r = rbk * kV3Rows + fp.row;
+    if (fp.tok >= p.M || r >= p.R) return;
+    f4 s = sum_partials(part, p, rbk, q);
+    f4* dst = reinterpret_cast<f4*>(Y + (size_t)fp.tok * p.R + r);
     if (mode == 1) s = *dst + s;
     *dst = s;
 }
 // q -> RoPE -> Q[tok];  k -> RoPE -> K-cache row n_past+tok;  v -> V-cache row  (K6, th-llama.cpp:318-339)
-__global__ void reduce_qkv_kernel(const float* __restrict__ part, PrefillPlan p, const float* __restrict__ tab, int n_past, int D,
-                                  float* __restrict__ Q, float* __restrict__ kc, float* __restrict__ vc) {
-    const int r4 = p.R / 4;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)p.M * 3 * r4) return;
-    const int tok = (int)(i / (3 * r4)), rem = (int)(i % (3 * r4)), mat = rem / r4, r = (rem % r4) * 4;
-    f4 s = sum_partials(part, p, mat * p.Rpad + r, tok);
+__global__ __launch_bounds__(256) void reduce_qkv_kernel(const float* __restrict__ part, PrefillPlan p, const float* __restrict__ tab, int n_past, int D,
+                                                         float* __restrict__ Q, float* __restrict__ kc, float* __restrict__ vc) {
+    const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;
+    const FragPos fp = frag_decode(q, p.MT);
+    const int mat = rbk / p.rb_per_mat, r = (rbk % p.rb_per_mat) * kV3Rows + fp.row, tok = fp.tok;
+    if (tok >= p.M || r >= p.R) return;
+    f4 s = sum_partials(part, p, rbk, q);
     const int pos = n_past + tok;
     if (mat < 2) {
         const int half = D >> 1, jp = (r % D) >> 1;
@@ -312,24 +327,26 @@ __global__ void reduce_qkv_kernel(const float* __restrict__ part, PrefillPlan p,
     float* dst = mat == 0 ? Q + (size_t)tok * p.R + r : (mat == 1 ? kc : vc) + (size_t)pos * p.R + r;
     *reinterpret_cast<f4*>(dst) = s;
 }
-// hidden = silu(w1 x) * (w3 x)  (K10, K11) written straight into the X image of the w2 GEMM (C = R of this plan)
-__global__ void reduce_swiglu_ximg_kernel(const float* __restrict__ part, PrefillPlan p, char* __restrict__ img) {
-    const int r8 = p.R / 8;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)p.Mpad * r8) return;
-    const int tok = (int)(i / r8), r = (int)(i % r8) * 8;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+// hidden = silu(w1 x) * (w3 x)  (K10, K11) written straight into the X image of the w2 GEMM (C = R of this plan);
+// a thread owns 4 columns = half of a 16-byte image piece
+__global__ __launch_bounds__(256) void reduce_swiglu_ximg_kernel(const float* __restrict__ part, PrefillPlan p, char* __restrict__ img) {
+    const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;     // rbk < rb_per_mat: w1's tile; w3's is rbk + rb_per_mat
+    const FragPos fp = frag_decode(q, p.MT);
+    const int r = rbk * kV3Rows + fp.row, tok = fp.tok;
+    if (r >= p.R) return;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 hi = h4{0, 0, 0, 0}, lo = h4{0, 0, 0, 0};
     if (tok < p.M) {
+        const f4 u1 = sum_partials(part, p, rbk, q), u3 = sum_partials(part, p, rbk + p.rb_per_mat, q);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f4 u1 = sum_partials(part, p, r + 4 * h, tok), u3 = sum_partials(part, p, p.Rpad + r + 4 * h, tok);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float sl = u1[e] / (1.0f + expf(-u1[e])); v[4 * h + e] = sl * u3[e]; }
+        for (int e = 0; e < 4; ++e) {
+            const float sl = u1[e] / (1.0f + expf(-u1[e])), v = sl * u3[e];
+            hi[e] = (_Float16)v; lo[e] = (_Float16)(v - (float)hi[e]);
         }
     }
-    ximg_store8(img, p.MT, tok, r, v);
+    const size_t sub = (size_t)(r & 4) * 2;                              // second half of the piece
+    *reinterpret_cast<h4*>(img + ximg_off(p.MT, 0, tok, r) + sub) = hi;
+    *reinterpret_cast<h4*>(img + ximg_off(p.MT, 1, tok, r) + sub) = lo;
 }
 
 hipError_t launch_prefill_ximg(const float* X, const float* gain, int M, int C, void* ximg, hipStream_t st) {
@@ -344,13 +361,13 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, c
     const _Float16* w0 = reinterpret_cast<const _Float16*>(W[0]);
     const _Float16* w1 = reinterpret_cast<const _Float16*>(W[p.nmat > 1 ? 1 : 0]);
     const _Float16* w2 = reinterpret_cast<const _Float16*>(W[p.nmat > 2 ? 2 : 0]);
-    const size_t lds = (ximg_stage_bytes(p.MT) + 16384) * kNST;
     hipError_t e = hipSuccess;
 #define THK_V3(MTV)                                                                                                      \
     {                                                                                                                    \
+        const size_t lds = (ximg_stage_bytes(MTV) + 16384) * kNST;                                                       \
         static bool attr_done = false;                                                                                   \
         if (!attr_done) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3_kernel<MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = (e == hipSuccess); } \
-        if (e == hipSuccess) hipLaunchKernelGGL(gemm_prefill_v3_kernel<MTV>, dim3(kG), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, part, p);          \
+        if (e == hipSuccess) hipLaunchKernelGGL((gemm_prefill_v3_kernel<MTV>), dim3(p.G), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, part, p); \
     }
     switch (p.MT) {
         case 1: THK_V3(1) break;
@@ -362,23 +379,20 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, c
     return e != hipSuccess ? e : hipGetLastError();
 }
 hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st) {
-    const size_t n = (size_t)p.M * (p.R / 4);
-    hipLaunchKernelGGL(reduce_store_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, p, Y, residual ? 1 : 0);
+    hipLaunchKernelGGL(reduce_store_kernel, dim3(p.MT * 8, p.rb_total), dim3(256), 0, st, part, p, Y, residual ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, float* kcache, float* vcache, hipStream_t st) {
-    const size_t n = (size_t)p.M * 3 * (p.R / 4);
-    hipLaunchKernelGGL(reduce_qkv_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache);
+    hipLaunchKernelGGL(reduce_qkv_kernel, dim3(p.MT * 8, p.rb_total), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache);
     return hipGetLastError();
 }
 hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st) {
-    const size_t n = (size_t)p.Mpad * (p.R / 8);
-    hipLaunchKernelGGL(reduce_swiglu_ximg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, p, (char*)ximg_out);
+    hipLaunchKernelGGL(reduce_swiglu_ximg_kernel, dim3(p.MT * 8, p.rb_per_mat), dim3(256), 0, st, part, p, (char*)ximg_out);
     return hipGetLastError();
 }
 
 size_t gemm_prefill_workspace_bytes(int M, int R, int C) {
-    const PrefillPlan p = prefill_plan(M < 128 ? M : 128, R, 1, C);
+    const PrefillPlan p = prefill_plan(M < 128 ? M : 128, R, 1, C, 0);
     return (p.ximg_bytes + 255) / 256 * 256 + p.part_floats * 4;
 }
 
@@ -387,7 +401,7 @@ hipError_t launch_gemm_f16_prefill(const uint16_t* W, int R, int C, const float*
     if (C % kKC != 0 || R % 4 != 0) return hipErrorInvalidValue;
     for (int m0 = 0; m0 < M; m0 += 128) {
         const int mc = (M - m0) < 128 ? (M - m0) : 128;
-        const PrefillPlan p = prefill_plan(mc, R, 1, C);
+        const PrefillPlan p = prefill_plan(mc, R, 1, C, 0);
         char* img = reinterpret_cast<char*>(workspace);
         float* part = reinterpret_cast<float*>(img + (p.ximg_bytes + 255) / 256 * 256);
         hipError_t e = launch_prefill_ximg(X + (size_t)m0 * C, nullptr, mc, C, img, st);

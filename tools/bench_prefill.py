@@ -20,6 +20,8 @@ shape = {"7b": thk.LLAMA_7B, "13b": thk.LLAMA_13B}[name]
 rng = np.random.default_rng(128)
 toks = np.concatenate([[1], rng.integers(3, shape.n_vocab, M - 1)]).astype(np.int32)
 with thk.Context(0) as ctx:
+    for kv in sys.argv[4:]:                      # tunables: name=value
+        k, v = kv.split("="); ctx.set_tunable(k, int(v))
     m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
     lp = m.prefill(toks, 0)                      # warm-up (allocates the workspace)
     ts = []

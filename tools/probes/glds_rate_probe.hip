@@ -40,6 +40,46 @@ __global__ __launch_bounds__(256, 1) void probe(const char* __restrict__ src, in
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = acc[0];
 }
 
+// HBM streaming in the prefill GEMM's shape: a block owns 256 rows of 8 KiB (4 waves x 64 rows) and walks along the
+// rows; per step every wave issues 4 instructions that fetch PIECE bytes from each of (4096 / PIECE) rows... i.e.
+// PIECE = 64: 16 rows x 64 B per instruction (KC = 32 halfs), 128: 8 rows x 128 B, 256: 4 rows x 256 B, 1024: 1 row.
+template <int PIECE>
+__global__ __launch_bounds__(256, 1) void hbm_probe(const char* __restrict__ src, int row_blocks, float* out) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int LPR = PIECE / 16, RPI = 64 / LPR;          // lanes per row, rows per instruction
+    constexpr int IPS = 64 / RPI;                            // instructions per wave to cover its 64 rows once
+    int n = 0;
+    for (int rb = 0; rb < row_blocks; ++rb) {
+        const char* base = src + ((size_t)(rb * gridDim.x + blockIdx.x) * 256 + wave * 64) * 8192;
+        for (int col = 0; col < 8192; col += PIECE) {
+#pragma unroll
+            for (int j = 0; j < IPS; ++j) {
+                const char* p = base + (size_t)(j * RPI + lane / LPR) * 8192 + col + (lane % LPR) * 16;
+                glds16(p, lds + ((n & 15) * 4 + wave) * 1024);
+                ++n;
+            }
+            if (IPS >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads();
+    f4 acc = *reinterpret_cast<const f4*>(lds + threadIdx.x * 16);
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = acc[0];
+}
+template <int PIECE> static void run_hbm(const char* src, float* out) {
+    const int rbs = 4;     // 256 blocks x 4 x 2 MiB = 2 GiB
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    CHECK(hipFuncSetAttribute((const void*)hbm_probe<PIECE>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    hipLaunchKernelGGL((hbm_probe<PIECE>), dim3(256), dim3(256), 65536, 0, src, 1, out);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL((hbm_probe<PIECE>), dim3(256), dim3(256), 65536, 0, src, rbs, out);
+    CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
+    float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = 256.0 * rbs * 256 * 8192;
+    printf("HBM stream, %4d B per row per step: %8.1f GB/s total (%.2f ms for %.0f MiB)\n", PIECE, bytes / ms / 1e6, ms, bytes / 1048576);
+}
+
 template <bool DMA, int FRAG> static void run(const char* name, const char* src, float* out, int blocks) {
     const int iters = 2000;
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -67,5 +107,8 @@ int main() {
         run<true, 5>("glds x4, 8 rows x 128 B", src, out, blocks);
         run<false, 2>("global_load x4, 16 rows x 64 B", src, out, blocks);
     }
+    char* big; CHECK(hipMalloc(&big, (size_t)2 << 30)); CHECK(hipMemset(big, 1, (size_t)2 << 30));
+    run_hbm<64>(big, out); run_hbm<128>(big, out); run_hbm<256>(big, out); run_hbm<1024>(big, out);
+    run_hbm<64>(big, out); run_hbm<128>(big, out); run_hbm<256>(big, out); run_hbm<1024>(big, out);
     return 0;
 }
