@@ -116,7 +116,8 @@ static void default_tunables(thk_ctx* ctx) {
     // per-kernel launch geometry: -1 = auto (table below, from tools/sweep.py on MI355X, profiles/r01_sweep_*.json),
     // 0 = gemv_blocks_per_cu / variant 0, > 0 = explicit
     // workgroups per prefill GEMM launch (<= 256): fewer = fewer K-splits = less partial-tile traffic, but fewer CUs streaming
-    for (const char* k : {"qkv", "wo", "w13", "w2"}) ctx->tun[std::string("prefill_blocks_") + k] = 256;
+    for (const char* k : {"qkv", "wo", "w13", "w2"}) { ctx->tun[std::string("prefill_blocks_") + k] = 256; ctx->tun[std::string("prefill_tile_") + k] = 256; }   // tile rows: 128 | 256
+    ctx->tun["prefill_tile_wo"] = 128; ctx->tun["prefill_tile_w2"] = 128;   // 16 row-blocks only: halve the 16-way split-K partials (-3 %)
     for (const char* k : {"qkv", "wo", "w13", "w2", "head"}) {
         ctx->tun[std::string("gemv_bpc_") + k] = -1;
         ctx->tun[std::string("gemv_variant_") + k] = -1;   // (rows/iteration, slots/batch) variant, see gemv_variant()
@@ -980,9 +981,13 @@ static int prefill_workspace(thk_model* m, PrefillBufs* b) {
     thk_ctx* ctx = m->ctx;
     const int E = m->hp.n_embd, F = m->n_ff;
     const size_t per = align256((size_t)128 * E * 4);
-    const PrefillPlan pq = prefill_plan(128, E, 3, E, 256), po = prefill_plan(128, E, 1, E, 256), p13 = prefill_plan(128, F, 2, E, 256), p2 = prefill_plan(128, E, 1, F, 256);   // 256 = the largest G used
-    const size_t imgE = align256(pq.ximg_bytes), imgF = align256(p2.ximg_bytes);
-    const size_t part = align256(4 * std::max(std::max(pq.part_floats, po.part_floats), std::max(p13.part_floats, p2.part_floats)));
+    size_t part_floats = 0, img_e = 0, img_f = 0;
+    for (int tile : {128, 256}) {                 // the tunables may pick either tile; G <= 256
+        const PrefillPlan pq = prefill_plan(128, E, 3, E, 256, tile), po = prefill_plan(128, E, 1, E, 256, tile), p13 = prefill_plan(128, F, 2, E, 256, tile), p2 = prefill_plan(128, E, 1, F, 256, tile);
+        part_floats = std::max(part_floats, std::max(std::max(pq.part_floats, po.part_floats), std::max(p13.part_floats, p2.part_floats)));
+        img_e = pq.ximg_bytes; img_f = p2.ximg_bytes;
+    }
+    const size_t imgE = align256(img_e), imgF = align256(img_f), part = align256(4 * part_floats);
     const size_t bytes = 3 * per + 1024 + imgE + imgF + part;
     if (m->prefill_ws_bytes < bytes) {
         if (m->prefill_ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(m->prefill_ws)); m->prefill_ws = nullptr; }
@@ -1003,7 +1008,8 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
     const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, T = m->hp.n_ctx;
     const int g_qkv = (int)tun(ctx, "prefill_blocks_qkv"), g_wo = (int)tun(ctx, "prefill_blocks_wo"), g_w13 = (int)tun(ctx, "prefill_blocks_w13"), g_w2 = (int)tun(ctx, "prefill_blocks_w2");
     REQUIRE(ctx, g_qkv >= 1 && g_qkv <= 256 && g_wo >= 1 && g_wo <= 256 && g_w13 >= 1 && g_w13 <= 256 && g_w2 >= 1 && g_w2 <= 256, "prefill_blocks_* tunables must be in [1, 256]");
-    const PrefillPlan pq = prefill_plan(M, E, 3, E, g_qkv), po = prefill_plan(M, E, 1, E, g_wo), p13 = prefill_plan(M, F, 2, E, g_w13), p2 = prefill_plan(M, E, 1, F, g_w2);
+    const int t_qkv = (int)tun(ctx, "prefill_tile_qkv"), t_wo = (int)tun(ctx, "prefill_tile_wo"), t_w13 = (int)tun(ctx, "prefill_tile_w13"), t_w2 = (int)tun(ctx, "prefill_tile_w2");
+    const PrefillPlan pq = prefill_plan(M, E, 3, E, g_qkv, t_qkv), po = prefill_plan(M, E, 1, E, g_wo, t_wo), p13 = prefill_plan(M, F, 2, E, g_w13, t_w13), p2 = prefill_plan(M, E, 1, F, g_w2, t_w2);
     HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));   // tokens may be a stack buffer
     HIPCHK(ctx, launch_embed_rows(m->tok_embeddings, b.tok, M, E, b.X, st));

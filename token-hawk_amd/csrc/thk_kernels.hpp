@@ -101,10 +101,10 @@ size_t gemm_prefill_workspace_bytes(int M, int R, int C);
 // the MFMA loop), up to 3 matrices sharing the operand run in one launch, partial tiles are reduced by a
 // kernel that carries the fused epilogue.  M <= 128 tokens per call.
 struct PrefillPlan {
-    int M, MT, Mpad, R, Rpad, nmat, C, nchunks, rb_per_mat, rb_total, per, maxseg, G;
+    int M, MT, Mpad, R, Rpad, nmat, C, nchunks, rb_per_mat, rb_total, per, maxseg, G, tile_rows;
     size_t ximg_bytes, slot_floats, part_floats;
 };
-PrefillPlan prefill_plan(int M, int R, int nmat, int C, int G /* workgroups; 0 = default (256) */);
+PrefillPlan prefill_plan(int M, int R, int nmat, int C, int G /* workgroups; 0 = default (256) */, int tile_rows /* 128 | 256 (default) */);
 hipError_t launch_prefill_ximg(const float* X, const float* gain_or_null, int M, int C, void* ximg, hipStream_t st);
 hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, const void* ximg, float* part, hipStream_t st);
 hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st);

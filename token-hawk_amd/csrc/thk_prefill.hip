@@ -56,24 +56,25 @@ constexpr int kKC = 32;                  // K columns per LDS stage (2 MFMA k-st
 //     most `maxseg` row-blocks; each span goes to its own partial slot and the reducers below sum
 //     the slots of a row-block in workgroup order (deterministic, no atomics) and apply the fused
 //     epilogue (store | residual add | RoPE + KV-cache write | SwiGLU + hi/lo image for w2).
-constexpr int kV3Rows = 256;       // weight rows per workgroup (4 waves x 64)
+constexpr int kV3Rows = 256;       // default weight rows per workgroup (4 waves x 64); 128 (4 x 32) halves the partial-tile bytes
 constexpr int kNST = 4;            // LDS stages
 constexpr int kG = 256;            // default workgroups per launch: a constant, so results do not depend on the CU count
 
 static __host__ __device__ inline size_t ximg_stage_bytes(int MT) { return (size_t)MT * 32 * 64 * 2; }
 
-PrefillPlan prefill_plan(int M, int R, int nmat, int C, int G) {
+PrefillPlan prefill_plan(int M, int R, int nmat, int C, int G, int tile_rows) {
     PrefillPlan p{};
     if (G <= 0) G = kG;
     p.G = G;
+    p.tile_rows = tile_rows == 128 ? 128 : kV3Rows;
     p.M = M; p.MT = (M + 31) / 32; p.Mpad = p.MT * 32; p.R = R; p.nmat = nmat; p.C = C;
     p.nchunks = C / kKC;
-    p.rb_per_mat = (R + kV3Rows - 1) / kV3Rows; p.Rpad = p.rb_per_mat * kV3Rows; p.rb_total = p.rb_per_mat * nmat;
+    p.rb_per_mat = (R + p.tile_rows - 1) / p.tile_rows; p.Rpad = p.rb_per_mat * p.tile_rows; p.rb_total = p.rb_per_mat * nmat;
     const long total = (long)p.rb_total * p.nchunks;
     p.per = (int)((total + G - 1) / G);
     p.maxseg = (p.per - 1 + p.nchunks - 1) / p.nchunks + 1;
     p.ximg_bytes = (size_t)p.nchunks * ximg_stage_bytes(p.MT);
-    p.slot_floats = (size_t)p.Mpad * kV3Rows;
+    p.slot_floats = (size_t)p.Mpad * p.tile_rows;
     p.part_floats = (size_t)G * p.maxseg * p.slot_floats;
     return p;
 }
@@ -100,27 +101,28 @@ __device__ __forceinline__ int swz_pos(int row, int piece) { return piece ^ ((ro
 // in the layout above, so a linear copy) and its own 64 weight rows (16 rows x 64 B per instruction).
 // A plain function with by-value arguments: as a by-reference lambda the closure (and every captured local)
 // ended up in scratch.
-template <int MT>
+template <int MT, int NF>
 __device__ __forceinline__ void v3_issue_chunk(char* sb, const char* xs /* image of the chunk + lane*16 */, const _Float16* wcol /* matrix + chunk column + this lane's piece */,
                                                int row0 /* loader row of instruction 0 */, int R, int C, int wave) {
     constexpr int XI = MT * 32 * 64 * 2;
 #pragma unroll
     for (int i = 0; i < MT; ++i) glds16(xs + (wave + 4 * i) * 1024, sb + (wave + 4 * i) * 1024);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 2 * NF; ++j) {
         int row = row0 + 16 * j; row = row < R ? row : R - 1;      // rows past the matrix repeat the last one (their outputs are never read)
-        glds16(wcol + (size_t)row * C, sb + XI + (wave * 4 + j) * 1024);
+        glds16(wcol + (size_t)row * C, sb + XI + (wave * 2 * NF + j) * 1024);
     }
 }
 
-template <int MT, int NST = kNST>
+template <int MT, int NF /* 32-row fragments per wave: 2 (256-row tile) or 1 (128-row tile) */, int NST = kNST>
 __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16* __restrict__ w0, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
                                                                  const char* __restrict__ ximg, float* __restrict__ part, const PrefillPlan plan) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     constexpr int XI = MT * 32 * 64 * 2;               // X image bytes per stage (hi rows, then lo rows)
-    constexpr int WI = 4 * 64 * 64;                    // W image: 4 waves x 64 rows x 64 B
+    constexpr int TR = 128 * NF;                       // tile rows
+    constexpr int WI = TR * 64;                        // W image: 4 waves x (32 NF) rows x 64 B
     constexpr int ST = XI + WI;
-    constexpr int LPS = MT + 4;                        // loads per wave per stage
+    constexpr int LPS = MT + 2 * NF;                   // loads per wave per stage
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31;
@@ -142,21 +144,21 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
 #define THK_ISSUE_NEXT()                                                                         \
     {                                                                                            \
         const _Float16* wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);                           \
-        v3_issue_chunk<MT>(lds + i_buf * ST, ximg + (size_t)i_ch * XI + lane * 16, wm + (size_t)i_ch * kKC + ld_piece * 8, \
-                           i_rbl * kV3Rows + wave * 64 + (lane >> 2), R, C, wave);                                      \
+        v3_issue_chunk<MT, NF>(lds + i_buf * ST, ximg + (size_t)i_ch * XI + lane * 16, wm + (size_t)i_ch * kKC + ld_piece * 8, \
+                               i_rbl * TR + wave * 32 * NF + (lane >> 2), R, C, wave);                                  \
         ++issued;                                                                                \
         i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;                                                \
         if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }  \
     }
-    auto flush = [&](f16v (&acc)[2][MT], int seg) __attribute__((always_inline)) {    // accumulators -> partial slot
+    auto flush = [&](f16v (&acc)[NF][MT], int seg) __attribute__((always_inline)) {    // accumulators -> partial slot
         float* slot = part + ((size_t)blockIdx.x * maxseg + seg) * slot_floats;
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int g = 0; g < 4; ++g)         // fragment order: one contiguous 1 KiB store per (f, t, g); frag_decode() below is the inverse
-                    *reinterpret_cast<f4*>(slot + (size_t)(((((wave * 2 + f) * MT + t) * 4 + g) * 64 + lane) * 4)) =
+                    *reinterpret_cast<f4*>(slot + (size_t)(((((wave * NF + f) * MT + t) * 4 + g) * 64 + lane) * 4)) =
                         f4{acc[f][t][4 * g], acc[f][t][4 * g + 1], acc[f][t][4 * g + 2], acc[f][t][4 * g + 3]};
     };
 
@@ -167,9 +169,9 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
     int buf = 0, rbk = rbk_first;
     for (int s0 = g0; s0 < g1; ++rbk) {                // one pass per row-block this share touches
         const int rb_end = (rbk + 1) * nchunks, s1 = rb_end < g1 ? rb_end : g1;
-        f16v acc[2][MT];
+        f16v acc[NF][MT];
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
@@ -183,17 +185,26 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
             __builtin_amdgcn_s_barrier();              // every wave's loads of chunk g have landed; stage (buf-1) is free
             if (issued < g1) THK_ISSUE_NEXT()
             const char* sb = lds + buf * ST;
-            // Fragment reads of k-step 1 are issued right behind the first MFMA of k-step 0 and land under the other
-            // fifteen; hipcc only ever waits lgkmcnt(0) here, so the order is pinned by hand.
-            h8 af[2][2], bh[2][MT], bl[2][MT];
+            // Fragment reads of k-step 1 are issued right behind the first MFMA of k-step 0 and land under the
+            // others; hipcc only ever waits lgkmcnt(0) here, so the order is pinned by hand.
+            h8 af[2][NF], bh[2][MT], bl[2][MT];
             auto read_frags = [&](const int ks) __attribute__((always_inline)) {
                 const char* rp = sb + (ks == 0 ? rd0 : rd1);
-                af[ks][0] = *reinterpret_cast<const h8*>(rp + XI + wave * 4096);
-                af[ks][1] = *reinterpret_cast<const h8*>(rp + XI + wave * 4096 + 2048);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) af[ks][f] = *reinterpret_cast<const h8*>(rp + XI + (wave * NF + f) * 2048);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     bh[ks][t] = *reinterpret_cast<const h8*>(rp + t * 2048);
                     bl[ks][t] = *reinterpret_cast<const h8*>(rp + XI / 2 + t * 2048);
+                }
+            };
+            auto mfma_kstep = [&](const int ks, const int t_begin) __attribute__((always_inline)) {   // (f, hi/lo) for tokens t_begin.., minus the hoisted first one
+#pragma unroll
+                for (int t = t_begin; t < MT; ++t) {
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][f], bh[ks][t], acc[f][t], 0, 0, 0);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][f], bl[ks][t], acc[f][t], 0, 0, 0);
                 }
             };
             read_frags(0);
@@ -202,24 +213,13 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
             __builtin_amdgcn_sched_barrier(0);
             read_frags(1);
             __builtin_amdgcn_sched_barrier(0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bh[0][0], acc[1][0], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bl[0][0], acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bl[0][0], acc[1][0], 0, 0, 0);
 #pragma unroll
-            for (int t = 1; t < MT; ++t) {
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bh[0][t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bh[0][t], acc[1][t], 0, 0, 0);
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bl[0][t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][1], bl[0][t], acc[1][t], 0, 0, 0);
-            }
+            for (int f = 1; f < NF; ++f) acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][f], bh[0][0], acc[f][0], 0, 0, 0);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][f], bl[0][0], acc[f][0], 0, 0, 0);
+            mfma_kstep(0, 1);
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bh[1][t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][1], bh[1][t], acc[1][t], 0, 0, 0);
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][0], bl[1][t], acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][1], bl[1][t], acc[1][t], 0, 0, 0);
-            }
+            mfma_kstep(1, 0);
             __builtin_amdgcn_sched_barrier(0);
             buf = buf + 1 == NST ? 0 : buf + 1;
         }
@@ -279,7 +279,8 @@ __global__ __launch_bounds__(256) void ximg_from_rows_kernel(const float* __rest
 // ---- reducers ----------------------------------------------------------------------------------
 // A partial slot holds one 256-row x Mpad-token tile in the MFMA accumulator's own order ("fragment order"), so the
 // GEMM's spill is a sequence of contiguous 1 KiB stores and the reducers' reads are contiguous too: float4 number
-// q = (((wave*2 + f)*MT + t)*4 + g)*64 + lane  holds rows [wave*64 + f*32 + 8g + 4*(lane>>5), +4) of token t*32 + (lane&31).
+// q = (((wave*NF + f)*MT + t)*4 + g)*64 + lane  holds rows [(wave*NF + f)*32 + 8g + 4*(lane>>5), +4) of token t*32 + (lane&31)
+// (NF = tile_rows / 128 fragments per wave).
 // (Token-major slots made every spill instruction touch 32 different lines: the spill cost 58 us per layer.)
 struct FragPos { int tok, row; };
 __device__ __forceinline__ FragPos frag_decode(int q, int MT) {
@@ -290,12 +291,17 @@ __device__ __forceinline__ FragPos frag_decode(int q, int MT) {
 __device__ __forceinline__ f4 sum_partials(const float* __restrict__ part, const PrefillPlan& p, int rbk, int q) {
     const int lo = rbk * p.nchunks, hi = lo + p.nchunks - 1;
     const int b0 = lo / p.per, b1 = hi / p.per;
-    f4 s = f4{0.f, 0.f, 0.f, 0.f};
-    for (int b = b0; b <= b1; ++b) {
-        const int seg = rbk - (b * p.per) / p.nchunks;
-        const f4 v = *reinterpret_cast<const f4*>(part + ((size_t)b * p.maxseg + seg) * p.slot_floats + (size_t)q * 4);
-        s = b == b0 ? v : s + v;
+    // loads four slots ahead of the adds; the sum itself stays strictly in workgroup order
+    const float* base = part + (size_t)q * 4;
+    auto slot_of = [&](int b) { return base + ((size_t)b * p.maxseg + (rbk - (b * p.per) / p.nchunks)) * p.slot_floats; };
+    f4 s = *reinterpret_cast<const f4*>(slot_of(b0));
+    int b = b0 + 1;
+    for (; b + 3 <= b1; b += 4) {
+        const f4 v0 = *reinterpret_cast<const f4*>(slot_of(b)), v1 = *reinterpret_cast<const f4*>(slot_of(b + 1));
+        const f4 v2 = *reinterpret_cast<const f4*>(slot_of(b + 2)), v3 = *reinterpret_cast<const f4*>(slot_of(b + 3));
+        s = s + v0; s = s + v1; s = s + v2; s = s + v3;
     }
+    for (; b <= b1; ++b) s = s + *reinterpret_cast<const f4*>(slot_of(b));
     return s;
 }
 // one thread per float4 of every tile: grid = row-blocks x (MT * 2048)
@@ -303,7 +309,7 @@ __device__ __forceinline__ f4 sum_partials(const float* __restrict__ part, const
 __global__ __launch_bounds__(256) void reduce_store_kernel(const float* __restrict__ part, PrefillPlan p, float* __restrict__ Y, int mode) {
     const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;
     const FragPos fp = frag_decode(q, p.MT);
-    const int r = rbk * kV3Rows + fp.row;
+    const int r = rbk * p.tile_rows + fp.row;
     if (fp.tok >= p.M || r >= p.R) return;
     f4 s = sum_partials(part, p, rbk, q);
     f4* dst = reinterpret_cast<f4*>(Y + (size_t)fp.tok * p.R + r);
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256) void reduce_qkv_kernel(const float* __restrict
                                                          float* __restrict__ Q, float* __restrict__ kc, float* __restrict__ vc) {
     const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;
     const FragPos fp = frag_decode(q, p.MT);
-    const int mat = rbk / p.rb_per_mat, r = (rbk % p.rb_per_mat) * kV3Rows + fp.row, tok = fp.tok;
+    const int mat = rbk / p.rb_per_mat, r = (rbk % p.rb_per_mat) * p.tile_rows + fp.row, tok = fp.tok;
     if (tok >= p.M || r >= p.R) return;
     f4 s = sum_partials(part, p, rbk, q);
     const int pos = n_past + tok;
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256) void reduce_qkv_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void reduce_swiglu_ximg_kernel(const float* __restrict__ part, PrefillPlan p, char* __restrict__ img) {
     const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;     // rbk < rb_per_mat: w1's tile; w3's is rbk + rb_per_mat
     const FragPos fp = frag_decode(q, p.MT);
-    const int r = rbk * kV3Rows + fp.row, tok = fp.tok;
+    const int r = rbk * p.tile_rows + fp.row, tok = fp.tok;
     if (r >= p.R) return;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 hi = h4{0, 0, 0, 0}, lo = h4{0, 0, 0, 0};
@@ -362,37 +368,42 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, c
     const _Float16* w1 = reinterpret_cast<const _Float16*>(W[p.nmat > 1 ? 1 : 0]);
     const _Float16* w2 = reinterpret_cast<const _Float16*>(W[p.nmat > 2 ? 2 : 0]);
     hipError_t e = hipSuccess;
-#define THK_V3(MTV)                                                                                                      \
+#define THK_V3(MTV, NFV)                                                                                                 \
     {                                                                                                                    \
-        const size_t lds = (ximg_stage_bytes(MTV) + 16384) * kNST;                                                       \
+        const size_t lds = (ximg_stage_bytes(MTV) + (size_t)NFV * 8192) * kNST;                                          \
         static bool attr_done = false;                                                                                   \
-        if (!attr_done) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3_kernel<MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = (e == hipSuccess); } \
-        if (e == hipSuccess) hipLaunchKernelGGL((gemm_prefill_v3_kernel<MTV>), dim3(p.G), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, part, p); \
+        if (!attr_done) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3_kernel<MTV, NFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = (e == hipSuccess); } \
+        if (e == hipSuccess) hipLaunchKernelGGL((gemm_prefill_v3_kernel<MTV, NFV>), dim3(p.G), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, part, p); \
     }
-    switch (p.MT) {
-        case 1: THK_V3(1) break;
-        case 2: THK_V3(2) break;
-        case 3: THK_V3(3) break;
-        default: THK_V3(4) break;
+    if (p.tile_rows == 128) switch (p.MT) {
+        case 1: THK_V3(1, 1) break;
+        case 2: THK_V3(2, 1) break;
+        case 3: THK_V3(3, 1) break;
+        default: THK_V3(4, 1) break;
+    } else switch (p.MT) {
+        case 1: THK_V3(1, 2) break;
+        case 2: THK_V3(2, 2) break;
+        case 3: THK_V3(3, 2) break;
+        default: THK_V3(4, 2) break;
     }
 #undef THK_V3
     return e != hipSuccess ? e : hipGetLastError();
 }
 hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_store_kernel, dim3(p.MT * 8, p.rb_total), dim3(256), 0, st, part, p, Y, residual ? 1 : 0);
+    hipLaunchKernelGGL(reduce_store_kernel, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, Y, residual ? 1 : 0);
     return hipGetLastError();
 }
 hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, float* kcache, float* vcache, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_qkv_kernel, dim3(p.MT * 8, p.rb_total), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache);
+    hipLaunchKernelGGL(reduce_qkv_kernel, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache);
     return hipGetLastError();
 }
 hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_swiglu_ximg_kernel, dim3(p.MT * 8, p.rb_per_mat), dim3(256), 0, st, part, p, (char*)ximg_out);
+    hipLaunchKernelGGL(reduce_swiglu_ximg_kernel, dim3(p.MT * p.tile_rows / 32, p.rb_per_mat), dim3(256), 0, st, part, p, (char*)ximg_out);
     return hipGetLastError();
 }
 
 size_t gemm_prefill_workspace_bytes(int M, int R, int C) {
-    const PrefillPlan p = prefill_plan(M < 128 ? M : 128, R, 1, C, 0);
+    const PrefillPlan p = prefill_plan(M < 128 ? M : 128, R, 1, C, 0, 0);
     return (p.ximg_bytes + 255) / 256 * 256 + p.part_floats * 4;
 }
 
@@ -401,7 +412,7 @@ hipError_t launch_gemm_f16_prefill(const uint16_t* W, int R, int C, const float*
     if (C % kKC != 0 || R % 4 != 0) return hipErrorInvalidValue;
     for (int m0 = 0; m0 < M; m0 += 128) {
         const int mc = (M - m0) < 128 ? (M - m0) : 128;
-        const PrefillPlan p = prefill_plan(mc, R, 1, C, 0);
+        const PrefillPlan p = prefill_plan(mc, R, 1, C, 0, 0);
         char* img = reinterpret_cast<char*>(workspace);
         float* part = reinterpret_cast<float*>(img + (p.ximg_bytes + 255) / 256 * 256);
         hipError_t e = launch_prefill_ximg(X + (size_t)m0 * C, nullptr, mc, C, img, st);

@@ -10,8 +10,9 @@
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, AUX);
 }
 // region: 2 MiB shared by all blocks (L2 resident).  FRAG: lane -> row (lane&31) * 8192 B + (lane>>5)*16 + k*32
 template <bool DMA, int FRAG>
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256, 1) void probe(const char* __restrict__ src, in
 // HBM streaming in the prefill GEMM's shape: a block owns 256 rows of 8 KiB (4 waves x 64 rows) and walks along the
 // rows; per step every wave issues 4 instructions that fetch PIECE bytes from each of (4096 / PIECE) rows... i.e.
 // PIECE = 64: 16 rows x 64 B per instruction (KC = 32 halfs), 128: 8 rows x 128 B, 256: 4 rows x 256 B, 1024: 1 row.
-template <int PIECE>
+template <int PIECE, int AUX = 0>
 __global__ __launch_bounds__(256, 1) void hbm_probe(const char* __restrict__ src, int row_blocks, float* out) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256, 1) void hbm_probe(const char* __restrict__ src
 #pragma unroll
             for (int j = 0; j < IPS; ++j) {
                 const char* p = base + (size_t)(j * RPI + lane / LPR) * 8192 + col + (lane % LPR) * 16;
-                glds16(p, lds + ((n & 15) * 4 + wave) * 1024);
+                glds16<AUX>(p, lds + ((n & 15) * 4 + wave) * 1024);
                 ++n;
             }
             if (IPS >= 4) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
@@ -66,18 +67,18 @@ __global__ __launch_bounds__(256, 1) void hbm_probe(const char* __restrict__ src
     f4 acc = *reinterpret_cast<const f4*>(lds + threadIdx.x * 16);
     if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) out[0] = acc[0];
 }
-template <int PIECE> static void run_hbm(const char* src, float* out) {
+template <int PIECE, int AUX = 0> static void run_hbm(const char* src, float* out) {
     const int rbs = 4;     // 256 blocks x 4 x 2 MiB = 2 GiB
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    CHECK(hipFuncSetAttribute((const void*)hbm_probe<PIECE>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    hipLaunchKernelGGL((hbm_probe<PIECE>), dim3(256), dim3(256), 65536, 0, src, 1, out);
+    CHECK(hipFuncSetAttribute((const void*)hbm_probe<PIECE, AUX>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    hipLaunchKernelGGL((hbm_probe<PIECE, AUX>), dim3(256), dim3(256), 65536, 0, src, 1, out);
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((hbm_probe<PIECE>), dim3(256), dim3(256), 65536, 0, src, rbs, out);
+    hipLaunchKernelGGL((hbm_probe<PIECE, AUX>), dim3(256), dim3(256), 65536, 0, src, rbs, out);
     CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     const double bytes = 256.0 * rbs * 256 * 8192;
-    printf("HBM stream, %4d B per row per step: %8.1f GB/s total (%.2f ms for %.0f MiB)\n", PIECE, bytes / ms / 1e6, ms, bytes / 1048576);
+    printf("HBM stream (aux=%d), %4d B per row per step: %8.1f GB/s total (%.2f ms for %.0f MiB)\n", AUX, PIECE, bytes / ms / 1e6, ms, bytes / 1048576);
 }
 
 template <bool DMA, int FRAG> static void run(const char* name, const char* src, float* out, int blocks) {
@@ -109,6 +110,8 @@ int main() {
     }
     char* big; CHECK(hipMalloc(&big, (size_t)2 << 30)); CHECK(hipMemset(big, 1, (size_t)2 << 30));
     run_hbm<64>(big, out); run_hbm<128>(big, out); run_hbm<256>(big, out); run_hbm<1024>(big, out);
+    run_hbm<64, 2>(big, out); run_hbm<128, 2>(big, out); run_hbm<256, 2>(big, out); run_hbm<1024, 2>(big, out);
     run_hbm<64>(big, out); run_hbm<128>(big, out); run_hbm<256>(big, out); run_hbm<1024>(big, out);
+    run_hbm<64, 2>(big, out); run_hbm<128, 2>(big, out); run_hbm<256, 2>(big, out); run_hbm<1024, 2>(big, out);
     return 0;
 }
