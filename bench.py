@@ -277,7 +277,7 @@ def main():
             roof["timing"] = "HIP events around eager launches on the libthk stream (includes the ~1.5-2.5 us launch gap)"
             for key, fname in (("traffic", "pmc_traffic.json"), ("rocprof_avg_us", "kernel_durations.json")):
                 path = os.path.join(ROOT, "profiles", fname)     # committed rocprofv3 summaries of this same command
-                if os.path.exists(path):
+                if os.path.exists(path) and args.model == "7b" and T == 512:   # the summaries are of the default workload only
                     try:
                         roof[key] = json.load(open(path)).get(dom)
                     except Exception:
