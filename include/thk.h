@@ -115,6 +115,14 @@ int thk_kv_append(thk_ctx* ctx, float* kcache, float* vcache, const float* k, co
 int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache, const float* vcache,
                     int64_t T, int64_t H, int64_t D, float* out);
 
+/* Causal attention for M query tokens at positions [n_past, n_past + M) over the cached positions
+ * (the rows of those M tokens must already be in the caches).  Stands in for the batch branch of
+ * build_layer_cmdbuf: mat_mul(QK^T) + cmdbuf_masked_softmax (K14, th.cpp:1619-1863) + mat_mul(PV)
+ * (th-llama.cpp:365-404) with the mask the reference intended: query i sees positions
+ * <= n_past + i (the reference's own mask ignores n_past).  q and out are [M, H*D]. */
+int thk_attn_prefill(thk_ctx* ctx, const float* q, const float* kcache, const float* vcache,
+                     int64_t n_past, int64_t M, int64_t H, int64_t D, float* out);
+
 /* cmdbuf_row_softmax (th.hpp:359-365, th.cpp:1865-2119): in place, rows x N. */
 int thk_row_softmax(thk_ctx* ctx, float* x, int64_t rows, int64_t N);
 

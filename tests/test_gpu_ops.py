@@ -152,6 +152,21 @@ def test_attn_decode(ctx, orc, splits, T, H, D, n_ctx):
     assert np.abs(got - exp).max() < 2e-5
 
 
+@pytest.mark.parametrize("M,n_past,H,D,n_ctx", [(1, 0, 8, 64, 64), (5, 0, 8, 64, 64), (33, 7, 8, 64, 64), (128, 0, 32, 128, 512), (128, 384, 32, 128, 512)])
+def test_attn_prefill_is_causal_decode_per_query(ctx, orc, M, n_past, H, D, n_ctx):
+    """thk_attn_prefill: query i at position n_past+i == thk_attn_decode semantics with T = n_past+i+1 (oracle)."""
+    rng = np.random.default_rng(M * 7 + n_past)
+    E = H * D
+    Q, Kc, Vc = rnd(rng, M, E), rnd(rng, n_ctx, E), rnd(rng, n_ctx, E)
+    Kc[n_past + M:] = 1e6; Vc[n_past + M:] = 1e6   # rows beyond the last query's position must never be read
+    dq, dk, dv, do = ctx.from_numpy(Q), ctx.from_numpy(Kc), ctx.from_numpy(Vc), ctx.alloc(M * E * 4)
+    ctx.attn_prefill(dq, dk, dv, n_past, M, H, D, do)
+    got = do.download(np.float32, (M, E))
+    for i in sorted({0, M // 2, M - 1}):
+        exp = oracle_attention(orc, Q[i], Kc, Vc, n_past + i + 1, H, D)
+        assert np.abs(got[i] - exp).max() < 2e-5, i
+
+
 def test_kv_append(ctx):
     rng = np.random.default_rng(5)
     H, D, n_ctx = 8, 64, 16

@@ -156,6 +156,9 @@ class Context:
     def attn_decode(self, q, kc, vc, T, H, D, out):
         self.check(self.lib.thk_attn_decode(self.h, _ptr(q), _ptr(kc), _ptr(vc), T, H, D, _ptr(out)), "thk_attn_decode")
 
+    def attn_prefill(self, q, kc, vc, n_past, M, H, D, out):
+        self.check(self.lib.thk_attn_prefill(self.h, _ptr(q), _ptr(kc), _ptr(vc), n_past, M, H, D, _ptr(out)), "thk_attn_prefill")
+
     def row_softmax(self, x, rows, N):
         self.check(self.lib.thk_row_softmax(self.h, _ptr(x), rows, N), "thk_row_softmax")
 

@@ -49,6 +49,7 @@ SIGNATURES = {
     "thk_rope": (C.c_int, [vp, vp, i64, i64, i64, i64]),
     "thk_kv_append": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, i64]),
     "thk_attn_decode": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
+    "thk_attn_prefill": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, i64, vp]),
     "thk_row_softmax": (C.c_int, [vp, vp, i64, i64]),
     "thk_add": (C.c_int, [vp, vp, vp, vp, i64]),
     "thk_silu": (C.c_int, [vp, vp, i64]),

@@ -386,6 +386,17 @@ extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache
     if (nsplit > 1) HIPCHK(ctx, launch_attn_combine(a.part_o, a.part_ml, out, (int)H, (int)D, nsplit, ctx->stream));
     return THK_OK;
 }
+extern "C" int thk_attn_prefill(thk_ctx* ctx, const float* q, const float* kcache, const float* vcache, int64_t n_past, int64_t M, int64_t H, int64_t D, float* out) {
+    if (!ctx) return THK_ERR_INVALID;
+    REQUIRE(ctx, q && kcache && vcache && out && M > 0 && H > 0 && n_past >= 0, "thk_attn_prefill: bad arguments");
+    REQUIRE(ctx, valid_head_dim(D), "thk_attn_prefill: head dim %lld not in {64,128,256}", (long long)D);
+    REQUIRE(ctx, n_past + M <= 0x7FFFFFFF / (H * D), "thk_attn_prefill: shape too large");
+    AttnArgs a{};
+    a.q = q; a.kcache = kcache; a.vcache = vcache; a.pos_ptr = nullptr; a.pos_val = (int)n_past; a.H = (int)H; a.D = (int)D;
+    a.nsplit = 1; a.tc = (int)(n_past + M); a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = (int)M; a.out = out;
+    HIPCHK(ctx, launch_attn_decode(a, ctx->stream));
+    return THK_OK;
+}
 extern "C" int thk_row_softmax(thk_ctx* ctx, float* x, int64_t rows, int64_t N) {
     if (!ctx) return THK_ERR_INVALID;
     REQUIRE(ctx, x && rows > 0 && N > 0, "thk_row_softmax: bad arguments");
