@@ -326,6 +326,26 @@ def test_prefill_in_slabs_of_128(thk, ctx, M, n_past):
     a.close(); b.close()
 
 
+def test_context_beyond_512(thk, orc, ctx):
+    """n_ctx is a parameter, not the reference's compile-time 512 (th-llama.hpp:105): 1100 prompt tokens through the
+    slab prefill, then decode steps at T > 1100, against the oracle fed token by token."""
+    shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=1200)
+    oshape = orc.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=1200)
+    m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    om = orc.OracleModel(oshape); om.fill_synthetic()
+    rng = np.random.default_rng(1100)
+    toks = np.concatenate([[1], rng.integers(3, 2048, 1102)]).astype(np.int32)
+    lp = m.prefill(toks[:1100], 0)
+    for i in range(1100):
+        lo, _ = om.eval(int(toks[i]), i)
+    assert np.abs(lp - lo).max() < LOGIT_TOL
+    for i in (1100, 1101):
+        lg, _ = m.eval([int(toks[i])], i); lo, _ = om.eval(int(toks[i]), i)
+        assert np.abs(lg - lo).max() < LOGIT_TOL
+        assert int(lg.argmax()) == orc.greedy(lo)
+    m.close()
+
+
 def test_prefill_full_width_128_tokens(thk, orc, ctx):
     """128-token prompt at 7B row geometry (2 layers): MFMA GEMMs at (M=128, C=4096/11008) vs token-by-token decode."""
     shape = thk.ModelShape(n_layer=2)
