@@ -49,7 +49,8 @@ constexpr int kKC = 32;                  // K columns per LDS stage (2 MFMA k-st
 //     by data in flight and hipcc's waitcnt bookkeeping is out of the picture: completion is counted
 //     by hand (s_waitcnt vmcnt(N), loads retire in order);
 //   * kNST LDS stages of 32 KB => (kNST-1) chunks = 96 KB per CU in flight across a raw s_barrier;
-//   * a wave owns 64 weight rows (two A fragments share every B fragment read), a workgroup 256 rows x 128 tokens;
+//   * a wave owns 64 weight rows (two A fragments share every B fragment read), a workgroup 256 rows x 128 tokens
+//     (NF = 1: 32 rows per wave, 128-row tiles -- half the partial-tile bytes for matrices with few row-blocks);
 //   * stream-K: the (row-block, K-chunk) space of up to three matrices that share the operand
 //     (wq|wk|wv, w1|w3) is flattened and cut into kG equal contiguous shares, one per workgroup, so
 //     every CU streams the same number of bytes whatever the shape.  A workgroup's share spans at
@@ -97,8 +98,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // 16 B/clk/CU instead of 55-64 (tools/probes/glds_rate_probe.hip, profiles/r01_glds_rate_probe.txt).
 __device__ __forceinline__ int swz_pos(int row, int piece) { return piece ^ ((row >> 2) & 3); }
 
-// The loads of one K-chunk (LPS = MT + 4 per wave) into LDS stage `sb`: this wave's share of the X image (already
-// in the layout above, so a linear copy) and its own 64 weight rows (16 rows x 64 B per instruction).
+// The loads of one K-chunk (LPS = MT + 2 NF per wave) into LDS stage `sb`: this wave's share of the X image (already
+// in the layout above, so a linear copy) and its own 32 NF weight rows (16 rows x 64 B per instruction).
 // A plain function with by-value arguments: as a by-reference lambda the closure (and every captured local)
 // ended up in scratch.
 template <int MT, int NF>
