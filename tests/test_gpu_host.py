@@ -26,6 +26,7 @@ def host(thk):
     lib.thh_eval.argtypes = [C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.thh_do_inference.argtypes = [C.c_int64, C.c_char_p, C.c_void_p, C.c_char_p, C.c_int]
     lib.thh_set_sampler.argtypes = [C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float]
+    lib.thh_set_prefill.argtypes = [C.c_int64, C.c_int]
     lib.thh_free.argtypes = [C.c_int64]; lib.thh_reset.argtypes = [C.c_int64]; lib.thh_hparams.argtypes = [C.c_int64, C.c_void_p]
     lib.capi_model_begin_load.argtypes = [C.c_void_p]
     lib.capi_load_model_header.argtypes = [C.c_char_p, C.c_double]
@@ -154,3 +155,23 @@ def test_cli_greedy(host, orc, model_file):
     exp, _ = greedy_reference(orc, words, thc.py_tokenize(words, scores, b" hello world", True))
     assert r.stdout == b"".join(words[t] for t in exp)
     assert subprocess.run([exe, "-d", "dir", "x"], capture_output=True).returncode == 2
+
+
+@pytest.mark.parametrize("temp", [0.0, 0.8])
+def test_prompt_prefill_generates_the_same_text(host, ctx, model_file, temp):
+    """do_inference with prefillPrompt (one thk_model_prefill call for the whole prompt) == the reference-style loop
+    that feeds the prompt one token per step: same text, same final position, for the greedy branch and for the
+    seeded top-k/top-p sampler (the discarded per-prompt-token draws are replayed on the random stream)."""
+    path, _, words, scores = model_file
+    out = []
+    for prefill in (0, 1):
+        h = host.thh_load_file(ctx.h, path.encode(), 0)       # fresh model => fresh mt19937(780658349)
+        assert h > 0, host.thh_last_error()
+        host.thh_set_sampler(h, 40, 0.95, temp, 1.1)
+        host.thh_set_prefill(h, prefill)
+        n_past = C.c_int32(); text = C.create_string_buffer(1 << 16)
+        n_new = host.thh_do_inference(h, b"the quick brown fox jumps over the lazy dog", C.byref(n_past), text, len(text))
+        out.append((n_new, n_past.value, text.value))
+        host.thh_free(h)
+    assert out[0][0] > 0
+    assert out[0] == out[1]

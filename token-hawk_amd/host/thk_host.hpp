@@ -101,6 +101,10 @@ struct LlamaModel {
     LlamaVocab vocab{};
     SamplerParams sampler{};
     int lmhead_mode = THK_LMHEAD_CORRECT;   // THK_LMHEAD_FAITHFUL reproduces defect Q1
+    // false (default): the prompt is fed one token per step, as the reference does (kAllowedSubsequentBatchSize = 1,
+    // th-llama.cpp:15).  true: the whole prompt goes through thk_model_prefill (MFMA GEMMs) in one call; the sampler's
+    // random stream is advanced by the draws the token loop would have made, so the generated text is the same.
+    bool prefillPrompt = false;
 
     std::function<void(std::string /*token*/, std::string /*messageSoFar*/)> onNewToken;
     std::function<void(std::string /*fullMessage*/)> onInferenceComplete;

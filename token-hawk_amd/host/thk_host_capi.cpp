@@ -48,6 +48,7 @@ EXPORT const char* capi_on_human_message(const char* message) {
 }
 EXPORT const char* capi_last_error() { return g_last_error.c_str(); }
 EXPORT void capi_model_unload() { g_model.reset(); }
+EXPORT void capi_set_prompt_prefill(int on) { if (g_model) g_model->prefillPrompt = on != 0; }
 EXPORT void capi_set_sampler(int top_k, float top_p, float temp, float repeat_penalty) {
     if (g_model) g_model->sampler = SamplerParams{top_k, top_p, temp, repeat_penalty, false};
 }
@@ -122,6 +123,11 @@ EXPORT int thh_hparams(int64_t h, int32_t* hp7) {
 EXPORT int thh_set_sampler(int64_t h, int top_k, float top_p, float temp, float repeat_penalty) {
     auto it = g_handles.find(h); if (it == g_handles.end()) return 0;
     it->second->sampler = SamplerParams{top_k, top_p, temp, repeat_penalty, false};
+    return 1;
+}
+EXPORT int thh_set_prefill(int64_t h, int on) {
+    auto it = g_handles.find(h); if (it == g_handles.end()) return 0;
+    it->second->prefillPrompt = on != 0;
     return 1;
 }
 EXPORT int thh_eval(int64_t h, const int32_t* tokens, int n, int n_past, float* logits_out) {

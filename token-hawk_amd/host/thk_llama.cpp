@@ -151,7 +151,43 @@ void do_inference(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, std::string promp
     if (m->last_n_tokens.empty()) m->last_n_tokens.assign(kMaxContext, 0);
     m->generatedMessage.clear();
     const int n_ctx = std::min<int>(m->n_ctx, kMaxContext);
-    for (int64_t step = 0; step < kMaxOutputTokens && m->n_past < n_ctx; ++step) {
+    int64_t step = 0;
+    const int n_prompt = (int)m->embd_inp.size();
+    if (m->prefillPrompt && n_prompt >= 2 && m->n_past + n_prompt <= n_ctx && n_prompt <= kMaxOutputTokens) {
+        // Batched prompt ingestion: one thk_model_prefill call replaces n_prompt steps of the loop below.  Equivalent
+        // by construction: same KV rows, logits of the last prompt token, every prompt token pushed through
+        // last_n_tokens, and one discarded sampler draw per earlier prompt token (the loop samples after every token
+        // and throws the result away while the prompt is being consumed).
+        for (int i = 0; i < n_prompt; ++i) { m->last_n_tokens.erase(m->last_n_tokens.begin()); m->last_n_tokens.push_back(m->embd_inp[i]); }
+        m->logits.resize((size_t)m->n_vocab);
+        std::vector<int32_t> ids(m->embd_inp.begin(), m->embd_inp.end());
+        const int rc = thk_model_prefill(m->dev, 0, ids.data(), n_prompt, m->n_past, m->logits.data());
+        if (rc != THK_OK) {
+            report_error(*m, std::string("prompt prefill failed: ") + thk_last_error(m->ctx));
+            return;
+        }
+        const SamplerParams& sp = m->sampler;
+        if (sp.temp > 0) {
+            std::discrete_distribution<> two({1.0, 1.0});               // any distribution with > 1 outcome consumes one canonical draw
+            for (int i = 0; i < n_prompt - 1; ++i) (void)two(m->rng);
+        }
+        static const std::vector<tk_llama_token> none;
+        m->lastGeneratedToken = llama_sample_top_p_top_k(m->rng, m->n_vocab, sp.use_last_n_tokens ? m->last_n_tokens : none, sp.top_k, sp.top_p,
+                                                         sp.temp, sp.repeat_penalty, m->logits);
+        m->n_consumed = n_prompt; m->n_past += n_prompt; step = n_prompt;
+        if (m->lastGeneratedToken != tk_llama_token_eos()) {
+            const char* str = tk_llama_token_to_str(m, m->lastGeneratedToken);
+            if (str) {
+                m->generatedMessage += str;
+                if (m->onNewToken) m->onNewToken(str, m->generatedMessage);
+            }
+            m->last_n_tokens.erase(m->last_n_tokens.begin());
+            m->last_n_tokens.push_back(m->lastGeneratedToken);
+        } else {
+            step = kMaxOutputTokens;                                    // EOS straight after the prompt
+        }
+    }
+    for (; step < kMaxOutputTokens && m->n_past < n_ctx; ++step) {
         tk_llama_token in;
         const bool from_prompt = m->n_consumed < (int)m->embd_inp.size();
         if (from_prompt) {
