@@ -117,6 +117,7 @@ static void default_tunables(thk_ctx* ctx) {
     // 0 = gemv_blocks_per_cu / variant 0, > 0 = explicit
     // workgroups per prefill GEMM launch (<= 256): fewer = fewer K-splits = less partial-tile traffic, but fewer CUs streaming
     for (const char* k : {"qkv", "wo", "w13", "w2"}) { ctx->tun[std::string("prefill_blocks_") + k] = 256; ctx->tun[std::string("prefill_tile_") + k] = 256; }   // tile rows: 128 | 256
+    ctx->tun["prefill_attn_mfma"] = 1;
     ctx->tun["prefill_tile_wo"] = 128; ctx->tun["prefill_tile_w2"] = 128;   // 16 row-blocks only: halve the 16-way split-K partials (-3 %)
     for (const char* k : {"qkv", "wo", "w13", "w2", "head"}) {
         ctx->tun[std::string("gemv_bpc_") + k] = -1;
@@ -386,15 +387,20 @@ extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache
     if (nsplit > 1) HIPCHK(ctx, launch_attn_combine(a.part_o, a.part_ml, out, (int)H, (int)D, nsplit, ctx->stream));
     return THK_OK;
 }
+// MFMA tile kernel for D = 64 | 128 (tunable prefill_attn_mfma, default on); otherwise one workgroup per (head, query)
+static hipError_t attn_prefill_dispatch(thk_ctx* ctx, const float* q, const float* kc, const float* vc, int n_past, int M, int H, int D, float* out) {
+    if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) return launch_attn_prefill_mfma(q, kc, vc, n_past, M, H, D, out, ctx->stream);
+    AttnArgs a{};
+    a.q = q; a.kcache = kc; a.vcache = vc; a.pos_ptr = nullptr; a.pos_val = n_past; a.H = H; a.D = D;
+    a.nsplit = 1; a.tc = n_past + M; a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = M; a.out = out;
+    return launch_attn_decode(a, ctx->stream);
+}
 extern "C" int thk_attn_prefill(thk_ctx* ctx, const float* q, const float* kcache, const float* vcache, int64_t n_past, int64_t M, int64_t H, int64_t D, float* out) {
     if (!ctx) return THK_ERR_INVALID;
     REQUIRE(ctx, q && kcache && vcache && out && M > 0 && H > 0 && n_past >= 0, "thk_attn_prefill: bad arguments");
     REQUIRE(ctx, valid_head_dim(D), "thk_attn_prefill: head dim %lld not in {64,128,256}", (long long)D);
     REQUIRE(ctx, n_past + M <= 0x7FFFFFFF / (H * D), "thk_attn_prefill: shape too large");
-    AttnArgs a{};
-    a.q = q; a.kcache = kcache; a.vcache = vcache; a.pos_ptr = nullptr; a.pos_val = (int)n_past; a.H = (int)H; a.D = (int)D;
-    a.nsplit = 1; a.tc = (int)(n_past + M); a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = (int)M; a.out = out;
-    HIPCHK(ctx, launch_attn_decode(a, ctx->stream));
+    HIPCHK(ctx, attn_prefill_dispatch(ctx, q, kcache, vcache, (int)n_past, (int)M, (int)H, (int)D, out));
     return THK_OK;
 }
 extern "C" int thk_row_softmax(thk_ctx* ctx, float* x, int64_t rows, int64_t N) {
@@ -1033,12 +1039,7 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
         HIPCHK(ctx, launch_prefill_ximg(b.X, L.attention_norm, M, E, b.imgE, st));
         HIPCHK(ctx, launch_prefill_gemm(wqkv, pq, b.imgE, b.part, st));
         HIPCHK(ctx, launch_prefill_reduce_qkv(b.part, pq, m->rope_tab, n_past, D, b.Q, kc, vc, st));
-        {
-            AttnArgs a{};
-            a.q = b.Q; a.kcache = kc; a.vcache = vc; a.pos_ptr = nullptr; a.pos_val = n_past; a.H = H; a.D = D;
-            a.nsplit = 1; a.tc = n_past + M; a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = M; a.out = b.ATT;
-            HIPCHK(ctx, launch_attn_decode(a, st));
-        }
+        HIPCHK(ctx, attn_prefill_dispatch(ctx, b.Q, kc, vc, n_past, M, H, D, b.ATT));
         HIPCHK(ctx, launch_prefill_ximg(b.ATT, nullptr, M, E, b.imgE, st));
         HIPCHK(ctx, launch_prefill_gemm(&L.wo, po, b.imgE, b.part, st));
         HIPCHK(ctx, launch_prefill_reduce_store(b.part, po, b.X, true, st));

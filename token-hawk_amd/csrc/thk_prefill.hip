@@ -403,6 +403,196 @@ hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p,
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- causal prefill attention on MFMA
+// out[q, h, :] = softmax_{pos <= n_past + q}( Q[q,h,:] . K[pos,h,:] / sqrt(D) ) V[pos,h,:]   for the M queries of a slab.
+// Workgroup = (head, 32-query tile), 4 waves; wave w takes the 32-position tiles w, w+4, ... with its own online
+// softmax state, the four states are merged through LDS at the end.  Per tile:
+//   S^T[pos][q] = K Q^T      A = K tile rows (f32 -> hi/lo f16, staged in LDS: coalesced global reads, XOR-swizzled
+//                            rows => conflict-free fragment reads), B = Q^T fragments held in registers;
+//   online softmax           with S TRANSPOSED a lane owns ONE query (column) and 16 of the tile's 32 positions, so
+//                            the row max / row sum are 16 register ops + one xor-32 shuffle, and the O^T accumulator
+//                            (columns = the same query) is rescaled by a per-lane scalar;
+//   O^T[d][q] += V^T P^T     B = P^T straight from the S^T registers (k-slot order = register order; the A side
+//                            gathers V[pos][d] from the LDS tile in that same order with 16-bit reads).
+// Every product of two f32 operands is three f16 MFMAs (hi.hi + hi.lo + lo.hi): f32-class accuracy, as in the GEMM.
+// Replaces one workgroup per (head, query) re-reading that head's K/V from L2: 17 -> 105 us per slab-layer as the
+// context grew from 128 to 512 positions.
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4(const f4 v, h4v& hi, h4v& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
+}
+// A 32 x D f32 tile of the cache -> registers (all loads issued back to back: written as load+convert+store per
+// segment, hipcc waits vmcnt(0) after every load, 32 serialized L2 round trips per tile = 17 us) ...
+template <int D>
+struct AttnTileRegs { f4 v[32 * (D / 4) / 64]; };
+template <int D>
+__device__ __forceinline__ void attn_load_tile(AttnTileRegs<D>& r, const float* __restrict__ cache, int p0, int p_last, int E, int hcol, int lane) {
+    constexpr int SPR = D / 4;                          // float4 segments per row
+#pragma unroll
+    for (int i = 0; i < 32 * SPR / 64; ++i) {
+        const int idx = i * 64 + lane, row = idx / SPR, seg = idx % SPR;
+        const int prow = p0 + row < p_last ? p0 + row : p_last;          // rows past the context repeat the last cached row (masked later)
+        r.v[i] = *reinterpret_cast<const f4*>(cache + (size_t)prow * E + hcol + seg * 4);
+    }
+}
+// ... -> hi/lo f16 in the wave's LDS tile, rows of D halfs; SWZ: 16-byte pieces XOR-swizzled by the row (fragment reads)
+template <int D, bool SWZ>
+__device__ __forceinline__ void attn_store_tile(const AttnTileRegs<D>& r, int lane, _Float16* t_hi, _Float16* t_lo) {
+    constexpr int SPR = D / 4;
+#pragma unroll
+    for (int i = 0; i < 32 * SPR / 64; ++i) {
+        const int idx = i * 64 + lane, row = idx / SPR, seg = idx % SPR;
+        h4v hi, lo; split4(r.v[i], hi, lo);
+        const int piece = seg >> 1, pos = SWZ ? (piece ^ (row & (D / 8 - 1))) : piece;
+        const int off = row * D + pos * 8 + (seg & 1) * 4;
+        *reinterpret_cast<h4v*>(t_hi + off) = hi;
+        *reinterpret_cast<h4v*>(t_lo + off) = lo;
+    }
+}
+template <int D>
+__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ Kc, const float* __restrict__ Vc,
+                                                                int n_past, int M, int H, float scale, float* __restrict__ out) {
+    constexpr int KS = D / 16, DB = D / 32;
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // 4 waves x {hi, lo} x 32 x D halfs; reused for the merge
+    __shared__ float sm_m[4][32], sm_l[4][32], sm_f[4][32];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = blockIdx.x % H, q0 = (blockIdx.x / H) * 32;
+    const int E = H * D, hcol = h * D;
+    const int qn = lane & 31, half = lane >> 5;
+    _Float16* t_hi = reinterpret_cast<_Float16*>(lds_raw) + (size_t)wave * 2 * 32 * D;
+    _Float16* t_lo = t_hi + 32 * D;
+
+    h8 qh[KS], ql[KS];                                  // B fragments of Q^T: lane (q, half) holds d = 16 ks + 8 half + e
+    {
+        const int qrow = q0 + qn < M ? q0 + qn : M - 1;
+        const float* qp = Q + (size_t)qrow * E + hcol + half * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const f4 a = *reinterpret_cast<const f4*>(qp + ks * 16), b = *reinterpret_cast<const f4*>(qp + ks * 16 + 4);
+            h4v ah, al, bh, bl; split4(a, ah, al); split4(b, bh, bl);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { qh[ks][e] = ah[e]; qh[ks][4 + e] = bh[e]; ql[ks][e] = al[e]; ql[ks][4 + e] = bl[e]; }
+        }
+    }
+    float m = -INFINITY, l = 0.f;
+    f16v o[DB];
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[b][i] = 0.f;
+
+    const int q_last = q0 + 31 < M ? q0 + 31 : M - 1;
+    const int p_last = n_past + M - 1;                  // last cached row
+    const int ntiles = (n_past + q_last) / 32 + 1;      // tiles that hold a position some query of this tile may see
+    const int qabs = n_past + q0 + qn;                  // this lane's query position
+    for (int t = wave; t < ntiles; t += 4) {
+        const int p0 = t * 32;
+        AttnTileRegs<D> tr;
+        attn_load_tile<D>(tr, Kc, p0, p_last, E, hcol, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        attn_store_tile<D, true>(tr, lane, t_hi, t_lo);
+        __builtin_amdgcn_sched_barrier(0);
+        attn_load_tile<D>(tr, Vc, p0, p_last, E, hcol, lane);           // V's round trip runs under the S^T / softmax phase
+        __builtin_amdgcn_sched_barrier(0);
+        f16v s;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {               // A fragment: row = position (lane & 31), piece 2 ks + half
+            const int off = qn * D + (((ks * 2 + half) ^ (qn & (D / 8 - 1))) * 8);
+            const h8 kh = *reinterpret_cast<const h8*>(t_hi + off), kl = *reinterpret_cast<const h8*>(t_lo + off);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+        }
+        // s[r] = S[pos = p0 + (r&3) + 8 (r>>2) + 4 half][this lane's query]; scale after the sum (th.cpp:527-529), causal mask
+        float bm = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pos = p0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            s[r] = pos <= qabs ? s[r] * scale : -INFINITY;
+            bm = fmaxf(bm, s[r]);
+        }
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m, bm);
+        const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);       // mn == -inf only while m == -inf
+        float ps = 0.f;
+        h8 ph[2], pl[2];                                // B fragments of P^T: k-slot (s2, half, e) = register 8 s2 + e
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pv = (s[r] == -INFINITY) ? 0.f : expf(s[r] - mn);
+            ps += pv;
+            const _Float16 hi = (_Float16)pv;
+            ph[r >> 3][r & 7] = hi; pl[r >> 3][r & 7] = (_Float16)(pv - (float)hi);
+        }
+        ps += __shfl_xor(ps, 32, 64);
+        l = l * alpha + ps; m = mn;
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[b][i] *= alpha;
+        __builtin_amdgcn_sched_barrier(0);
+        attn_store_tile<D, false>(tr, lane, t_hi, t_lo);                 // same LDS region: K is consumed
+#pragma unroll
+        for (int b = 0; b < DB; ++b)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {            // A fragment of V^T: row d = 32 b + (lane & 31), k-slot e -> position 16 s2 + (e&3) + 8 (e>>2) + 4 half
+                h8 vh, vl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int off = (16 * s2 + (e & 3) + 8 * (e >> 2) + 4 * half) * D + 32 * b + qn;
+                    vh[e] = t_hi[off]; vl[e] = t_lo[off];
+                }
+                o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, ph[s2], o[b], 0, 0, 0);
+                o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, pl[s2], o[b], 0, 0, 0);
+                o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s2], o[b], 0, 0, 0);
+            }
+    }
+    // merge the four waves: o[b][r] = O^T[d = 32 b + (r&3) + 8 (r>>2) + 4 half][q = qn]
+    __syncthreads();                                    // every wave is done with its tile region
+    float* sm_o = reinterpret_cast<float*>(lds_raw);    // [wave][d][32]
+    if (half == 0) { sm_m[wave][qn] = m; sm_l[wave][qn] = l; }
+#pragma unroll
+    for (int b = 0; b < DB; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm_o[((size_t)wave * D + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * half) * 32 + qn] = o[b][r];
+    __syncthreads();
+    if (threadIdx.x < 128) {                            // per (wave, query) weight exp(m_w - max m) / denominator, once
+        const int w = threadIdx.x >> 5, q = threadIdx.x & 31;
+        const float mm = fmaxf(fmaxf(sm_m[0][q], sm_m[1][q]), fmaxf(sm_m[2][q], sm_m[3][q]));
+        float den = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) den += (sm_m[u][q] == -INFINITY) ? 0.f : sm_l[u][q] * expf(sm_m[u][q] - mm);
+        sm_f[w][q] = (sm_m[w][q] == -INFINITY) ? 0.f : expf(sm_m[w][q] - mm) / den;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * D; idx += 256) {
+        const int q = idx / D, d = idx % D;
+        if (q0 + q >= M) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc += sm_o[((size_t)w * D + d) * 32 + q] * sm_f[w][q];
+        out[(size_t)(q0 + q) * E + hcol + d] = acc;
+    }
+}
+
+hipError_t launch_attn_prefill_mfma(const float* Q, const float* Kc, const float* Vc, int n_past, int M, int H, int D, float* out, hipStream_t st) {
+    if (D != 64 && D != 128) return hipErrorInvalidValue;
+    const int grid = H * ((M + 31) / 32);
+    const size_t lds = (size_t)4 * 2 * 32 * D * 2;
+    const float scale = 1.0f / sqrtf((float)D);
+    hipError_t e = hipSuccess;
+    if (D == 128) {
+        static bool done = false;
+        if (!done) { e = hipFuncSetAttribute((const void*)attn_prefill_mfma_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = (e == hipSuccess); }
+        if (e == hipSuccess) hipLaunchKernelGGL(attn_prefill_mfma_kernel<128>, dim3(grid), dim3(256), lds, st, Q, Kc, Vc, n_past, M, H, scale, out);
+    } else {
+        hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, dim3(grid), dim3(256), lds, st, Q, Kc, Vc, n_past, M, H, scale, out);
+    }
+    return e != hipSuccess ? e : hipGetLastError();
+}
+
 size_t gemm_prefill_workspace_bytes(int M, int R, int C) {
     const PrefillPlan p = prefill_plan(M < 128 ? M : 128, R, 1, C, 0, 0);
     return (p.ximg_bytes + 255) / 256 * 256 + p.part_floats * 4;
