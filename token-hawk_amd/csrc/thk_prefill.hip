@@ -37,6 +37,8 @@ __device__ __forceinline__ float wave_sum_prefill(float v) {
 }
 
 constexpr int kKC = 32;                  // K columns per LDS stage (2 MFMA k-steps)
+constexpr int kMaxDevices = 64;
+static int current_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < kMaxDevices ? d : 0; }
 
 // ---------------------------------------------------------------- LDS-DMA pipeline, stream-K
 // A kernel that keeps one K-chunk of loads in flight per wave runs, at one workgroup per CU, at the memory
@@ -372,8 +374,9 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, c
 #define THK_V3(MTV, NFV)                                                                                                 \
     {                                                                                                                    \
         const size_t lds = (ximg_stage_bytes(MTV) + (size_t)NFV * 8192) * kNST;                                          \
-        static bool attr_done = false;                                                                                   \
-        if (!attr_done) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3_kernel<MTV, NFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = (e == hipSuccess); } \
+        static bool attr_done[kMaxDevices] = {};     /* the attribute is per device */                                   \
+        const int dev = current_device();                                                                                \
+        if (!attr_done[dev]) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3_kernel<MTV, NFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[dev] = (e == hipSuccess); } \
         if (e == hipSuccess) hipLaunchKernelGGL((gemm_prefill_v3_kernel<MTV, NFV>), dim3(p.G), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, part, p); \
     }
     if (p.tile_rows == 128) switch (p.MT) {
@@ -584,8 +587,9 @@ hipError_t launch_attn_prefill_mfma(const float* Q, const float* Kc, const float
     const float scale = 1.0f / sqrtf((float)D);
     hipError_t e = hipSuccess;
     if (D == 128) {
-        static bool done = false;
-        if (!done) { e = hipFuncSetAttribute((const void*)attn_prefill_mfma_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done = (e == hipSuccess); }
+        static bool done[kMaxDevices] = {};          // the attribute is per device
+        const int dev = current_device();
+        if (!done[dev]) { e = hipFuncSetAttribute((const void*)attn_prefill_mfma_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[dev] = (e == hipSuccess); }
         if (e == hipSuccess) hipLaunchKernelGGL(attn_prefill_mfma_kernel<128>, dim3(grid), dim3(256), lds, st, Q, Kc, Vc, n_past, M, H, scale, out);
     } else {
         hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, dim3(grid), dim3(256), lds, st, Q, Kc, Vc, n_past, M, H, scale, out);
