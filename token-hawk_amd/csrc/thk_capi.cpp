@@ -389,7 +389,7 @@ extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache
 }
 // MFMA tile kernel for D = 64 | 128 (tunable prefill_attn_mfma, default on); otherwise one workgroup per (head, query)
 static hipError_t attn_prefill_dispatch(thk_ctx* ctx, const float* q, const float* kc, const float* vc, int n_past, int M, int H, int D, float* out) {
-    if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) return launch_attn_prefill_mfma(q, kc, vc, n_past, M, H, D, out, ctx->stream);
+    if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) return launch_attn_prefill_mfma(q, kc, vc, n_past, M, H, D, out, nullptr, ctx->stream);
     AttnArgs a{};
     a.q = q; a.kcache = kc; a.vcache = vc; a.pos_ptr = nullptr; a.pos_val = n_past; a.H = H; a.D = D;
     a.nsplit = 1; a.tc = n_past + M; a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = M; a.out = out;
@@ -989,8 +989,8 @@ extern "C" int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_ent
 // is disabled, th-llama.cpp:15, and its causal mask is only right at n_past == 0, Q5): causal
 // attention over the f32 cache, K/V rows appended at [n_past, n_past+M), logits of the last token.
 //
-// Per 128-token slab and layer, 12 launches: norm->X image | wq,wk,wv GEMM | reduce + RoPE + KV write | causal
-// attention | X image | wo GEMM | reduce + residual | norm->X image | w1,w3 GEMM | reduce + SwiGLU -> X image |
+// Per 128-token slab and layer, 11 launches: norm->X image | wq,wk,wv GEMM | reduce + RoPE + KV write | causal
+// attention -> X image | wo GEMM | reduce + residual | norm->X image | w1,w3 GEMM | reduce + SwiGLU -> X image |
 // w2 GEMM | reduce + residual.  (thk_prefill.hip explains the GEMM: LDS-DMA pipeline, stream-K, hi/lo split.)
 struct PrefillBufs { float *X, *Q, *ATT; int32_t* tok; char *imgE, *imgF; float* part; };
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -1039,8 +1039,12 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
         HIPCHK(ctx, launch_prefill_ximg(b.X, L.attention_norm, M, E, b.imgE, st));
         HIPCHK(ctx, launch_prefill_gemm(wqkv, pq, b.imgE, b.part, st));
         HIPCHK(ctx, launch_prefill_reduce_qkv(b.part, pq, m->rope_tab, n_past, D, b.Q, kc, vc, st));
-        HIPCHK(ctx, attn_prefill_dispatch(ctx, b.Q, kc, vc, n_past, M, H, D, b.ATT));
-        HIPCHK(ctx, launch_prefill_ximg(b.ATT, nullptr, M, E, b.imgE, st));
+        if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) {
+            HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, n_past, M, H, D, nullptr, b.imgE, st));   // writes wo's X image directly
+        } else {
+            HIPCHK(ctx, attn_prefill_dispatch(ctx, b.Q, kc, vc, n_past, M, H, D, b.ATT));
+            HIPCHK(ctx, launch_prefill_ximg(b.ATT, nullptr, M, E, b.imgE, st));
+        }
         HIPCHK(ctx, launch_prefill_gemm(&L.wo, po, b.imgE, b.part, st));
         HIPCHK(ctx, launch_prefill_reduce_store(b.part, po, b.X, true, st));
         HIPCHK(ctx, launch_prefill_ximg(b.X, L.ffn_norm, M, E, b.imgE, st));

@@ -110,7 +110,8 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, c
 hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st);
 hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, float* kcache, float* vcache, hipStream_t st);
 // causal attention for the M queries of a slab (D = 64 | 128), f32-class accuracy on MFMA
-hipError_t launch_attn_prefill_mfma(const float* Q, const float* Kc, const float* Vc, int n_past, int M, int H, int D, float* out, hipStream_t st);
+hipError_t launch_attn_prefill_mfma(const float* Q, const float* Kc, const float* Vc, int n_past, int M, int H, int D, float* out /* [M,H*D] or null */,
+                                    void* ximg /* if out is null: the X image of the consuming GEMM */, hipStream_t st);
 hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st);
 
 }  // namespace thk

@@ -453,9 +453,10 @@ __device__ __forceinline__ void attn_store_tile(const AttnTileRegs<D>& r, int la
         *reinterpret_cast<h4v*>(t_lo + off) = lo;
     }
 }
-template <int D>
+// IMG: instead of out[M, E] f32, write the hi/lo X image of the wo GEMM directly (one launch and one 2 MB round trip less)
+template <int D, bool IMG>
 __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ Kc, const float* __restrict__ Vc,
-                                                                int n_past, int M, int H, float scale, float* __restrict__ out) {
+                                                                int n_past, int M, int H, float scale, float* __restrict__ out, char* __restrict__ img) {
     constexpr int KS = D / 16, DB = D / 32;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // 4 waves x {hi, lo} x 32 x D halfs; reused for the merge
     __shared__ float sm_m[4][32], sm_l[4][32], sm_f[4][32];
@@ -572,29 +573,38 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
     __syncthreads();
     for (int idx = threadIdx.x; idx < 32 * D; idx += 256) {
         const int q = idx / D, d = idx % D;
-        if (q0 + q >= M) break;
+        if (!IMG && q0 + q >= M) break;
         float acc = 0.f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) acc += sm_o[((size_t)w * D + d) * 32 + q] * sm_f[w][q];
-        out[(size_t)(q0 + q) * E + hcol + d] = acc;
+        if (IMG) {                                      // pad rows (tok >= M) of the image are zeros
+            if (q0 + q >= M) acc = 0.f;
+            const int MT = (M + 31) / 32, col = hcol + d;
+            const _Float16 hi = (_Float16)acc;
+            *reinterpret_cast<_Float16*>(img + ximg_off(MT, 0, q0 + q, col) + (col & 7) * 2) = hi;
+            *reinterpret_cast<_Float16*>(img + ximg_off(MT, 1, q0 + q, col) + (col & 7) * 2) = (_Float16)(acc - (float)hi);
+        } else {
+            out[(size_t)(q0 + q) * E + hcol + d] = acc;
+        }
     }
 }
 
-hipError_t launch_attn_prefill_mfma(const float* Q, const float* Kc, const float* Vc, int n_past, int M, int H, int D, float* out, hipStream_t st) {
-    if (D != 64 && D != 128) return hipErrorInvalidValue;
+template <int D, bool IMG>
+static hipError_t launch_attn_prefill_t(const float* Q, const float* Kc, const float* Vc, int n_past, int M, int H, float* out, char* img, hipStream_t st) {
     const int grid = H * ((M + 31) / 32);
     const size_t lds = (size_t)4 * 2 * 32 * D * 2;
-    const float scale = 1.0f / sqrtf((float)D);
     hipError_t e = hipSuccess;
-    if (D == 128) {
-        static bool done[kMaxDevices] = {};          // the attribute is per device
-        const int dev = current_device();
-        if (!done[dev]) { e = hipFuncSetAttribute((const void*)attn_prefill_mfma_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[dev] = (e == hipSuccess); }
-        if (e == hipSuccess) hipLaunchKernelGGL(attn_prefill_mfma_kernel<128>, dim3(grid), dim3(256), lds, st, Q, Kc, Vc, n_past, M, H, scale, out);
-    } else {
-        hipLaunchKernelGGL(attn_prefill_mfma_kernel<64>, dim3(grid), dim3(256), lds, st, Q, Kc, Vc, n_past, M, H, scale, out);
-    }
+    static bool done[kMaxDevices] = {};                 // the attribute is per device (64 KB dynamic + the static arrays)
+    const int dev = current_device();
+    if (!done[dev]) { e = hipFuncSetAttribute((const void*)attn_prefill_mfma_kernel<D, IMG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[dev] = (e == hipSuccess); }
+    if (e == hipSuccess) hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, IMG>), dim3(grid), dim3(256), lds, st, Q, Kc, Vc, n_past, M, H, 1.0f / sqrtf((float)D), out, img);
     return e != hipSuccess ? e : hipGetLastError();
+}
+// out != null: out[M, H*D] f32;  otherwise ximg = the hi/lo X image (C = H*D, M <= 128) of the GEMM that consumes the attention output
+hipError_t launch_attn_prefill_mfma(const float* Q, const float* Kc, const float* Vc, int n_past, int M, int H, int D, float* out, void* ximg, hipStream_t st) {
+    if ((D != 64 && D != 128) || (!out && (!ximg || M > 128 || (H * D) % kKC != 0))) return hipErrorInvalidValue;
+    if (D == 128) return out ? launch_attn_prefill_t<128, false>(Q, Kc, Vc, n_past, M, H, out, nullptr, st) : launch_attn_prefill_t<128, true>(Q, Kc, Vc, n_past, M, H, nullptr, (char*)ximg, st);
+    return out ? launch_attn_prefill_t<64, false>(Q, Kc, Vc, n_past, M, H, out, nullptr, st) : launch_attn_prefill_t<64, true>(Q, Kc, Vc, n_past, M, H, nullptr, (char*)ximg, st);
 }
 
 size_t gemm_prefill_workspace_bytes(int M, int R, int C) {
