@@ -116,6 +116,12 @@ def kernel_profile(model, shape, T, n_steps=6):
 
 def main():
     args = parse()
+    # stdout must carry exactly ONE line (the JSON).  Native libraries print there too (RCCL writes a version banner
+    # through C stdio when a communicator is created, flushed at exit), so fd 1 is pointed at stderr for the whole
+    # process and the JSON goes to a private duplicate of the real stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -293,7 +299,7 @@ def main():
             except Exception as e:   # the baseline is a report item; never let it kill the GPU number
                 result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if rank == 0:
-            print(json.dumps(result), flush=True)
+            os.write(json_fd, (json.dumps(result) + "\n").encode())
         if stage is not None and getattr(stage, "pp", None) is not None:
             ctx.lib.thk_pp_destroy(stage.pp)
         model.close()
