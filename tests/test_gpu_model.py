@@ -346,6 +346,21 @@ def test_context_beyond_512(thk, orc, ctx):
     m.close()
 
 
+def test_prefill_13b_geometry(thk, ctx):
+    """Prefill at the 13B row geometry (E=5120, H=40, F=13824; 2 layers): different row-block counts, K-chunk
+    counts and stream-K shares than 7B.  Reference: token-by-token decode of the same prompt."""
+    shape = thk.ModelShape(n_embd=5120, n_head=40, n_layer=2)
+    a = thk.Model(ctx, shape); a.fill_synthetic(); a.finalize()
+    b = thk.Model(ctx, shape); b.fill_synthetic(); b.finalize()
+    rng = np.random.default_rng(13)
+    toks = np.concatenate([[1], rng.integers(3, 32000, 99)]).astype(np.int32)      # 100 tokens: MT = 4 with 28 pad rows
+    lp = a.prefill(toks, 0)
+    ld, _ = b.eval(toks, 0)
+    assert np.abs(lp - ld).max() < LOGIT_TOL
+    assert int(lp.argmax()) == int(ld.argmax())
+    a.close(); b.close()
+
+
 def test_prefill_full_width_128_tokens(thk, orc, ctx):
     """128-token prompt at 7B row geometry (2 layers): MFMA GEMMs at (M=128, C=4096/11008) vs token-by-token decode."""
     shape = thk.ModelShape(n_layer=2)
