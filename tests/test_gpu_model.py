@@ -363,6 +363,21 @@ def test_prefill_is_bitwise_repeatable(thk, ctx, M):
     m.close()
 
 
+def test_prefill_into_second_sequence_and_faithful_head(thk, orc, ctx):
+    """Prefill writes the KV rows of the sequence it is given (not sequence 0) and honours the lm-head mode."""
+    m, om = make_pair(thk, orc, ctx, "TINY_Q1", n_seq=2, lm_mode=1)     # 1 = THK_LMHEAD_FAITHFUL (defect Q1 reproduced)
+    rng = np.random.default_rng(77)
+    toks = [1] + rng.integers(3, 32000, 24).tolist()
+    m.eval([5], 0, seq=0)                                               # sequence 0 holds unrelated state
+    lp = m.prefill(toks, 0, seq=1)
+    for i, t in enumerate(toks):
+        lo, _ = om.eval(t, i, flags=orc.FAITHFUL_ORDER | orc.LM_FAITHFUL)
+    assert np.abs(lp - lo).max() < LOGIT_TOL
+    lg, _ = m.eval([9], len(toks), seq=1); lo2, _ = om.eval(9, len(toks), flags=orc.FAITHFUL_ORDER | orc.LM_FAITHFUL)
+    assert np.abs(lg - lo2).max() < LOGIT_TOL
+    m.close()
+
+
 def test_prefill_13b_geometry(thk, ctx):
     """Prefill at the 13B row geometry (E=5120, H=40, F=13824; 2 layers): different row-block counts, K-chunk
     counts and stream-K shares than 7B.  Reference: token-by-token decode of the same prompt."""
