@@ -183,6 +183,9 @@ def main():
                 except Exception as e:
                     log(f"[bench r{rank}] native transport unavailable: {e}"); ok = 0
                 dist.broadcast(uid, 0)
+                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # agree BEFORE the collective ncclCommInitRank inside thk_pp_create
+                ok = int(flag.item())
                 torch.cuda.synchronize(dev)
                 if ok:
                     try:
