@@ -136,7 +136,7 @@ struct Geo { int bpc, var; };
 static Geo auto_geometry(const char* kernel, int n_embd) {
     const bool w13b = n_embd == 5120;
     if (!strcmp(kernel, "qkv")) return w13b ? Geo{3, 3} : Geo{3, 0};
-    if (!strcmp(kernel, "wo")) return Geo{2, 0};
+    if (!strcmp(kernel, "wo")) return w13b ? Geo{2, 0} : Geo{2, 3};   // 7B: variant 3 is +0.5 % in graph mode (profiles/r01_sweep_graph_7b.json)
     if (!strcmp(kernel, "w13")) return w13b ? Geo{8, 1} : Geo{8, 0};
     if (!strcmp(kernel, "w2")) return Geo{2, 2};
     if (!strcmp(kernel, "head")) return w13b ? Geo{8, 2} : Geo{8, 1};
