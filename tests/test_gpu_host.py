@@ -175,3 +175,25 @@ def test_prompt_prefill_generates_the_same_text(host, ctx, model_file, temp):
         host.thh_free(h)
     assert out[0][0] > 0
     assert out[0] == out[1]
+
+
+def test_cli_matches_library(host, ctx, model_file):
+    """`thk_cli -m file --greedy "prompt"` (the reference's `th -m ... "prompt"` contract, cli/main.cpp:182-198) prints
+    the text do_inference produces through the library, with and without --prefill."""
+    import subprocess
+    path, _, words, scores = model_file
+    cli = os.path.join(ROOT, "token-hawk_amd", "thk_cli")
+    if not os.path.exists(cli):
+        pytest.skip("thk_cli not built")
+    h = host.thh_load_file(ctx.h, path.encode(), 0)
+    host.thh_set_sampler(h, 40, 0.95, 0.0, 1.1)
+    n_past = C.c_int32(); text = C.create_string_buffer(1 << 16)
+    host.thh_do_inference(h, b"hello world", C.byref(n_past), text, len(text))
+    host.thh_free(h)
+    for extra in ([], ["--prefill"]):
+        r = subprocess.run([cli, "-m", path, "--greedy", *extra, "hello world"], capture_output=True, timeout=240)
+        assert r.returncode == 0, r.stderr.decode()[-400:]
+        assert r.stdout == text.value
+        assert b"tokens generated" in r.stderr
+    r = subprocess.run([cli, "--bogus"], capture_output=True, timeout=60)
+    assert r.returncode == 2 and b"unknown option" in r.stderr
