@@ -259,7 +259,9 @@ int thk_pp_recv_token(thk_pp* pp, thk_model* m, int32_t seq, int peer);
  * per call.  Unknown names return THK_ERR_NOTFOUND.
  *   decode : gemv_blocks_per_cu; gemv_bpc_{qkv,wo,w13,w2,head} and gemv_variant_{...}
  *            (-1 = per-shape default, 0 = generic, >0 explicit); attn_splits (1|2|4|8);
- *            attn_waves (4|8); use_graph; experiments kept off: fuse_attn_wo, attn_combine
+ *            attn_waves (4|8); use_graph; experiments kept off: fuse_attn_wo, attn_combine;
+ *            measure_skip_kernel (1..6: that kernel is not launched -- bench.py's marginal-cost
+ *            measurement; results are garbage, never set it in a product)
  *   prefill: prefill_blocks_{qkv,wo,w13,w2} (workgroups per GEMM launch, <= 256);
  *            prefill_tile_{...} (weight rows per workgroup, 128|256); prefill_attn_mfma */
 int thk_set_tunable(thk_ctx* ctx, const char* name, int64_t value);

@@ -89,6 +89,7 @@ struct thk_model {
     void* prefill_ws = nullptr; size_t prefill_ws_bytes = 0;
     // fused attention+wo launch: per-layer arrival counters (zeroed at the start of every step) + error word
     int fuse_attn_wo = 0, fuse_initial_sleeps = 0, attn_waves = 8, attn_combine = 0;
+    int skip_kernel = 0;   // measurement aid (tunable measure_skip_kernel): 1 qkv, 2 attention, 3 wo, 4 w13, 5 w2, 6 lm-head are NOT launched
     unsigned* head_ticket = nullptr;   // [H] counters of the in-launch split combine
     unsigned* fuse_counters = nullptr;   // [n_local_layers] then [1] error
 };
@@ -128,6 +129,7 @@ static void default_tunables(thk_ctx* ctx) {
     ctx->tun["attn_combine"] = 0;         // last-arriving split block of a head merges the partials inside the attention launch (measured: slower)
     ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
     ctx->tun["fuse_attn_wo"] = 0;         // attention splits + wo mat-vec in one launch (in-launch hand-off)
+    ctx->tun["measure_skip_kernel"] = 0;  // bench.py: marginal cost of one kernel = step time with minus without it (results are garbage then)
     ctx->tun["fuse_initial_sleeps"] = 0;  // consumer s_sleep(32) repetitions (~0.85 us each) before the first poll
 }
 // Auto launch geometry per (kernel, n_embd): {blocks per CU, variant}.  7B and 13B rows are swept values; other
@@ -668,7 +670,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.x = xr_in; a.gain = L.attention_norm; a.y = m->q;
             a.kcache = kc; a.vcache = vc; a.rope_tab = m->rope_tab; a.pos_ptr = &sb.st->pos; a.E = E; a.D = D;
             MARK("norm_qkv_rope_kv");
-            HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_ROPE_KV, m->var_qkv, a, m->grid_qkv, nt, st));
+            if (m->skip_kernel != 1) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_ROPE_KV, m->var_qkv, a, m->grid_qkv, nt, st));
         }
         {   // attention over the cache in place (steps 5-9, th-llama.cpp:341-397), then
             // split combine -> wo -> + residual (steps 10-11, th-llama.cpp:401-413)
@@ -693,9 +695,9 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
                 HIPCHK(ctx, launch_attn_wo(t, a, 0 /* default variant */, m->grid_wo, nt, st));
             } else {
                 MARK("attn_decode");
-                HIPCHK(ctx, launch_attn_decode(t, st));
+                if (m->skip_kernel != 2) HIPCHK(ctx, launch_attn_decode(t, st));
                 MARK("attn_wo_resid");
-                HIPCHK(ctx, launch_gemv((m->nsplit == 1 || combined) ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, wo_var, a, m->grid_wo, nt, st));
+                if (m->skip_kernel != 3) HIPCHK(ctx, launch_gemv((m->nsplit == 1 || combined) ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, wo_var, a, m->grid_wo, nt, st));
             }
         }
         {   // rms_norm*gain -> w1,w3 -> silu*gate   (steps 12-14, th-llama.cpp:415-438)
@@ -703,7 +705,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.W[0] = L.w1; a.W[1] = L.w3; a.R = F; a.C = E; a.n_groups = F;
             a.x = m->x; a.gain = L.ffn_norm; a.y = m->u;
             MARK("norm_w13_swiglu");
-            HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_SWIGLU, m->var_w13, a, m->grid_w13, nt, st));
+            if (m->skip_kernel != 4) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_SWIGLU, m->var_w13, a, m->grid_w13, nt, st));
         }
         {   // w2 -> + residual   (steps 15-16, th-llama.cpp:440-451)
             GemvArgs a{};
@@ -713,7 +715,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.x = m->u; a.resid = m->x;
             a.y = (i == nl - 1 && !(m->flags & THK_STAGE_HEAD)) ? sb.hidden_out : m->x;
             MARK("w2_resid");
-            HIPCHK(ctx, launch_gemv(GEMV_PRO_COPY, GEMV_EPI_RESID, m->var_w2, a, m->grid_w2, nt, st));
+            if (m->skip_kernel != 5) HIPCHK(ctx, launch_gemv(GEMV_PRO_COPY, GEMV_EPI_RESID, m->var_w2, a, m->grid_w2, nt, st));
         }
     }
     if (m->flags & THK_STAGE_HEAD) {   // final norm -> lm-head -> greedy pick   (th-llama.cpp:240-268, :826-838)
@@ -725,7 +727,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         a.lm_faithful = m->lm_mode == THK_LMHEAD_FAITHFUL; q1_constants(V, &a.q1_split, &a.q1_cov);
         a.block_best = m->block_best;
         MARK("norm_lmhead");
-        HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, nt, st));
+        if (m->skip_kernel != 6) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, nt, st));
         MARK("finish_token");
         HIPCHK(ctx, launch_finish_token(m->block_best, m->grid_head, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, st));
     } else {
@@ -776,6 +778,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->nt = true;
     m->use_graph = tun(ctx, "use_graph") != 0;
     m->fuse_initial_sleeps = (int)tun(ctx, "fuse_initial_sleeps");
+    m->skip_kernel = (int)tun(ctx, "measure_skip_kernel");
     m->attn_waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
     m->attn_combine = tun(ctx, "attn_combine") != 0 && m->nsplit > 1;
     m->fuse_attn_wo = tun(ctx, "fuse_attn_wo") != 0 && m->nsplit > 1 && (D == 64 || D == 128);
