@@ -729,7 +729,8 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         MARK("norm_lmhead");
         if (m->skip_kernel != 6) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, nt, st));
         MARK("finish_token");
-        HIPCHK(ctx, launch_finish_token(m->block_best, m->grid_head, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, st));
+        if (m->skip_kernel != 6) HIPCHK(ctx, launch_finish_token(m->block_best, m->grid_head, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, st));
+        else HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, st));       // no arg-max keys were written: keep the token
     } else {
         MARK("advance_pos");
         HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, st));
