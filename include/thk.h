@@ -215,9 +215,21 @@ int thk_model_seq_set_token(thk_model* m, int32_t seq, int32_t token);
  *   advance != 0: pos[seq] += 1 afterwards (0 = keep re-evaluating the same slot,
  *                 the fixed-T=512 benchmark protocol of BASELINE.md) */
 int thk_model_decode_step(thk_model* m, int32_t seq, int advance);
-/* n_steps back-to-back decode steps; replays a captured multi-step graph (8 steps per launch) when it
- * can, which amortises the inter-graph launch latency (~8 us) of the single-step form. */
+/* n_steps back-to-back decode steps; replays captured 8-, 4- and 2-step graphs (20 = 8 + 8 + 4), which
+ * amortises the inter-graph launch latency (~8 us) of the single-step form.
+ * Position contract (both calls): a step at position p needs p < n_ctx; an advancing step leaves p + 1.
+ * A call that would evaluate a position >= n_ctx returns THK_ERR_INVALID and enqueues nothing (the device
+ * side additionally never advances past n_ctx - 1). */
 int thk_model_decode_steps(thk_model* m, int32_t seq, int32_t n_steps, int advance);
+/* Capture now (nothing is run) the multi-step graphs thk_model_decode_steps(n_steps) will replay, so the first
+ * timed call does not pay for stream capture + graph instantiation. */
+int thk_model_prepare_steps(thk_model* m, int32_t seq, int32_t n_steps);
+/* 1 when the finalized model runs a decode step as ONE persistent loader/consumer launch (thk_engine.hip;
+ * tunable "engine", default on, shape permitting), 0 when it runs 5 fused launches per layer. */
+int thk_model_uses_engine(const thk_model* m);
+/* Development aid (tunable engine_trace=1 before finalize): the last step's per-workgroup, per-op s_memtime stamps,
+ * [n_cu][n_ops][8] 64-bit words (slot meaning in thk_engine.hip). */
+int thk_model_engine_trace(thk_model* m, unsigned long long* out, int64_t cap_words, int32_t* n_cu, int32_t* n_ops);
 void* thk_model_hidden_in(thk_model* m, int32_t seq);   /* dev f32[E], RCCL recv target */
 void* thk_model_hidden_out(thk_model* m, int32_t seq);  /* dev f32[E], RCCL send source */
 void* thk_model_token_dev(thk_model* m, int32_t seq);   /* dev int32: current/next token id */
@@ -259,9 +271,10 @@ int thk_pp_recv_token(thk_pp* pp, thk_model* m, int32_t seq, int peer);
  * per call.  Unknown names return THK_ERR_NOTFOUND.
  *   decode : gemv_blocks_per_cu; gemv_bpc_{qkv,wo,w13,w2,head} and gemv_variant_{...}
  *            (-1 = per-shape default, 0 = generic, >0 explicit); attn_splits (1|2|4|8);
- *            attn_waves (4|8); use_graph; experiments kept off: fuse_attn_wo, attn_combine;
+ *            attn_waves (4|8); use_graph; engine (1 = persistent loader/consumer launch per step when the
+ *            shape allows, 0 = launches); experiments kept off: fuse_attn_wo, attn_combine;
  *            measure_skip_kernel (1..6: that kernel is not launched -- bench.py's marginal-cost
- *            measurement; results are garbage, never set it in a product)
+ *            measurement; results are garbage; REFUSED unless the environment has THK_MEASURE_HOOKS=1)
  *   prefill: prefill_blocks_{qkv,wo,w13,w2} (workgroups per GEMM launch, <= 256);
  *            prefill_tile_{...} (weight rows per workgroup, 128|256); prefill_attn_mfma */
 int thk_set_tunable(thk_ctx* ctx, const char* name, int64_t value);

@@ -306,6 +306,22 @@ class Model:
     def decode_steps(self, n_steps: int, seq: int = 0, advance: bool = True):
         self.ctx.check(self.ctx.lib.thk_model_decode_steps(self.h, seq, n_steps, int(advance)), "thk_model_decode_steps")
 
+    def prepare_steps(self, n_steps: int, seq: int = 0):
+        """Capture the multi-step graphs decode_steps(n_steps) replays, without running anything."""
+        self.ctx.check(self.ctx.lib.thk_model_prepare_steps(self.h, seq, n_steps), "thk_model_prepare_steps")
+
+    def engine_trace(self):
+        """Development timeline of the last engine step: uint64 array [n_cu, n_ops, 8] (tunable engine_trace=1)."""
+        cap = 256 * 512 * 8 * 2
+        out = np.zeros(cap, np.uint64)
+        ncu, nops = C.c_int32(), C.c_int32()
+        self.ctx.check(self.ctx.lib.thk_model_engine_trace(self.h, out.ctypes.data, cap, C.byref(ncu), C.byref(nops)), "thk_model_engine_trace")
+        return out[:ncu.value * nops.value * 8].reshape(ncu.value, nops.value, 8)
+
+    def uses_engine(self) -> bool:
+        """True when decode steps run as one persistent loader/consumer launch (thk_engine.hip)."""
+        return bool(self.ctx.lib.thk_model_uses_engine(self.h))
+
     def seq_get(self, seq: int = 0, cap: int = 4096):
         out = np.empty(cap, np.int32)
         n, pos = C.c_int32(), C.c_int32()

@@ -74,6 +74,9 @@ SIGNATURES = {
     "thk_model_seq_set_token": (C.c_int, [vp, i32, i32]),
     "thk_model_decode_step": (C.c_int, [vp, i32, C.c_int]),
     "thk_model_decode_steps": (C.c_int, [vp, i32, i32, C.c_int]),
+    "thk_model_prepare_steps": (C.c_int, [vp, i32, i32]),
+    "thk_model_uses_engine": (C.c_int, [vp]),
+    "thk_model_engine_trace": (C.c_int, [vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]),
     "thk_model_hidden_in": (vp, [vp, i32]),
     "thk_model_hidden_out": (vp, [vp, i32]),
     "thk_model_token_dev": (vp, [vp, i32]),

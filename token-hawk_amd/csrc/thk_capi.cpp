@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <map>
@@ -58,12 +59,15 @@ struct SeqBuf {
     int advance_host = -1;           // last value written
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    hipGraph_t graph_multi = nullptr;        // kMultiStep decode steps in one graph (captured on first use)
-    hipGraphExec_t exec_multi = nullptr;
+    hipGraph_t graph_multi[3] = {nullptr, nullptr, nullptr};        // 2, 4 and 8 decode steps in one graph (thk_model_prepare_steps / first use)
+    hipGraphExec_t exec_multi[3] = {nullptr, nullptr, nullptr};
+    int pos_host = 0;                // position the NEXT step evaluates (every change goes through this API, so the host knows it exactly)
+    EngOp* eng_ops = nullptr;        // device: this sequence's engine program (cache / hidden-state pointers differ per sequence)
+    int eng_n_ops = 0;
 };
 
 static const int kGenLogCap = 4096;
-static const int kMultiStep = 8;
+static const int kMultiSteps[3] = {2, 4, 8};
 static const size_t kFuseStride = 1024;   // words per layer: counter line + kFuseFlags flag lines, padded
 
 struct thk_model {
@@ -92,6 +96,12 @@ struct thk_model {
     int skip_kernel = 0;   // measurement aid (tunable measure_skip_kernel): 1 qkv, 2 attention, 3 wo, 4 w13, 5 w2, 6 lm-head are NOT launched
     unsigned* head_ticket = nullptr;   // [H] counters of the in-launch split combine
     unsigned* fuse_counters = nullptr;   // [n_local_layers] then [1] error
+    // persistent loader/consumer engine (thk_engine.hip): one launch per decode step instead of 5 per layer
+    int engine = 0;                      // resolved at finalize (tunable "engine" and shape eligibility)
+    int eng_NS = 0, eng_v0 = 0, eng_v1 = 0, eng_nsplit = 1, eng_tc = 0;
+    unsigned long long* eng_gran = nullptr;   // all granule arrays: XG[2][E] | QG[3E] | OG[E] | UG[F] | PG[H*S*(D+2)]
+    unsigned* eng_words = nullptr;       // [0] epoch, [32] error word
+    unsigned long long* eng_trace = nullptr;   // development timeline (tunable engine_trace), [n_cu][n_ops][8]
 };
 
 // ---------------------------------------------------------------- helpers
@@ -129,7 +139,13 @@ static void default_tunables(thk_ctx* ctx) {
     ctx->tun["attn_combine"] = 0;         // last-arriving split block of a head merges the partials inside the attention launch (measured: slower)
     ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
     ctx->tun["fuse_attn_wo"] = 0;         // attention splits + wo mat-vec in one launch (in-launch hand-off)
-    ctx->tun["measure_skip_kernel"] = 0;  // bench.py: marginal cost of one kernel = step time with minus without it (results are garbage then)
+    ctx->tun["measure_skip_kernel"] = 0;  // bench.py: marginal cost of one kernel = step time with minus without it (results are garbage then);
+                                          // refused unless the process runs with THK_MEASURE_HOOKS=1 (never in a product)
+    ctx->tun["engine_park"] = 1;          // engine variant whose waiting consumer waves park one landed ring slot in registers (more loader run-ahead)
+    ctx->tun["engine_trace"] = 0;         // development: per-op s_memtime timeline of the engine (thk_model_engine_trace)
+    ctx->tun["engine"] = 0;               // 1 = decode step as ONE persistent loader/consumer launch (thk_engine.hip) when the shape allows; default 0 = 5
+                                          // launches per layer: measured on MI355X the engine streams at 6.9-7.0 TB/s but every in-launch all-to-all hand-off
+                                          // costs ~7 us against ~3.5 us for a kernel boundary (profiles/r02_engine_*.txt), 3.4 vs 2.5 ms per 7B token
     ctx->tun["fuse_initial_sleeps"] = 0;  // consumer s_sleep(32) repetitions (~0.85 us each) before the first poll
 }
 // Auto launch geometry per (kernel, n_embd): {blocks per CU, variant}.  7B and 13B rows are swept values; other
@@ -258,6 +274,10 @@ extern "C" int thk_set_tunable(thk_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return THK_ERR_INVALID;
     auto it = ctx->tun.find(name);
     if (it == ctx->tun.end()) return fail(ctx, THK_ERR_NOTFOUND, "unknown tunable '%s'", name);
+    if (!strcmp(name, "measure_skip_kernel") && value != 0) {
+        const char* hook = getenv("THK_MEASURE_HOOKS");
+        if (!hook || strcmp(hook, "1")) return fail(ctx, THK_ERR_INVALID, "measure_skip_kernel makes a model skip work; it is only accepted with THK_MEASURE_HOOKS=1 in the environment");
+    }
     it->second = value;
     return THK_OK;
 }
@@ -455,7 +475,7 @@ extern "C" int thk_argmax(thk_ctx* ctx, const float* logits, int64_t V, int32_t*
     if (rc != THK_OK) return rc;
     int nblocks = (int)((V + kBlock - 1) / kBlock); if (nblocks > 256) nblocks = 256;
     HIPCHK(ctx, launch_argmax(logits, (int)V, (unsigned long long*)ctx->scratch, nblocks, ctx->stream));
-    HIPCHK(ctx, launch_finish_token((const unsigned long long*)ctx->scratch, nblocks, nullptr, nullptr, 0, nullptr, id_out, ctx->stream));
+    HIPCHK(ctx, launch_finish_token((const unsigned long long*)ctx->scratch, nblocks, nullptr, nullptr, 0, nullptr, id_out, 0, nullptr, ctx->stream));
     return THK_OK;
 }
 extern "C" int thk_embed_f16(thk_ctx* ctx, const void* table, int64_t E, int32_t token, float* x) {
@@ -527,8 +547,8 @@ extern "C" int thk_model_create(thk_ctx* ctx, const thk_hparams* hp, int32_t lay
 static void free_seq(SeqBuf& s) {
     if (s.exec) hipGraphExecDestroy(s.exec);
     if (s.graph) hipGraphDestroy(s.graph);
-    if (s.exec_multi) hipGraphExecDestroy(s.exec_multi);
-    if (s.graph_multi) hipGraphDestroy(s.graph_multi);
+    for (int i = 0; i < 3; ++i) { if (s.exec_multi[i]) hipGraphExecDestroy(s.exec_multi[i]); if (s.graph_multi[i]) hipGraphDestroy(s.graph_multi[i]); }
+    hipFree(s.eng_ops);
     hipFree(s.kv); hipFree(s.st); hipFree(s.gen_log); hipFree(s.hidden_in); hipFree(s.hidden_out); hipFree(s.logits); hipFree(s.advance);
     s = SeqBuf();
 }
@@ -537,6 +557,8 @@ static void free_working(thk_model* m) {
     m->seqs.clear();
     hipFree(m->x); hipFree(m->q); hipFree(m->u); hipFree(m->attn_out); hipFree(m->part_o); hipFree(m->part_ml); hipFree(m->block_best); hipFree(m->rope_tab);
     hipFree(m->prefill_ws); hipFree(m->fuse_counters); m->fuse_counters = nullptr; hipFree(m->head_ticket); m->head_ticket = nullptr;
+    hipFree(m->eng_trace); m->eng_trace = nullptr;
+    hipFree(m->eng_gran); m->eng_gran = nullptr; hipFree(m->eng_words); m->eng_words = nullptr; m->engine = 0;
     m->x = m->q = m->u = m->attn_out = m->part_o = m->part_ml = nullptr; m->block_best = nullptr; m->rope_tab = nullptr;
     m->prefill_ws = nullptr; m->prefill_ws_bytes = 0;
     m->finalized = false;
@@ -551,6 +573,20 @@ extern "C" int thk_model_destroy(thk_model* m) {
     delete m;
     return THK_OK;
 }
+// Development aid: copies the engine timeline of the last step ([n_cu][n_ops][8] u64, see thk_engine.hip) to the host.
+extern "C" int thk_model_engine_trace(thk_model* m, unsigned long long* out, int64_t cap_words, int32_t* n_cu, int32_t* n_ops) {
+    if (!m || !out) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized && m->engine && m->eng_trace, "no engine timeline (set the tunable engine_trace=1 before finalize)");
+    const int64_t words = (int64_t)ctx->n_cu * m->seqs[0].eng_n_ops * 8;
+    REQUIRE(ctx, cap_words >= words, "engine timeline needs %lld words", (long long)words);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(out, m->eng_trace, (size_t)words * 8, hipMemcpyDeviceToHost));
+    if (n_cu) *n_cu = ctx->n_cu;
+    if (n_ops) *n_ops = m->seqs[0].eng_n_ops;
+    return THK_OK;
+}
+extern "C" int thk_model_uses_engine(const thk_model* m) { return (m && m->finalized && m->engine) ? 1 : 0; }
 extern "C" int32_t thk_model_n_ff(const thk_model* m) { return m ? m->n_ff : 0; }
 extern "C" int32_t thk_model_n_embd(const thk_model* m) { return m ? m->hp.n_embd : 0; }
 
@@ -659,6 +695,24 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         HIPCHK(ctx, launch_embed(m->tok_embeddings, sb.st, 0, E, m->x, st));
         xin = m->x;
     }
+    if (m->engine) {   // every layer (+ lm-head) of this stage in ONE persistent launch; the program was built at finalize
+        EngArgs a{};
+        a.ops = sb.eng_ops; a.n_ops = sb.eng_n_ops; a.st = sb.st; a.epoch = m->eng_words; a.err = m->eng_words + 32;
+        a.E = E; a.H = H; a.D = D; a.nsplit = m->eng_nsplit; a.tc = m->eng_tc;
+        a.NS = m->eng_NS; a.v0_bytes = m->eng_v0; a.v1_bytes = m->eng_v1;
+        a.rope_tab = m->rope_tab; a.scale = 1.0f / sqrtf((float)D); a.block_best = m->block_best; a.trace = m->eng_trace; a.park = (int)tun(ctx, "engine_park");
+        MARK("engine");
+        HIPCHK(ctx, launch_engine(a, ctx->n_cu, st));
+        if (m->flags & THK_STAGE_HEAD) {
+            MARK("finish_token");
+            HIPCHK(ctx, launch_finish_token(m->block_best, ctx->n_cu, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, T, m->eng_words, st));
+        } else {
+            MARK("advance_pos");
+            HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, T, m->eng_words, st));
+        }
+        MARK(nullptr);
+        return THK_OK;
+    }
     for (int i = 0; i < nl; ++i) {
         const LayerW& L = m->layers[i];
         float* kc = sb.kv + (size_t)i * 2 * T * E;
@@ -729,11 +783,11 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         MARK("norm_lmhead");
         if (m->skip_kernel != 6) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, nt, st));
         MARK("finish_token");
-        if (m->skip_kernel != 6) HIPCHK(ctx, launch_finish_token(m->block_best, m->grid_head, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, st));
-        else HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, st));       // no arg-max keys were written: keep the token
+        if (m->skip_kernel != 6) HIPCHK(ctx, launch_finish_token(m->block_best, m->grid_head, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, T, nullptr, st));
+        else HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, T, nullptr, st));       // no arg-max keys were written: keep the token
     } else {
         MARK("advance_pos");
-        HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, st));
+        HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, T, nullptr, st));
     }
     MARK(nullptr);
     return THK_OK;
@@ -746,6 +800,7 @@ __global__ void set_seq_token_kernel(SeqState* st, int token) {
     if (threadIdx.x == 0 && blockIdx.x == 0) st->token = token;
 }
 static int set_seq_state(thk_model* m, int seq, int token, int pos, bool reset_gen) {
+    m->seqs[seq].pos_host = pos;
     hipLaunchKernelGGL(set_seq_state_kernel, dim3(1), dim3(64), 0, m->ctx->stream, m->seqs[seq].st, token, pos, reset_gen ? 1 : 0);
     HIPCHK(m->ctx, hipGetLastError());
     return THK_OK;
@@ -762,6 +817,35 @@ static int set_advance(thk_model* m, int seq, int advance) {
 static int run_step(thk_model* m, int seq) {
     if (m->use_graph && m->seqs[seq].exec) { HIPCHK(m->ctx, hipGraphLaunch(m->seqs[seq].exec, m->ctx->stream)); return THK_OK; }
     return enqueue_step(m, seq, nullptr);
+}
+
+// ----- persistent engine (thk_engine.hip): eligibility, LDS plan and the per-sequence op program
+static bool engine_plan(thk_model* m) {
+    thk_ctx* ctx = m->ctx;
+    const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, V = m->hp.n_vocab, T = m->hp.n_ctx;
+    if (tun(ctx, "engine") == 0) return false;
+    if (D != 64 && D != 128) return false;
+    if (E % 512 != 0 || F % 256 != 0 || E > 6144 || (V & 1)) return false;            // row pairs, one-sweep norm gather, whole pieces
+    if ((m->flags & THK_STAGE_HEAD) && m->lm_mode != THK_LMHEAD_CORRECT) return false;  // the Q1-faithful combine stays on the launch path
+    if (m->skip_kernel || m->fuse_attn_wo || H > ctx->n_cu) return false;
+    int S = 1;
+    while (S * 2 <= kMaxSplit && S * 2 * H <= ctx->n_cu) S *= 2;
+    const int v1 = ((E + 511) / 512) * 2048, v0 = ((std::max(E, F) + 511) / 512) * 2048;
+    const long budget = 160 * 1024 - (long)engine_lds_bytes(0, v0, v1);
+    const int NS = (int)(budget / kEngSlotBytes);
+    if (NS < 3) return false;
+    m->eng_NS = NS > 8 ? 8 : NS; m->eng_v0 = v0; m->eng_v1 = v1;
+    if (m->flags & THK_STAGE_HEAD) {   // final norm -> lm-head -> greedy keys (th-llama.cpp:240-268, :826-838)
+        EngOp h{};
+        h.kind = EOP_HEAD; h.n_units = V / 2; h.C = E; eng_unit_geometry(h); h.W[0] = m->output; h.gain = m->norm;
+        h.in_src = EIN_GRAN; h.in_ptr = XG0; h.in_n = E; h.in_tag_op = prev_w2; h.in_dst = 1; h.out_plain = sb.logits;
+        ops.push_back(h);
+    }
+    REQUIRE(ctx, ops.size() < 511, "engine program of %zu ops does not fit the 9-bit op tag", ops.size());
+    HIPCHK(ctx, hipMalloc((void**)&sb.eng_ops, ops.size() * sizeof(EngOp)));
+    HIPCHK(ctx, hipMemcpy(sb.eng_ops, ops.data(), ops.size() * sizeof(EngOp), hipMemcpyHostToDevice));
+    sb.eng_n_ops = (int)ops.size();
+    return THK_OK;
 }
 
 extern "C" int thk_model_finalize(thk_model* m) {
@@ -799,7 +883,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
     } while (0)
     ALLOCZ(m->x, E * 4); ALLOCZ(m->q, E * 4); ALLOCZ(m->u, F * 4); ALLOCZ(m->attn_out, E * 4);
     ALLOCZ(m->part_o, H * kMaxSplit * D * 4); ALLOCZ(m->part_ml, H * kMaxSplit * 2 * 4);
-    ALLOCZ(m->block_best, (size_t)(m->grid_head > 0 ? m->grid_head : 1) * 8 + 4096);
+    ALLOCZ(m->block_best, (size_t)std::max(m->grid_head > 0 ? m->grid_head : 1, ctx->n_cu) * 8 + 4096);
     ALLOCZ(m->rope_tab, T * (D / 2) * 2 * 4);
     ALLOCZ(m->fuse_counters, ((size_t)nl * kFuseStride + 32) * 4);
     ALLOCZ(m->head_ticket, (size_t)H * 4);
@@ -816,6 +900,18 @@ extern "C" int thk_model_finalize(thk_model* m) {
         ALLOCZ(s.hidden_in, E * 4); ALLOCZ(s.hidden_out, E * 4); ALLOCZ(s.advance, 4);
         if (m->flags & THK_STAGE_HEAD) ALLOCZ(s.logits, V * 4);
         s.advance_host = 0;
+    }
+    m->engine = engine_plan(m) ? 1 : 0;
+    if (m->engine) {
+        const size_t ngran = 2 * E + 3 * E + E + F + H * (size_t)m->eng_nsplit * (D + 2);
+        ALLOCZ(m->eng_gran, ngran * 8);
+        ALLOCZ(m->eng_words, 64 * 4);
+        HIPCHK(ctx, hipMemsetAsync(m->eng_words, 0, 4, ctx->stream));
+        unsigned one = 1;                                   // epoch 0 would make a zero-filled granule look valid for op tag 0
+        HIPCHK(ctx, hipMemcpyAsync(m->eng_words, &one, 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto& sq : m->seqs) { int rc_ = engine_build_program(m, sq); if (rc_ != THK_OK) return rc_; }
+        if (tun(ctx, "engine_trace") != 0) ALLOCZ(m->eng_trace, (size_t)ctx->n_cu * m->seqs[0].eng_n_ops * 8 * 8);
     }
 #undef ALLOCZ
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -841,6 +937,15 @@ extern "C" int thk_model_finalize(thk_model* m) {
 
 // Bounded in-launch waits raise a device-side error word instead of hanging; surface it.
 static int check_fuse_error(thk_model* m) {
+    if (m->engine && m->eng_words) {
+        unsigned e = 0;
+        HIPCHK(m->ctx, hipMemcpyAsync(&e, m->eng_words + 32, 4, hipMemcpyDeviceToHost, m->ctx->stream));
+        HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
+        if (e) {
+            HIPCHK(m->ctx, hipMemsetAsync(m->eng_words + 32, 0, 4, m->ctx->stream));
+            return fail(m->ctx, THK_ERR_STATE, "decode engine: bounded wait timed out (code %u, op %u, workgroup %u)", (e >> 24) & 0x7f, (e >> 12) & 0xfff, e & 0xfff);
+        }
+    }
     if (!m->fuse_counters || !m->fuse_attn_wo) return THK_OK;   // only the fused experiment has in-launch waits
     unsigned e = 0;
     const int nl = m->l1 - m->l0;
@@ -858,6 +963,7 @@ extern "C" int thk_model_reset_kv(thk_model* m, int32_t seq) {
     const size_t bytes = (size_t)(m->l1 - m->l0) * 2 * m->hp.n_ctx * m->hp.n_embd * 4;
     HIPCHK(ctx, hipMemsetAsync(m->seqs[seq].kv, 0, bytes, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(m->seqs[seq].st, 0, sizeof(SeqState), ctx->stream));
+    m->seqs[seq].pos_host = 0;
     return THK_OK;
 }
 
@@ -905,31 +1011,70 @@ extern "C" int thk_model_seq_set_token(thk_model* m, int32_t seq, int32_t token)
     HIPCHK(m->ctx, hipGetLastError());
     return THK_OK;
 }
+// A step at position p evaluates T = p + 1 <= n_ctx cache rows and writes row p; an advancing step leaves p + 1.  The
+// host mirrors the device position exactly (every change goes through this API), so running past the context is
+// refused here instead of corrupting the caches (the device-side clamp in finish_token / advance_pos is the backstop).
+static int check_room(thk_model* m, int seq, int n_steps, int advance) {
+    const SeqBuf& sb = m->seqs[seq];
+    const int last = sb.pos_host + (advance ? n_steps - 1 : 0);
+    REQUIRE(m->ctx, n_steps <= 0 || last < m->hp.n_ctx, "sequence %d is at position %d: %d %s step(s) would run past n_ctx=%d (thk_model_seq_set / thk_model_reset_kv first)",
+            seq, sb.pos_host, n_steps, advance ? "advancing" : "hold-position", m->hp.n_ctx);
+    return THK_OK;
+}
+static int ensure_multi_graph(thk_model* m, int seq, int idx) {
+    thk_ctx* ctx = m->ctx;
+    SeqBuf& sb = m->seqs[seq];
+    if (sb.exec_multi[idx]) return THK_OK;
+    int rc = THK_OK;
+    HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    for (int k = 0; k < kMultiSteps[idx] && rc == THK_OK; ++k) rc = enqueue_step(m, seq, nullptr);
+    hipError_t e = hipStreamEndCapture(ctx->stream, &sb.graph_multi[idx]);
+    if (rc != THK_OK) return rc;
+    if (e != hipSuccess) return fail(ctx, THK_ERR_HIP, "hipStreamEndCapture (%d-step graph): %s", kMultiSteps[idx], hipGetErrorString(e));
+    HIPCHK(ctx, hipGraphInstantiate(&sb.exec_multi[idx], sb.graph_multi[idx], nullptr, nullptr, 0));
+    return THK_OK;
+}
 extern "C" int thk_model_decode_step(thk_model* m, int32_t seq, int advance) {
     if (!m) return THK_ERR_INVALID;
     REQUIRE(m->ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
-    int rc = set_advance(m, seq, advance);
+    int rc = check_room(m, seq, 1, advance);
     if (rc != THK_OK) return rc;
-    return run_step(m, seq);
+    rc = set_advance(m, seq, advance);
+    if (rc != THK_OK) return rc;
+    rc = run_step(m, seq);
+    if (rc == THK_OK && advance) m->seqs[seq].pos_host += 1;
+    return rc;
+}
+// Capture (without running) every multi-step graph thk_model_decode_steps(n_steps) will replay, so that the first
+// timed call does not pay for stream capture + hipGraphInstantiate (several ms for 8 x 161 nodes).
+extern "C" int thk_model_prepare_steps(thk_model* m, int32_t seq, int32_t n_steps) {
+    if (!m) return THK_ERR_INVALID;
+    REQUIRE(m->ctx, m->finalized && seq >= 0 && seq < m->n_seq && n_steps >= 0, "bad sequence %d / step count %d (or model not finalized)", seq, n_steps);
+    if (!m->use_graph) return THK_OK;
+    int left = n_steps;
+    for (int idx = 2; idx >= 0; --idx)
+        if (left >= kMultiSteps[idx]) { int rc = ensure_multi_graph(m, seq, idx); if (rc != THK_OK) return rc; left %= kMultiSteps[idx]; }
+    return THK_OK;
 }
 extern "C" int thk_model_decode_steps(thk_model* m, int32_t seq, int32_t n_steps, int advance) {
     if (!m) return THK_ERR_INVALID;
     thk_ctx* ctx = m->ctx;
     REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq && n_steps >= 0, "bad sequence %d / step count %d (or model not finalized)", seq, n_steps);
-    int rc = set_advance(m, seq, advance);
+    int rc = check_room(m, seq, n_steps, advance);
+    if (rc != THK_OK) return rc;
+    rc = set_advance(m, seq, advance);
     if (rc != THK_OK) return rc;
     SeqBuf& sb = m->seqs[seq];
-    if (m->use_graph && n_steps >= kMultiStep && !sb.exec_multi) {       // capture kMultiStep steps once
-        HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        for (int k = 0; k < kMultiStep && rc == THK_OK; ++k) rc = enqueue_step(m, seq, nullptr);
-        hipError_t e = hipStreamEndCapture(ctx->stream, &sb.graph_multi);
-        if (rc != THK_OK) return rc;
-        if (e != hipSuccess) return fail(ctx, THK_ERR_HIP, "hipStreamEndCapture (multi-step): %s", hipGetErrorString(e));
-        HIPCHK(ctx, hipGraphInstantiate(&sb.exec_multi, sb.graph_multi, nullptr, nullptr, 0));
-    }
     int left = n_steps;
-    while (m->use_graph && sb.exec_multi && left >= kMultiStep) { HIPCHK(ctx, hipGraphLaunch(sb.exec_multi, ctx->stream)); left -= kMultiStep; }
+    if (m->use_graph)
+        for (int idx = 2; idx >= 0; --idx)          // 8-, 4-, 2-step graphs, then single steps: 20 = 8 + 8 + 4
+            while (left >= kMultiSteps[idx]) {
+                if ((rc = ensure_multi_graph(m, seq, idx)) != THK_OK) return rc;
+                HIPCHK(ctx, hipGraphLaunch(sb.exec_multi[idx], ctx->stream));
+                left -= kMultiSteps[idx];
+            }
     while (left-- > 0) { rc = run_step(m, seq); if (rc != THK_OK) return rc; }
+    if (advance) sb.pos_host += n_steps;
     return THK_OK;
 }
 extern "C" void* thk_model_hidden_in(thk_model* m, int32_t seq) { return (m && m->finalized && seq >= 0 && seq < m->n_seq) ? m->seqs[seq].hidden_in : nullptr; }

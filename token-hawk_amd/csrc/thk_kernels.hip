@@ -546,11 +546,17 @@ static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_
     const size_t smem = (size_t)ns * 512 * 4 + 128;
     (void)nt;   // weights always stream with non-temporal loads (default-policy loads measured 8 % slower)
     auto kn = gemv_kernel<NR, U, NS, PRO, EPI, true, NSP>;
-    static size_t attr_set[2] = {0, 0};   // per instantiation; first call happens outside graph capture
-    if (smem > 48 * 1024 && smem > attr_set[nt ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static size_t attr_set[kMaxDevices] = {};   // per instantiation AND per device; first call happens outside graph capture
+    if (smem > 48 * 1024) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        attr_set[nt ? 1 : 0] = smem;
+        if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+        if (smem > attr_set[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            attr_set[dev] = smem;
+        }
     }
     hipLaunchKernelGGL(kn, dim3(grid), dim3(kBlock), smem, st, a);
     return hipGetLastError();
@@ -821,11 +827,17 @@ static hipError_t launch_attn_wo_k(const AttnArgs& t, const GemvArgs& g, int gri
     const size_t smem = (size_t)ns * 512 * 4 + 128;
     (void)nt;
     auto kn = attn_wo_kernel<D, NR, U, NS, NSP, true>;
-    static size_t attr_set[2] = {0, 0};
-    if (smem > 48 * 1024 && smem > attr_set[nt ? 1 : 0]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    static size_t attr_set[kMaxDevices] = {};
+    if (smem > 48 * 1024) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        attr_set[nt ? 1 : 0] = smem;
+        if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+        if (smem > attr_set[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            attr_set[dev] = smem;
+        }
     }
     hipLaunchKernelGGL(kn, dim3(t.H * t.nsplit + grid_wo), dim3(kBlock), smem, st, t, g);
     return hipGetLastError();
@@ -1004,9 +1016,12 @@ hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token
 // Greedy pick + sequence bookkeeping after the head kernel: reduce the per-block
 // best keys, write the token (first max wins, th-llama.cpp:826-838), log it,
 // advance the position when asked.
+// n_ctx > 0: the position only advances while pos + 1 < n_ctx, so a decode loop that outruns the host-side check
+// (thk_model_decode_step(s) refuse it) can never index the caches or the RoPE table out of bounds.
+// epoch != NULL: the engine's tag epoch is bumped here, i.e. after the engine launch of this step and before the next.
 __global__ __launch_bounds__(kBlock) void finish_token_kernel(const unsigned long long* __restrict__ block_best, int nblocks,
                                                               SeqState* st, int32_t* gen_log, int log_cap,
-                                                              const int* advance_ptr, int32_t* id_out) {
+                                                              const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch) {
     __shared__ unsigned long long sm[kBlock];
     unsigned long long b = 0ull;
     for (int i = threadIdx.x; i < nblocks; i += kBlock) { const unsigned long long k = block_best[i]; b = k > b ? k : b; }
@@ -1023,21 +1038,25 @@ __global__ __launch_bounds__(kBlock) void finish_token_kernel(const unsigned lon
             st->token = tok;
             if (gen_log && st->n_gen < log_cap) gen_log[st->n_gen] = tok;
             st->n_gen += 1;
-            if (advance_ptr && *advance_ptr) st->pos += 1;
+            if (advance_ptr && *advance_ptr && (n_ctx <= 0 || st->pos + 1 < n_ctx)) st->pos += 1;
         }
+        if (epoch) *epoch += 1u;
     }
 }
 hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
-                               const int* advance_ptr, int32_t* id_out, hipStream_t st) {
-    hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(kBlock), 0, st, block_best, nblocks, st_dev, gen_log, log_cap, advance_ptr, id_out);
+                               const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st) {
+    hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(kBlock), 0, st, block_best, nblocks, st_dev, gen_log, log_cap, advance_ptr, id_out, n_ctx, epoch);
     return hipGetLastError();
 }
-// Non-head stages only advance the position.
-__global__ void advance_pos_kernel(SeqState* st, const int* advance_ptr) {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && *advance_ptr) st->pos += 1;
+// Non-head stages only advance the position (same clamp, same epoch bump).
+__global__ void advance_pos_kernel(SeqState* st, const int* advance_ptr, int n_ctx, unsigned* epoch) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (*advance_ptr && (n_ctx <= 0 || st->pos + 1 < n_ctx)) st->pos += 1;
+        if (epoch) *epoch += 1u;
+    }
 }
-hipError_t launch_advance_pos(SeqState* st_dev, const int* advance_ptr, hipStream_t st) {
-    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, st, st_dev, advance_ptr);
+hipError_t launch_advance_pos(SeqState* st_dev, const int* advance_ptr, int n_ctx, unsigned* epoch, hipStream_t st) {
+    hipLaunchKernelGGL(advance_pos_kernel, dim3(1), dim3(64), 0, st, st_dev, advance_ptr, n_ctx, epoch);
     return hipGetLastError();
 }
 

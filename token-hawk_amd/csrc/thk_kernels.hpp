@@ -88,11 +88,54 @@ hipError_t launch_kv_append(float* kc, float* vc, const float* k, const float* v
 hipError_t launch_embed_rows(const uint16_t* table, const int32_t* tokens_dev, int n, int E, float* x, hipStream_t st);
 hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token_val, int E, float* x, hipStream_t st);
 hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
-                               const int* advance_ptr, int32_t* id_out, hipStream_t st);
-hipError_t launch_advance_pos(SeqState* st_dev, const int* advance_ptr, hipStream_t st);
+                               const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st);
+hipError_t launch_advance_pos(SeqState* st_dev, const int* advance_ptr, int n_ctx, unsigned* epoch, hipStream_t st);
 hipError_t launch_argmax(const float* logits, int V, unsigned long long* block_best, int nblocks, hipStream_t st);
 hipError_t launch_synth_f16(uint64_t key, float scale, size_t n, void* out, hipStream_t st);
 hipError_t launch_synth_gain(uint64_t key, float scale, size_t n, float* out, hipStream_t st);
+
+// ---------------------------------------------------------------- thk_engine.hip: persistent loader/consumer decode engine
+constexpr int kMaxDevices = 64;
+constexpr int kEngSlotBytes = 16384;      // one ring slot = one fill = up to 16 pieces of 1 KiB (64 lanes x 16 B)
+enum { EOP_QKV = 0, EOP_ATTN = 1, EOP_WO = 2, EOP_W13 = 3, EOP_W2 = 4, EOP_HEAD = 5 };
+enum { EIN_GRAN = 0, EIN_PLAIN = 1 };
+// One op of the engine's program (device array, immutable after finalize).  A "unit" is what one consumer wave turns
+// into finished outputs: two weight rows (a row pair of one matrix, or row g of w1 and row g of w3 when dual).
+struct EngOp {
+    int kind;                 // EOP_*
+    int n_units;              // units of the op; CU c takes units c, c + n_cu, ...
+    int fpu;                  // fills (ring slots) per unit
+    int pieces_last;          // 1 KiB pieces in the unit's last fill (the others carry 16)
+    int C;                    // input features (length of the activation vector)
+    int row_bytes;            // C * 2
+    int dual;                 // unit = row u of W[0] followed by row u of W[1]
+    int in_src;               // EIN_GRAN: 8-byte {value, tag} granules published by op in_tag_op; EIN_PLAIN: f32 written before the launch
+    const uint16_t* W[3];
+    const float* gain;        // non-null: RMSNorm * gain applied while the input is gathered
+    const void* in_ptr;
+    int in_n;                 // elements of the input vector (multiple of 64, >= 192)
+    int in_tag_op;
+    int in_dst;               // LDS vector 0 (large) or 1
+    int resid_src;            // 0 none, 1 granules, 2 plain f32 (element 2u, 2u+1 for unit u)
+    const void* resid_ptr;
+    unsigned long long* out_g;   // granules out (QKV: [3E] q | k_new | v_new; ATTN: attention output [E])
+    float* out_plain;         // optional f32 copy of the outputs (hidden state for the host / next stage, logits)
+    float* kcache; float* vcache;                 // QKV (append) and ATTN (read): this layer's f32 [n_ctx, H, D] caches
+    const unsigned long long* qg;                 // ATTN: the QKV op's granules
+    unsigned long long* pg;                       // ATTN: split partials [H, nsplit, D + 2]
+};
+struct EngArgs {
+    const EngOp* ops; int n_ops;
+    const SeqState* st; const unsigned* epoch; unsigned* err;
+    int E, H, D, nsplit, tc;
+    int NS, v0_bytes, v1_bytes;                   // LDS plan: ring slots, bytes of activation vectors 0 and 1
+    const float* rope_tab; float scale;
+    unsigned long long* block_best;               // HEAD: one arg-max key per workgroup
+    unsigned long long* trace;                    // development timeline (NULL in production), see thk_engine.hip
+    int park;                                     // kernel variant: consumer waves park one landed slot in registers while they wait
+};
+size_t engine_lds_bytes(int NS, int v0_bytes, int v1_bytes);
+hipError_t launch_engine(const EngArgs& a, int n_cu, hipStream_t st);
 
 // thk_prefill.hip
 hipError_t launch_gemm_f16_prefill(const uint16_t* W, int R, int C, const float* X, int M, float* Y, void* workspace, hipStream_t st);

@@ -37,7 +37,7 @@ __device__ __forceinline__ float wave_sum_prefill(float v) {
 }
 
 constexpr int kKC = 32;                  // K columns per LDS stage (2 MFMA k-steps)
-constexpr int kMaxDevices = 64;
+
 static int current_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < kMaxDevices ? d : 0; }
 
 // ---------------------------------------------------------------- LDS-DMA pipeline, stream-K
