@@ -834,7 +834,54 @@ static bool engine_plan(thk_model* m) {
     const long budget = 160 * 1024 - (long)engine_lds_bytes(0, v0, v1);
     const int NS = (int)(budget / kEngSlotBytes);
     if (NS < 3) return false;
-    m->eng_NS = NS > 8 ? 8 : NS; m->eng_v0 = v0; m->eng_v1 = v1;
+    m->eng_NS = NS > 8 ? 8 : NS; m->eng_v0 = v0; m->eng_v1 = v1; m->eng_nsplit = S; m->eng_tc = (T + S - 1) / S;
+    return true;
+}
+static void eng_unit_geometry(EngOp& o) {       // a unit = two rows of C f16 = 4C bytes = C/256 pieces of 1 KiB
+    o.row_bytes = o.C * 2;
+    const int pieces = o.C / 256;
+    o.fpu = (pieces + 15) / 16;
+    o.pieces_last = pieces - 16 * (o.fpu - 1);
+}
+static int engine_build_program(thk_model* m, SeqBuf& sb) {
+    thk_ctx* ctx = m->ctx;
+    const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, V = m->hp.n_vocab, T = m->hp.n_ctx, S = m->eng_nsplit;
+    const int nl = m->l1 - m->l0;
+    unsigned long long* XG0 = m->eng_gran; unsigned long long* XG1 = XG0 + E; unsigned long long* QG = XG1 + E;
+    unsigned long long* OG = QG + 3 * (size_t)E; unsigned long long* UG = OG + E; unsigned long long* PG = UG + F;
+    (void)H; (void)S; (void)D;
+    const float* xin = (m->flags & THK_STAGE_EMBED) ? m->x : sb.hidden_in;
+    std::vector<EngOp> ops;
+    int prev_w2 = -1;
+    for (int i = 0; i < nl; ++i) {
+        const LayerW& L = m->layers[i];
+        float* kc = sb.kv + (size_t)i * 2 * T * E;
+        float* vc = kc + (size_t)T * E;
+        EngOp q{};    // rms_norm*gain -> wq,wk,wv -> RoPE -> K/V append (th-llama.cpp:299-339)
+        q.kind = EOP_QKV; q.n_units = 3 * E / 2; q.C = E; eng_unit_geometry(q);
+        q.W[0] = L.wq; q.W[1] = L.wk; q.W[2] = L.wv; q.gain = L.attention_norm;
+        q.in_src = i == 0 ? EIN_PLAIN : EIN_GRAN; q.in_ptr = i == 0 ? (const void*)xin : (const void*)XG0; q.in_n = E; q.in_tag_op = prev_w2; q.in_dst = 1;
+        q.out_g = QG; q.kcache = kc; q.vcache = vc;
+        const int iq = (int)ops.size(); ops.push_back(q);
+        EngOp at{};   // attention over the cache in place (th-llama.cpp:341-397)
+        at.kind = EOP_ATTN; at.in_tag_op = iq; at.qg = QG; at.pg = PG; at.out_g = OG; at.kcache = kc; at.vcache = vc;
+        const int ia = (int)ops.size(); ops.push_back(at);
+        EngOp o{};    // wo -> + residual (th-llama.cpp:401-413)
+        o.kind = EOP_WO; o.n_units = E / 2; o.C = E; eng_unit_geometry(o); o.W[0] = L.wo;
+        o.in_src = EIN_GRAN; o.in_ptr = OG; o.in_n = E; o.in_tag_op = ia; o.in_dst = 0;
+        o.resid_src = i == 0 ? 2 : 1; o.resid_ptr = i == 0 ? (const void*)xin : (const void*)XG0; o.out_g = XG1;
+        const int io = (int)ops.size(); ops.push_back(o);
+        EngOp g{};    // rms_norm*gain -> w1,w3 -> silu*gate (th-llama.cpp:415-438)
+        g.kind = EOP_W13; g.n_units = F; g.C = E; eng_unit_geometry(g); g.dual = (g.row_bytes % 4096 == 0) ? 1 : 2; g.W[0] = L.w1; g.W[1] = L.w3; g.gain = L.ffn_norm;
+        g.in_src = EIN_GRAN; g.in_ptr = XG1; g.in_n = E; g.in_tag_op = io; g.in_dst = 1; g.out_g = UG;
+        const int ig = (int)ops.size(); ops.push_back(g);
+        EngOp d{};    // w2 -> + residual (th-llama.cpp:440-451)
+        d.kind = EOP_W2; d.n_units = E / 2; d.C = F; eng_unit_geometry(d); d.W[0] = L.w2;
+        d.in_src = EIN_GRAN; d.in_ptr = UG; d.in_n = F; d.in_tag_op = ig; d.in_dst = 0;
+        d.resid_src = 1; d.resid_ptr = XG1; d.out_g = XG0;
+        if (i == nl - 1) d.out_plain = (m->flags & THK_STAGE_HEAD) ? m->x : sb.hidden_out;
+        prev_w2 = (int)ops.size(); ops.push_back(d);
+    }
     if (m->flags & THK_STAGE_HEAD) {   // final norm -> lm-head -> greedy keys (th-llama.cpp:240-268, :826-838)
         EngOp h{};
         h.kind = EOP_HEAD; h.n_units = V / 2; h.C = E; eng_unit_geometry(h); h.W[0] = m->output; h.gain = m->norm;
