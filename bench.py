@@ -51,7 +51,36 @@ def parse():
                    help="run the N>1 code path (process group, HipStage, ring driver with a self send/recv) even with one rank; plumbing check")
     p.add_argument("--transport", default="native", choices=["torch", "native"],
                    help="N>1 hidden-state hand-off: torch.distributed P2P ops (backend nccl = RCCL) or libthk's thk_pp_* (RCCL directly)")
+    p.add_argument("--cpu-baseline-layers", type=int, default=0,
+                   help="layers of the CPU baseline model (0 = the full model when host RAM allows, else a 4-layer sample scaled up and labelled so)")
+    p.add_argument("--master-port", type=int, default=29533, help="rendezvous port when bench.py launches its own ranks (--gpus N without torchrun)")
     return p.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without torchrun: start N ranks (one per GPU) under torch.distributed.run and relay
+    rank 0's single JSON line.  Refuses (exit 2) when fewer than N GPUs are visible instead of silently measuring one."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < args.gpus:
+        log(f"[bench] ERROR: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to run on fewer ranks")
+        return 2
+    cmd = launch_command(args.gpus, args.master_port, sys.argv[1:])
+    log("[bench] launching: " + " ".join(cmd))
+    return subprocess.call(cmd, env=launch_env(os.environ))
+
+
+def launch_command(n, port, argv):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_env(base):
+    env = dict(base)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # RCCL needs dmabuf IPC on this host driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    return env
 
 
 def model_shape(thk, name):
@@ -64,17 +93,26 @@ def synthetic_prompt(shape, T, seq):
     return np.concatenate([[1], rng.integers(3, shape.n_vocab, T - 1)]).astype(np.int32)
 
 
-def cpu_baseline(shape_name, T):
-    """Oracle fast flavour (AVX2/F16C + OpenMP) on a bounded sample of the same workload."""
+def cpu_baseline(shape_name, T, layers=0):
+    """Oracle fast flavour (AVX2/F16C + OpenMP) on this box's host cores: the FULL model for 16 decode steps at context T
+    when host RAM allows, otherwise a 4-layer sample scaled to the layer count and labelled so."""
     from oracle import oracle as orc
     oshape = {"7b": orc.LLAMA_7B, "13b": orc.LLAMA_13B, "tiny": orc.TINY}[shape_name]
-    n_sample = min(4, oshape.n_layer)
+    E, Fd, V = oshape.n_embd, oshape.n_ff, oshape.n_vocab
+    full_bytes = oshape.n_layer * (4 * E * E + 3 * E * Fd) * 2 + 2 * V * E * 2 + oshape.n_layer * 2 * oshape.n_ctx * E * 4
+    try:
+        avail = [int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]
+    except Exception:
+        avail = 0
+    n_sample = layers if layers > 0 else (oshape.n_layer if avail > full_bytes * 1.3 else min(4, oshape.n_layer))
+    n_sample = min(n_sample, oshape.n_layer)
+    full = n_sample == oshape.n_layer
     sample_shape = orc.ModelShape(oshape.n_vocab, oshape.n_embd, oshape.n_mult, oshape.n_head, n_sample, oshape.n_ctx)
     t0 = time.time()
     orc.set_num_threads(orc.usable_cpus())          # all usable host cores (affinity mask / cgroup quota aware)
     m = orc.OracleModel(sample_shape)
     m.fill_synthetic()
-    steps = 3
+    steps = 16 if full else 3
     m.time_decode(min(T, oshape.n_ctx) - 1, n_sample, 1)                       # touch pages
     tl, th = m.time_decode(min(T, oshape.n_ctx) - 1, n_sample, steps)
     m.close()
@@ -83,9 +121,12 @@ def cpu_baseline(shape_name, T):
         cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         cpu_model = "unknown"
+    what = (f"FULL model ({oshape.n_layer} layers + lm-head), {steps} decode steps at T={T}" if full else
+            f"SAMPLED: {n_sample} of {oshape.n_layer} layers + lm-head, {steps} decode steps at T={T}, layer time x{oshape.n_layer / n_sample:g} "
+            f"(host RAM {avail / 2**30:.0f} GiB < model)")
     return {"value": round(1.0 / per_tok, 3), "unit": "tokens/s", "cores": orc.num_threads(), "kind": "port",
-            "sample": f"{n_sample} of {oshape.n_layer} layers + lm-head, {steps} decode steps at T={T}, layer time x{oshape.n_layer // n_sample}; "
-                      f"oracle fast flavour (AVX2+F16C, OpenMP); llama.cpp unavailable; cpu='{cpu_model}'; setup {time.time() - t0:.1f}s"}
+            "sample": f"{what}; oracle fast flavour (AVX2+F16C, OpenMP) on all usable host cores; llama.cpp unavailable; "
+                      f"cpu='{cpu_model}'; setup+run {time.time() - t0:.1f}s"}
 
 
 def kernel_profile(model, shape, T, n_steps=6):
@@ -119,6 +160,7 @@ SKIP_IDS = {"norm_qkv_rope_kv": 1, "attn_decode": 2, "attn_wo_resid": 3, "norm_w
 
 def marginal_kernel_us(thk, ctx, shape, T, skip_id, launches_per_step, full_ms_per_step, steps, warmup, stream, torch):
     """Average duration of one kernel inside the replayed graph = (full step - step without it) / launches per step."""
+    os.environ["THK_MEASURE_HOOKS"] = "1"          # the skip hook is refused without it (never set in a product)
     ctx.set_tunable("measure_skip_kernel", skip_id)
     try:
         m2 = thk.Model(ctx, shape, n_seq=1)
@@ -128,6 +170,7 @@ def marginal_kernel_us(thk, ctx, shape, T, skip_id, launches_per_step, full_ms_p
         ctx.set_tunable("measure_skip_kernel", 0)
     try:
         m2.seq_set(0, 5, T - 1)            # KV contents do not matter for timing (same bytes are read)
+        m2.prepare_steps(steps); m2.prepare_steps(warmup)
         m2.decode_steps(warmup, 0, advance=False)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -149,11 +192,15 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        os.dup2(json_fd, 1)                      # the children print the JSON line themselves
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
+        log(f"[bench] ERROR: WORLD_SIZE={world} but --gpus {args.gpus}: launch exactly --gpus ranks (or run `python bench.py --gpus N` and let it launch them)")
+        sys.exit(2)
     N = world
     PIPE = N > 1 or args.force_pipeline          # pipeline driver path
     if not os.path.exists(graft.LIB):          # the prebuilt .so travels with the tree; never rebuild concurrently from N ranks
@@ -167,6 +214,9 @@ def main():
     T = min(args.ctx, shape.n_ctx)
 
     import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        log(f"[bench r{rank}] ERROR: no GPU for local rank {local_rank} ({torch.cuda.device_count() if torch.cuda.is_available() else 0} visible)")
+        sys.exit(2)
     dist = None
     if PIPE:
         import torch.distributed as dist
@@ -253,10 +303,12 @@ def main():
 
         def run_steps(k):
             if not PIPE:
-                model.decode_steps(k, 0, advance=False)       # multi-step graph replays (8 steps per launch)
+                model.decode_steps(k, 0, advance=False)       # replays of captured 8/4/2/1-step graphs (20 = 8 + 8 + 4)
             else:
                 drv.run(k, advance=False)
 
+        if not PIPE:                                         # capture every multi-step graph the two calls below replay, outside the timed region
+            model.prepare_steps(args.warmup); model.prepare_steps(args.steps)
         run_steps(args.warmup)
         if dist is not None:
             dist.barrier()
@@ -279,11 +331,27 @@ def main():
         tokens = args.steps * S
         value = tokens / elapsed
         ms_per_step = elapsed / args.steps * 1e3
+        joined = 1
+        stage_ms = None
+        if dist is not None:
+            one = torch.ones(1, device=dev, dtype=torch.int32)
+            dist.all_reduce(one)                                   # ranks that really took part in the timed region
+            joined = int(one.item())
+            # this stage alone (no hand-off), for the ideal-pipeline and pure-replica bounds reported next to the measurement
+            torch.cuda.synchronize(dev)
+            ts0 = time.perf_counter()
+            for _ in range(8):
+                stage.step(0, False)
+            torch.cuda.synchronize(dev)
+            st_ms = torch.tensor([(time.perf_counter() - ts0) / 8 * 1e3], device=dev, dtype=torch.float64)
+            allst = [torch.zeros_like(st_ms) for _ in range(N)]
+            dist.all_gather(allst, st_ms)
+            stage_ms = [round(float(t.item()), 4) for t in allst]
         b_tok = shape.bytes_per_token(T)                       # whole-model algorithmic bytes per token
         step_gbs = b_tok * value / 1e9 / N                     # per-GPU achieved GB/s over the whole step
         result = {
             "metric": "decode tokens/sec, LLaMA-7B f16, 512-ctx, 1/2/4/8 MI355X; % HBM roofline",
-            "value": round(value, 2), "unit": "tokens/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 2), "unit": "tokens/s", "n_gpus": N, "ranks_joined": joined, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (seeded Irwin-Hall~N(0,0.02^2) f16 weights, seeded prompt ids)",
@@ -291,11 +359,21 @@ def main():
                                    f"{'1 sequence' if N == 1 else f'{S} sequences in flight, layers pipelined over {N} GPUs (RCCL p2p)'}",
                        "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single", "transport": args.transport if PIPE else None,
                        "lmhead_mode": args.lmhead, "numerics": "f16 GGML weights x f32 activations, f32 accumulate, f32 KV cache (as the reference)",
-                       "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "attn_waves", "use_graph")}},
+                       "decode_path": "persistent engine (1 launch/step)" if model.uses_engine() else "5 fused launches per layer, hipGraph replay (8/4/2/1-step graphs)",
+                       "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "attn_waves", "use_graph", "engine")}},
             "bytes_per_token": b_tok,
             "step_roofline": {"achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                               "frac_of_copy_rate": round(step_gbs / COPY_RATE_GBS, 4), "event_ms_per_step": round(ev_ms / args.steps, 4)},
         }
+        if PIPE:
+            # A token of ONE sequence crosses all N stages in series: its latency is a full ring revolution = one step of the
+            # schedule above, so a lone stream would decode at 1/ms_per_step however many GPUs there are.
+            result["single_stream"] = {"latency_ms_per_token": round(ms_per_step, 4), "tokens_per_s": round(1e3 / ms_per_step, 2),
+                                       "note": "one ring revolution (N stage visits + N hand-offs); the aggregate needs >= N sequences in flight"}
+            if stage_ms:
+                result["stage_ms_no_handoff"] = stage_ms
+                result["ideal_pipeline_tokens_per_s"] = round(1e3 / max(stage_ms), 2)          # every stage busy, zero hand-off cost
+                result["pure_replica_upper_bound_tokens_per_s"] = round(N * 1e3 / sum(stage_ms), 2)   # N independent full models, no communication
         if rank == 0:
             gen, ngen, pos = (model.seq_get(0) if not PIPE else ([], 0, 0))
             if not PIPE:
@@ -311,15 +389,18 @@ def main():
                          "avg_us": kp[dom]["avg_us"], "alg_bytes_per_launch": kp[dom]["alg_bytes"],
                          "frac_of_copy_rate": round(kp[dom]["gbs"] / COPY_RATE_GBS, 4)})
             roof["timing"] = "HIP events around eager launches on the libthk stream (includes the ~1.5-2.5 us launch gap)"
+            builder = {}
             for key, fname in (("traffic", "pmc_traffic.json"), ("rocprof_avg_us", "kernel_durations.json")):
-                path = os.path.join(ROOT, "profiles", fname)     # committed rocprofv3 summaries of this same command
+                path = os.path.join(ROOT, "profiles", fname)     # committed rocprofv3 summaries of this same command (builder's box, not this run)
                 if os.path.exists(path) and args.model == "7b" and T == 512:   # the summaries are of the default workload only
                     try:
-                        roof[key] = json.load(open(path)).get(dom)
+                        builder[key] = json.load(open(path)).get(dom)
                     except Exception:
                         pass
-            if roof.get("rocprof_avg_us"):
-                roof["rocprof_frac"] = round(kp[dom]["alg_bytes"] / (roof["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            if builder.get("rocprof_avg_us"):
+                builder["rocprof_frac"] = round(kp[dom]["alg_bytes"] / (builder["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            roof["traffic"] = builder.get("traffic")             # PMC HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2, committed summary)
+            roof["builder_box"] = dict(builder, source="profiles/pmc_traffic.json, profiles/kernel_durations.json: rocprofv3 summaries committed by the builder, NOT measured in this run")
             # The eager figure above carries the 2-3 us dispatch gap of un-graphed launches.  What the kernel costs in the
             # configuration that is actually timed (graph replay) is measured as a difference: the same K-step loop, HIP
             # events on the same stream, on a second model instance whose graph omits that kernel.
@@ -341,7 +422,7 @@ def main():
 
         if rank == 0 and N == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(args.model, T)
+                result["cpu_baseline"] = cpu_baseline(args.model, T, args.cpu_baseline_layers)
             except Exception as e:   # the baseline is a report item; never let it kill the GPU number
                 result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if rank == 0:

@@ -1,0 +1,37 @@
+"""CPU tests of bench.py's own launcher: `--gpus N` must start N ranks or fail loudly, never measure
+one GPU and call it N."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_launch_command_and_env_for_world_2():
+    import bench
+    cmd = bench.launch_command(2, 29544, ["--gpus", "2", "--steps", "5"])
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29544"
+    assert cmd[-4:] == ["--gpus", "2", "--steps", "5"] and cmd[-5].endswith("bench.py")
+    env = bench.launch_env({"PATH": "/bin"})
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["MASTER_ADDR"] == "127.0.0.1" and env["PATH"] == "/bin"
+    assert bench.launch_env({"HSA_ENABLE_IPC_MODE_LEGACY": "1"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"   # an explicit setting wins
+
+
+def run_bench(args, env_extra):
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+
+
+def test_world_size_mismatch_is_an_error():
+    r = run_bench(["--gpus", "8", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=1 but --gpus 8" in r.stderr and r.stdout.strip() == ""
+
+
+def test_too_few_gpus_is_an_error_not_a_one_gpu_run():
+    """On a box with fewer than N GPUs (this container has none) `bench.py --gpus 2` exits 2 and prints no JSON line."""
+    r = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""

@@ -407,3 +407,58 @@ def test_prefill_full_width_128_tokens(thk, orc, ctx):
     la, _ = a.eval([77], 128); lb, _ = b.eval([77], 128)
     assert np.abs(la - lb).max() < LOGIT_TOL
     a.close(); b.close()
+
+
+# ------------------------------------------------------------------ position contract / graphs / hooks
+def test_decode_steps_refuse_to_run_past_n_ctx(thk, orc, ctx):
+    """ADVICE r1: an advancing decode loop may not walk off the cache.  The last slot can be evaluated (and advanced from)
+    once; anything further is THK_ERR_INVALID with nothing enqueued, until the sequence is re-positioned."""
+    shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=16)
+    m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    m.seq_set(0, 1, 0)
+    m.decode_steps(16, 0, advance=True)                       # positions 0..15: exactly fills the context
+    gen, n, pos = m.seq_get(0)
+    assert n == 16 and pos == 15                              # the device never advances past n_ctx - 1
+    with pytest.raises(thk.ThkError, match="n_ctx"):
+        m.decode_step(0, advance=True)
+    with pytest.raises(thk.ThkError, match="n_ctx"):
+        m.decode_steps(3, 0, advance=False)
+    _, n2, _ = m.seq_get(0)
+    assert n2 == 16                                           # nothing ran
+    m.seq_set(0, 7, 10)
+    with pytest.raises(thk.ThkError, match="n_ctx"):
+        m.decode_steps(7, 0, advance=True)                    # 10..16 would touch position 16
+    m.decode_steps(6, 0, advance=True)                        # 10..15 is fine
+    _, n3, pos3 = m.seq_get(0)
+    assert n3 == 6 and pos3 == 15
+    m.reset_kv(0)
+    m.decode_step(0, advance=True)                            # usable again after a reset
+    m.close()
+
+
+def test_prepare_steps_only_captures(thk, orc, ctx):
+    """thk_model_prepare_steps builds the 8/4/2-step graphs without running anything; results equal single steps."""
+    a, om = make_pair(thk, orc, ctx, "TINY")
+    b = thk.Model(ctx, thk.TINY); b.fill_synthetic(); b.finalize()
+    a.seq_set(0, 1, 0); b.seq_set(0, 1, 0)
+    a.prepare_steps(15)
+    _, n0, p0 = a.seq_get(0)
+    assert n0 == 0 and p0 == 0
+    a.decode_steps(15, 0, advance=True)                       # 8 + 4 + 2 + 1
+    for _ in range(15):
+        b.decode_step(0, advance=True)
+    ga, na, pa = a.seq_get(0); gb, nb, pb = b.seq_get(0)
+    assert na == nb == 15 and pa == pb == 15 and ga.tolist() == gb.tolist()
+    a.close(); b.close(); om.close()
+
+
+def test_measure_hook_is_refused_without_env(thk, ctx, monkeypatch):
+    """VERDICT r1 #8: the shipped ABI cannot be told to skip work unless the process opted in through the environment."""
+    monkeypatch.delenv("THK_MEASURE_HOOKS", raising=False)
+    with pytest.raises(thk.ThkError, match="THK_MEASURE_HOOKS"):
+        ctx.set_tunable("measure_skip_kernel", 4)
+    assert ctx.get_tunable("measure_skip_kernel") == 0
+    ctx.set_tunable("measure_skip_kernel", 0)                 # clearing is always allowed
+    monkeypatch.setenv("THK_MEASURE_HOOKS", "1")
+    ctx.set_tunable("measure_skip_kernel", 4)
+    ctx.set_tunable("measure_skip_kernel", 0)
