@@ -180,6 +180,9 @@ int32_t thk_model_n_embd(const thk_model* m);
  * (input features), ne1 = rows (1 for 1-D tensors).  Tensors of layers outside the
  * stage (or embeddings/head on a stage without them) are accepted and ignored. */
 int thk_model_set_tensor(thk_model* m, const char* name, int dtype, int64_t ne0, int64_t ne1, const void* host);
+/* Same, payload already on the device (e.g. thk_buf_ptr of a buffer the caller uploaded -- the host layer's TensorBuffer,
+ * th.hpp:83-148): one stream-ordered device-to-device copy; the source may be freed after thk_sync / thk_buf_free. */
+int thk_model_set_tensor_dev(thk_model* m, const char* name, int dtype, int64_t ne0, int64_t ne1, const void* dev_ptr);
 /* Device-side fill of every tensor this stage owns with the synthetic generator. */
 int thk_model_fill_synthetic(thk_model* m, uint64_t seed, float sigma);
 /* Allocates caches/working buffers, builds the RoPE table and captures the

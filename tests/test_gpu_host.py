@@ -20,7 +20,16 @@ def host(thk):
     lib = C.CDLL(os.path.join(ROOT, "token-hawk_amd", "libthk_host.so"))
     lib.thh_last_error.restype = C.c_char_p
     lib.capi_last_error.restype = C.c_char_p
-    lib.capi_on_human_message.restype = C.c_char_p
+    lib.capi_transcript.restype = C.c_char_p
+    lib.capi_on_human_message.restype = None
+    lib.capi_on_human_message.argtypes = [C.c_char_p]
+    lib.capi_model_begin_load.restype = None
+    lib.capi_load_model_header.restype = None
+    lib.capi_load_model_weights.restype = None
+    lib.capi_model_end_load.restype = C.c_bool
+    lib.capi_set_context.argtypes = [C.c_void_p]
+    lib.thh_set_greedy_device_loop.argtypes = [C.c_int64, C.c_int]
+    lib.thh_tensor_buffer_semantics.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     lib.thh_load_file.restype = C.c_int64
     lib.thh_load_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     lib.thh_eval.argtypes = [C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -28,7 +37,7 @@ def host(thk):
     lib.thh_set_sampler.argtypes = [C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float]
     lib.thh_set_prefill.argtypes = [C.c_int64, C.c_int]
     lib.thh_free.argtypes = [C.c_int64]; lib.thh_reset.argtypes = [C.c_int64]; lib.thh_hparams.argtypes = [C.c_int64, C.c_void_p]
-    lib.capi_model_begin_load.argtypes = [C.c_void_p]
+    lib.capi_model_begin_load.argtypes = []
     lib.capi_load_model_header.argtypes = [C.c_char_p, C.c_double]
     lib.capi_load_model_weights.argtypes = [C.c_char_p, C.c_double, C.c_double]
     lib.capi_set_sampler.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
@@ -107,32 +116,92 @@ def test_do_inference_greedy_matches_oracle(host, orc, ctx, model_file):
     host.thh_free(h)
 
 
+UPDATE_FN = C.CFUNCTYPE(None, C.c_char_p, C.c_char_p)
+SEND_FN = C.CFUNCTYPE(None, C.c_char_p, C.c_char_p)
+
+
 def test_streamed_capi_load_matches_file_load(host, orc, ctx, model_file):
-    """capi_model_begin_load / load_model_header / load_model_weights / model_end_load
-    (web/main.cpp:83-157): the file is fed header first, then one tensor record at a time."""
+    """The reference's wasm exports with their own signatures (web/main.cpp:83-179): capi_model_begin_load() /
+    capi_load_model_header(data, size) / capi_load_model_weights(data, offset, size) / bool capi_model_end_load() /
+    void capi_on_human_message(str).  The file is fed header first, then one tensor record at a time; the reply streams
+    through the two UI hooks while capi_on_human_message has already returned (non-blocking, as in the browser)."""
     path, offs, words, scores = model_file
     blob = open(path, "rb").read()
     hp = (C.c_int32 * 7)(); consumed = C.c_int64(); nv = C.c_int32()
     assert host.thh_parse_header(blob, C.c_int64(len(blob)), hp, C.byref(consumed), C.byref(nv)) == 1
-    assert host.capi_model_begin_load(ctx.h) == 1
-    assert host.capi_load_model_header(blob[:consumed.value], float(consumed.value)) == 1
+    updates, bots = [], []
+    upd = UPDATE_FN(lambda mid, text: updates.append((mid, text)))
+    snd = SEND_FN(lambda text, mid: bots.append((text, mid)))
+    host.capi_set_context(ctx.h)
+    host.capi_set_ui_hooks(upd, snd)
+    host.capi_model_begin_load()
+    host.capi_load_model_header(blob[:consumed.value], float(consumed.value))
     pos = consumed.value
     name = C.create_string_buffer(128); ty = C.c_int32(); shape = (C.c_int64 * 4)(); ne = (C.c_int64 * 2)()
     a, b, rb = C.c_int64(), C.c_int64(), C.c_int64()
     while pos < len(blob):
         rec = blob[pos:]
         assert host.thh_parse_tensor(rec, C.c_int64(len(rec)), C.c_int64(pos), name, 128, C.byref(ty), shape, ne, C.byref(a), C.byref(b), C.byref(rb)) == 1
-        assert host.capi_load_model_weights(blob[pos:pos + rb.value], float(pos), float(rb.value)) == 1, host.capi_last_error()
+        host.capi_load_model_weights(blob[pos:pos + rb.value], float(pos), float(rb.value))
         pos += rb.value
-    assert host.capi_model_end_load() == 1, host.capi_last_error()
+    assert host.capi_model_end_load() is True, host.capi_last_error()
     host.capi_set_sampler(40, 0.95, 0.0, 1.1)
-    out = host.capi_on_human_message(b"hello world")
+    host.capi_on_human_message(b"hello world")
+    host.capi_on_human_message(b"ignored: a reply is still being generated")     # web/main.cpp:172
+    host.capi_wait_idle()
+    assert host.capi_inference_complete() == 1
+    out = host.capi_transcript()
     import test_host_cpu as thc
     exp, _ = greedy_reference(orc, words, thc.py_tokenize(words, scores, b" hello world", True))
     assert out == b"".join(words[t] for t in exp)
-    assert host.capi_on_human_message(b"[cmd] reset") == b"context reset"
-    assert host.capi_on_human_message(b"hello world") == out
+    assert bots[0] == (b"--", b"bot-msg-1") and len([x for x in bots if x[0] == b"--"]) == 1       # the second message opened no reply
+    assert len(updates) == len(exp) and updates[-1] == (b"bot-msg-1", out) and all(m == b"bot-msg-1" for m, _ in updates)
+    host.capi_on_human_message(b"[cmd] reset")
+    assert bots[-1][0] == b"LLM context reset."
+    host.capi_on_human_message(b"hello world"); host.capi_wait_idle()
+    assert host.capi_transcript() == out
     host.capi_model_unload()
+    host.capi_set_ui_hooks(None, None)
+
+
+def test_capi_load_failure_is_reported_by_end_load(host, ctx, model_file):
+    """A bad header makes capi_model_end_load return false (the void loaders cannot report it themselves)."""
+    host.capi_set_context(ctx.h)
+    host.capi_model_begin_load()
+    host.capi_load_model_header(b"not a ggjt file at all", 22.0)
+    assert host.capi_model_end_load() is False
+    assert b"magic" in host.capi_last_error()
+    host.capi_model_unload()
+
+
+def test_greedy_device_loop_matches_eval_path(host, ctx, model_file):
+    """with temp <= 0 do_inference generates in the device-resident loop (4-byte token read-backs per 8
+    steps) instead of a 128 KB logits read-back per token: same text, same token count, same final position, with and
+    without prompt prefill."""
+    path, _, words, scores = model_file
+    out = []
+    for loop, prefill in ((0, 0), (1, 0), (1, 1)):
+        h = host.thh_load_file(ctx.h, path.encode(), 0)
+        assert h > 0, host.thh_last_error()
+        host.thh_set_sampler(h, 40, 0.95, 0.0, 1.1)
+        host.thh_set_greedy_device_loop(h, loop); host.thh_set_prefill(h, prefill)
+        n_past = C.c_int32(); text = C.create_string_buffer(1 << 16)
+        n_new = host.thh_do_inference(h, b"the quick brown fox", C.byref(n_past), text, len(text))
+        n2 = host.thh_do_inference(h, b"and then", C.byref(n_past), text, len(text))          # a follow-up message continues the context
+        out.append((n_new, n2, n_past.value, text.value))
+        host.thh_free(h)
+    assert out[0][0] > 0 and out[0] == out[1] == out[2]
+
+
+def test_tensor_buffer_semantics_on_device(host, ctx):
+    """A18: TensorBuffer (th.hpp:83-148) is what load_weights uploads every tensor through; here its allocation, upload,
+    move construction / assignment (source emptied, same device allocation), shape relabelling and download are checked."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((7, 256)).astype(np.float32)
+    back = np.zeros_like(x)
+    ok = host.thh_tensor_buffer_semantics(ctx.h, x.ctypes.data, 7, 256, back.ctypes.data)
+    assert ok == 0x3F, bin(ok)
+    assert (back == x).all()
 
 
 def test_missing_tensor_is_reported(host, orc, ctx, tmp_path):

@@ -32,7 +32,8 @@ def host(thk):
 
 def test_capi_present(host):
     assert host.capi_test_capi() == b"thk host capi"
-    for s in ("capi_model_begin_load", "capi_load_model_header", "capi_load_model_weights", "capi_model_end_load", "capi_on_human_message"):
+    for s in ("capi_model_begin_load", "capi_load_model_header", "capi_load_model_weights", "capi_model_end_load", "capi_on_human_message",
+              "capi_set_context", "capi_set_ui_hooks", "capi_wait_idle", "capi_inference_complete", "capi_transcript"):
         assert hasattr(host, s)   # the reference's wasm exports, web/main.cpp:72-179
 
 
@@ -249,3 +250,50 @@ def test_header_rejects_bad_files(host):
     name = C.create_string_buffer(16); ty = C.c_int32(); shape = (C.c_int64 * 4)(); ne = (C.c_int64 * 2)(); a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
     assert host.thh_parse_tensor(rec, C.c_int64(len(rec)), C.c_int64(0), name, 16, C.byref(ty), shape, ne, C.byref(a), C.byref(b), C.byref(c)) == 0
     assert b"quantized" in host.thh_last_error()
+
+
+def _file_with_tensor_header(path, dims, ftype=1, name=b"norm.weight", payload=b"\0" * 64):
+    """A ggjt v1 file with a 3-word toy vocabulary and ONE hand-made tensor record (dims may be hostile)."""
+    import struct
+    with open(path, "wb") as f:
+        f.write(struct.pack("<II", 0x67676A74, 1))
+        f.write(struct.pack("<7i", 3, 512, 256, 8, 1, 64, 1))
+        for w in (b"<unk>", b"<s>", b"</s>"):
+            f.write(struct.pack("<I", len(w))); f.write(w); f.write(struct.pack("<f", 0.0))
+        f.write(struct.pack("<3i", len(dims), len(name), ftype))
+        f.write(struct.pack(f"<{len(dims)}i", *dims))
+        f.write(name)
+        f.write(b"\0" * ((-f.tell()) % 32))
+        f.write(payload)
+
+
+@pytest.mark.parametrize("dims,why", [((-4,), b"non-positive"), ((0, 8), b"non-positive"), ((2 ** 31 - 1, 2 ** 31 - 1), b"exceed"),
+                                       ((1 << 20, 1 << 10, 1 << 10), b"exceed"), ((4096,), b"truncated tensor data")])
+def test_load_llama_file_rejects_hostile_tensor_dims(host, tmp_path, dims, why):
+    """negative / overflowing dimensions in the pre-scan used to give a negative record length (uncaught
+    length_error in resize) or an int64 overflow; every malformed input must return false with a message instead."""
+    lib = host
+    lib.thh_load_file.restype = C.c_int64
+    lib.thh_load_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    lib.thh_last_error.restype = C.c_char_p
+    path = str(tmp_path / "hostile.bin")
+    _file_with_tensor_header(path, dims)
+    assert lib.thh_load_file(None, path.encode(), 0) == 0          # fails in the pre-scan, before any device is needed
+
+
+def test_load_llama_file_rejects_non_ggjt_without_reading_it(host, tmp_path):
+    """A large file that is not ggjt v1 is rejected on its first 8 bytes (it used to be pulled into RAM prefix by prefix)."""
+    import time
+    lib = host
+    lib.thh_load_file.restype = C.c_int64
+    lib.thh_load_file.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+    path = str(tmp_path / "big.bin")
+    with open(path, "wb") as f:
+        f.write(b"GGUF\x03\x00\x00\x00")
+        f.truncate(3 << 30)                                          # sparse 3 GiB
+    t0 = time.time()
+    assert lib.thh_load_file(None, path.encode(), 0) == 0
+    assert time.time() - t0 < 1.0
+    with open(path, "r+b") as f:
+        f.write(bytes.fromhex("746a6767") + b"\x02\x00\x00\x00")    # right magic, wrong version
+    assert lib.thh_load_file(None, path.encode(), 0) == 0

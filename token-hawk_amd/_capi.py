@@ -64,6 +64,7 @@ SIGNATURES = {
     "thk_model_destroy": (C.c_int, [vp]),
     "thk_model_n_ff": (i32, [vp]),
     "thk_model_set_tensor": (C.c_int, [vp, C.c_char_p, C.c_int, i64, i64, vp]),
+    "thk_model_set_tensor_dev": (C.c_int, [vp, C.c_char_p, C.c_int, i64, i64, vp]),
     "thk_model_fill_synthetic": (C.c_int, [vp, u64, C.c_float]),
     "thk_model_finalize": (C.c_int, [vp]),
     "thk_model_reset_kv": (C.c_int, [vp, i32]),

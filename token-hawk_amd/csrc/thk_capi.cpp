@@ -626,6 +626,22 @@ extern "C" int thk_model_set_tensor(thk_model* m, const char* name, int dtype, i
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return THK_OK;
 }
+// Same as thk_model_set_tensor with the payload already in device memory (a thk_buf the caller uploaded, e.g. the host
+// layer's TensorBuffer): one stream-ordered device-to-device copy into the model's slot.
+extern "C" int thk_model_set_tensor_dev(thk_model* m, const char* name, int dtype, int64_t ne0, int64_t ne1, const void* dev_ptr) {
+    if (!m || !name || !dev_ptr) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    void* dst; int64_t c, r; int t;
+    const int rc = tensor_slot(m, name, &dst, &c, &r, &t);
+    if (rc < 0) return fail(ctx, THK_ERR_NOTFOUND, "unknown tensor '%s'", name);
+    if (ne1 <= 0) ne1 = 1;
+    REQUIRE(ctx, c == ne0 && r == ne1, "tensor '%s': shape [%lld,%lld] expected [%lld,%lld]", name, (long long)ne1, (long long)ne0, (long long)r, (long long)c);
+    REQUIRE(ctx, t == dtype, "tensor '%s': dtype %d expected %d (only GGML f16 models are supported, README.md:5)", name, dtype, t);
+    if (rc == 1) return THK_OK;   // another stage owns it
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(dst, dev_ptr, (size_t)(c * r) * (t == THK_F16 ? 2 : 4), hipMemcpyDeviceToDevice, ctx->stream));
+    return THK_OK;
+}
 extern "C" int thk_model_fill_synthetic(thk_model* m, uint64_t seed, float sigma) {
     if (!m) return THK_ERR_INVALID;
     thk_ctx* ctx = m->ctx;
@@ -1194,12 +1210,14 @@ static int prefill_workspace(thk_model* m, PrefillBufs* b) {
     thk_ctx* ctx = m->ctx;
     const int E = m->hp.n_embd, F = m->n_ff;
     const size_t per = align256((size_t)128 * E * 4);
-    size_t part_floats = 0, img_e = 0, img_f = 0;
-    for (int tile : {128, 256}) {                 // the tunables may pick either tile; G <= 256
-        const PrefillPlan pq = prefill_plan(128, E, 3, E, 256, tile), po = prefill_plan(128, E, 1, E, 256, tile), p13 = prefill_plan(128, F, 2, E, 256, tile), p2 = prefill_plan(128, E, 1, F, 256, tile);
-        part_floats = std::max(part_floats, std::max(std::max(pq.part_floats, po.part_floats), std::max(p13.part_floats, p2.part_floats)));
-        img_e = pq.ximg_bytes; img_f = p2.ximg_bytes;
-    }
+    // sized from the SAME plans prefill_slab builds (the prefill_blocks_* / prefill_tile_* tunables are read per call, and
+    // part_floats = G * maxseg * slot_floats is not monotonic in G, so a fixed G = 256 bound could be exceeded)
+    const int g_qkv = (int)tun(ctx, "prefill_blocks_qkv"), g_wo = (int)tun(ctx, "prefill_blocks_wo"), g_w13 = (int)tun(ctx, "prefill_blocks_w13"), g_w2 = (int)tun(ctx, "prefill_blocks_w2");
+    REQUIRE(ctx, g_qkv >= 1 && g_qkv <= 256 && g_wo >= 1 && g_wo <= 256 && g_w13 >= 1 && g_w13 <= 256 && g_w2 >= 1 && g_w2 <= 256, "prefill_blocks_* tunables must be in [1, 256]");
+    const int t_qkv = (int)tun(ctx, "prefill_tile_qkv"), t_wo = (int)tun(ctx, "prefill_tile_wo"), t_w13 = (int)tun(ctx, "prefill_tile_w13"), t_w2 = (int)tun(ctx, "prefill_tile_w2");
+    const PrefillPlan pq = prefill_plan(128, E, 3, E, g_qkv, t_qkv), po = prefill_plan(128, E, 1, E, g_wo, t_wo), p13 = prefill_plan(128, F, 2, E, g_w13, t_w13), p2 = prefill_plan(128, E, 1, F, g_w2, t_w2);
+    const size_t part_floats = std::max(std::max(pq.part_floats, po.part_floats), std::max(p13.part_floats, p2.part_floats));
+    const size_t img_e = std::max(std::max(pq.ximg_bytes, po.ximg_bytes), p13.ximg_bytes), img_f = p2.ximg_bytes;
     const size_t imgE = align256(img_e), imgF = align256(img_f), part = align256(4 * part_floats);
     const size_t bytes = 3 * per + 1024 + imgE + imgF + part;
     if (m->prefill_ws_bytes < bytes) {

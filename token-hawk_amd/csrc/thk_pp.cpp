@@ -41,7 +41,7 @@ Rccl& rccl() {
         r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.handle) break;
     }
-    if (!r.handle) { r.error = std::string("cannot load librccl: ") + dlerror(); return r; }
+    if (!r.handle) { const char* de = dlerror(); r.error = std::string("cannot load librccl: ") + (de ? de : "unknown dlopen error"); return r; }
 #define BIND(field, sym)                                                                 \
     *(void**)(&r.field) = dlsym(r.handle, sym);                                          \
     if (!r.field) { r.error = std::string("librccl lacks ") + sym; r.handle = nullptr; return r; }

@@ -105,6 +105,9 @@ struct LlamaModel {
     // th-llama.cpp:15).  true: the whole prompt goes through thk_model_prefill (MFMA GEMMs) in one call; the sampler's
     // random stream is advanced by the draws the token loop would have made, so the generated text is the same.
     bool prefillPrompt = false;
+    // true (default): with greedy sampling (temp <= 0) generation runs in the device-resident loop (thk_model_decode_steps,
+    // 4-byte token read-backs in chunks of 8) instead of one blocking 128 KB logits read-back per token; same text.
+    bool greedyDeviceLoop = true;
 
     std::function<void(std::string /*token*/, std::string /*messageSoFar*/)> onNewToken;
     std::function<void(std::string /*fullMessage*/)> onInferenceComplete;

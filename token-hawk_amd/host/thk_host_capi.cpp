@@ -7,8 +7,10 @@
 #include "thk_host.hpp"
 
 #include <string.h>
+#include <atomic>
 #include <map>
 #include <mutex>
+#include <thread>
 
 using namespace th;
 
@@ -25,30 +27,96 @@ int64_t g_next_handle = 1;
 }  // namespace
 
 // ---------------------------------------------------------------- capi_* (web/main.cpp:72-179)
+// Same names, argument lists and return types as the reference's wasm exports:
+//   void capi_model_begin_load()                                          web/main.cpp:83-86
+//   void capi_load_model_header(void* data, double dataSize)              :94-97
+//   void capi_load_model_weights(void* data, double offset, double size)  :100-104
+//   bool capi_model_end_load()                                            :138-157
+//   void capi_on_human_message(const char* str)                           :160-179
+// The reference gets its device from emscripten at start-up (`__main__`, :75-78); natively the embedder hands one over
+// with capi_set_context(thk_ctx*) before capi_model_begin_load.  The two JS hooks the reference calls
+// (updateMessageText(id, text), :106-110; sendChatMessage via sendNewBotMessage(text, id), :116-120) are C callbacks
+// registered with capi_set_ui_hooks.  Like the browser build (th-llama.cpp:176-198, :733-799) capi_on_human_message does
+// not block: inference runs on a worker thread, text streams through the hooks, and a message that arrives while a
+// reply is still being generated is ignored (web/main.cpp:172).  capi_wait_idle() joins the worker (tests, CLI-style hosts).
+namespace {
+typedef void (*update_message_text_fn)(const char* message_id, const char* text);
+typedef void (*send_new_bot_message_fn)(const char* text, const char* message_id);
+update_message_text_fn g_update_text = nullptr;
+send_new_bot_message_fn g_send_bot = nullptr;
+std::thread g_worker;
+std::atomic<bool> g_inference_complete{true};
+std::mutex g_text_mutex;                   // guards g_transcript / g_last_error / g_last_bot_id against the worker
+std::string g_last_bot_id;
+int g_bot_seq = 0;
+void join_worker() { if (g_worker.joinable()) g_worker.join(); }
+void new_bot_message(const char* prefix, const std::string& text) {
+    std::string id;
+    { std::lock_guard<std::mutex> l(g_text_mutex); g_bot_seq += 1; id = std::string(prefix) + std::to_string(g_bot_seq); g_last_bot_id = id; }
+    if (g_send_bot) g_send_bot(text.c_str(), id.c_str());
+}
+}  // namespace
+
 EXPORT const char* capi_test_capi() { return "thk host capi"; }
-EXPORT int capi_model_begin_load(thk_ctx* ctx) {
-    g_ctx = ctx; g_model = std::make_shared<LlamaModel>(); g_transcript.clear(); g_last_error.clear();
-    g_model->onError = [](std::string e) { g_last_error = e; };
-    g_model->onNewToken = [](std::string, std::string so_far) { g_transcript = so_far; };
-    g_model->onInferenceComplete = [](std::string full) { g_transcript = full; };
-    return 1;
+EXPORT void capi_set_context(thk_ctx* ctx) { g_ctx = ctx; }
+EXPORT void capi_set_ui_hooks(update_message_text_fn update_text, send_new_bot_message_fn send_bot) { g_update_text = update_text; g_send_bot = send_bot; }
+EXPORT void capi_model_begin_load() {
+    join_worker();
+    g_model = std::make_shared<LlamaModel>();
+    { std::lock_guard<std::mutex> l(g_text_mutex); g_transcript.clear(); g_last_error.clear(); }
+    g_model->onError = [](std::string e) { std::lock_guard<std::mutex> l(g_text_mutex); g_last_error = e; };   // load-time errors; replaced in end_load
 }
-EXPORT int capi_load_model_header(const void* data, double size) {
-    return g_model && load_header(g_model.get(), data, (int64_t)size) ? 1 : 0;
+EXPORT void capi_load_model_header(void* data, double dataSizeD) {
+    if (g_model) load_header(g_model.get(), data, (int64_t)dataSizeD);
 }
-EXPORT int capi_load_model_weights(const void* data, double fileOffset, double size) {
-    return g_model && load_weights(g_model.get(), g_ctx, data, (int64_t)size, 1, (int64_t)fileOffset) ? 1 : 0;
+EXPORT void capi_load_model_weights(void* data, double weightsBeginOffsetD, double dataSizeD) {
+    if (g_model && !g_model->loadFailed) load_weights(g_model.get(), g_ctx, data, (int64_t)dataSizeD, 1, (int64_t)weightsBeginOffsetD);
 }
-EXPORT int capi_model_end_load() { return g_model && post_load_init_model(g_ctx, g_model) ? 1 : 0; }
-EXPORT const char* capi_on_human_message(const char* message) {
-    if (!g_model || !g_model->dev) return "";
-    if (!strncmp(message, "[cmd] reset", 11)) { reset_context(g_model); g_transcript = "context reset"; return g_transcript.c_str(); }
-    do_inference(g_ctx, g_model, message);
-    return g_transcript.c_str();
+EXPORT bool capi_model_end_load() {
+    if (!g_model || g_model->loadFailed || !post_load_init_model(g_ctx, g_model)) { if (g_model) g_model->loadFailed = true; return false; }
+    g_model->onNewToken = [](std::string, std::string message) {            // web/main.cpp:112-114
+        std::string id;
+        { std::lock_guard<std::mutex> l(g_text_mutex); g_transcript = message; id = g_last_bot_id; }
+        if (g_update_text) g_update_text(id.c_str(), message.c_str());
+    };
+    g_model->onInferenceComplete = [](std::string message) {                // :122-128
+        { std::lock_guard<std::mutex> l(g_text_mutex); g_transcript = message; }
+        g_inference_complete = true;
+    };
+    g_model->onError = [](std::string message) {                            // :130-135
+        { std::lock_guard<std::mutex> l(g_text_mutex); g_last_error = message; }
+        new_bot_message("bot-error-msg-", message);
+        g_inference_complete = true;
+    };
+    g_inference_complete = true;
+    return true;
 }
-EXPORT const char* capi_last_error() { return g_last_error.c_str(); }
-EXPORT void capi_model_unload() { g_model.reset(); }
+EXPORT void capi_on_human_message(const char* str) {
+    if (!g_model || !g_model->dev || !str) return;
+    const std::string input(str);
+    if (input == "[cmd] reset") {                                           // :164-170
+        join_worker();
+        reset_context(g_model);
+        new_bot_message("bot-msg-", "LLM context reset.");
+        return;
+    }
+    if (!g_inference_complete.load()) return;                               // a reply is still being generated: ignored, as in the reference
+    join_worker();
+    g_inference_complete = false;
+    new_bot_message("bot-msg-", "--");
+    g_worker = std::thread([input] {
+        do_inference(g_ctx, g_model, input);
+        g_inference_complete = true;                                        // also on the early-return paths that reported through onError
+    });
+}
+// ---- native conveniences beyond the reference's exports (tests and CLI-style embedders)
+EXPORT int capi_inference_complete() { return g_inference_complete.load() ? 1 : 0; }
+EXPORT void capi_wait_idle() { join_worker(); }
+EXPORT const char* capi_transcript() { static std::string copy; std::lock_guard<std::mutex> l(g_text_mutex); copy = g_transcript; return copy.c_str(); }
+EXPORT const char* capi_last_error() { static std::string copy; std::lock_guard<std::mutex> l(g_text_mutex); copy = g_last_error; return copy.c_str(); }
+EXPORT void capi_model_unload() { join_worker(); g_model.reset(); }
 EXPORT void capi_set_prompt_prefill(int on) { if (g_model) g_model->prefillPrompt = on != 0; }
+EXPORT void capi_set_greedy_device_loop(int on) { if (g_model) g_model->greedyDeviceLoop = on != 0; }
 EXPORT void capi_set_sampler(int top_k, float top_p, float temp, float repeat_penalty) {
     if (g_model) g_model->sampler = SamplerParams{top_k, top_p, temp, repeat_penalty, false};
 }
@@ -129,6 +197,33 @@ EXPORT int thh_set_prefill(int64_t h, int on) {
     auto it = g_handles.find(h); if (it == g_handles.end()) return 0;
     it->second->prefillPrompt = on != 0;
     return 1;
+}
+EXPORT int thh_set_greedy_device_loop(int64_t h, int on) {
+    auto it = g_handles.find(h); if (it == g_handles.end()) return 0;
+    it->second->greedyDeviceLoop = on != 0;
+    return 1;
+}
+// TensorBuffer (th.hpp:83-148) on a real device: allocate + upload through the constructor, move-construct and move-assign
+// (the source must be left empty, the destination must own the SAME device allocation), relabel the shape and restore it,
+// download, free.  Returns a bit mask of the checks that passed (0x3F = all).
+EXPORT int thh_tensor_buffer_semantics(thk_ctx* ctx, const float* data, int64_t rows, int64_t cols, float* back) {
+    int ok = 0;
+    TensorBuffer a(data, TensorShape{0, 0, rows, cols}, TensorType_F32, /*backup=*/true, ctx);
+    if (a.is_valid() && a.gpu && a.get_size_bytes() == (size_t)(rows * cols * 4) && a.cpuBackup.size() == a.get_size_bytes()) ok |= 1;
+    void* dev = a.device_ptr();
+    TensorBuffer b(std::move(a));                                 // move construction
+    if (!a.gpu && !a.is_valid() && b.device_ptr() == dev && b.is_valid()) ok |= 2;
+    TensorBuffer c;
+    c = std::move(b);                                             // move assignment
+    if (!b.gpu && c.device_ptr() == dev) ok |= 4;
+    c.shape = TensorShape{0, 0, 1, rows * cols};                  // relabel without moving data (th-llama.cpp:343-361), then restore
+    const bool relabel_ok = c.get_size_bytes() == (size_t)(rows * cols * 4);
+    c.reset_shape();
+    if (relabel_ok && c.shape == TensorShape{0, 0, rows, cols}) ok |= 8;
+    if (c.download(back)) ok |= 16;
+    c.free_buffers();
+    if (!c.gpu && !c.device_ptr()) ok |= 32;
+    return ok;
 }
 EXPORT int thh_eval(int64_t h, const int32_t* tokens, int n, int n_past, float* logits_out) {
     auto it = g_handles.find(h); if (it == g_handles.end()) return -1;

@@ -117,18 +117,65 @@ void reset_context(std::shared_ptr<LlamaModel> m) {
 // kAllowedSubsequentBatchSize = 1), reads the last token's logits back and samples.
 tk_llama_token th_eval(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, const tk_llama_token* tokens, int n_tokens, int n_past) {
     (void)ctx;
-    if (!m || !m->dev) return 0;
+    if (!m || !m->dev) return -1;
     m->logits.resize((size_t)m->n_vocab);
     std::vector<int32_t> ids(tokens, tokens + n_tokens);
     const int rc = thk_model_eval(m->dev, 0, ids.data(), n_tokens, n_past, nullptr, m->logits.data());
     if (rc != THK_OK) {
         report_error(*m, std::string("th_eval failed: ") + thk_last_error(m->ctx));
-        return 0;
+        return -1;                                  // callers stop on a negative token (the reference returns 0 and carries on)
     }
     static const std::vector<tk_llama_token> none;
     const SamplerParams& sp = m->sampler;
     return llama_sample_top_p_top_k(m->rng, m->n_vocab, sp.use_last_n_tokens ? m->last_n_tokens : none, sp.top_k, sp.top_p, sp.temp,
                                     sp.repeat_penalty, m->logits);
+}
+
+// Greedy generation without a per-token host round trip: the reference drains the GPU and maps 128 KB
+// of logits after every token (th-llama.cpp:662-727) only to take their arg-max when temp <= 0.  Here the remaining prompt
+// tokens are evaluated without any read-back, then the device-resident loop (greedy pick on the GPU, graph replays) runs in
+// chunks and only the 4-byte token ids come back; onNewToken fires per token exactly as in the eval path.
+static bool greedy_device_loop(std::shared_ptr<LlamaModel> m, int n_ctx, int64_t step) {
+    const int n_prompt_left = (int)m->embd_inp.size() - m->n_consumed;
+    tk_llama_token cur;
+    if (n_prompt_left > 0) {
+        std::vector<int32_t> ids(m->embd_inp.begin() + m->n_consumed, m->embd_inp.end());
+        if (m->n_past + n_prompt_left > n_ctx) return true;            // would not fit: nothing to generate (as the loop's n_past < n_ctx guard)
+        for (int32_t id : ids) { m->last_n_tokens.erase(m->last_n_tokens.begin()); m->last_n_tokens.push_back(id); }
+        if (thk_model_seq_set(m->dev, 0, ids[0], m->n_past) != THK_OK) return false;       // clears the device token log
+        if (thk_model_eval(m->dev, 0, ids.data(), n_prompt_left, m->n_past, nullptr, nullptr) != THK_OK) return false;
+        int32_t n_log = 0, pos = 0;
+        std::vector<int32_t> log((size_t)n_prompt_left);
+        if (thk_model_seq_get(m->dev, 0, log.data(), n_prompt_left, &n_log, &pos) != THK_OK || n_log != n_prompt_left) return false;
+        cur = log[(size_t)n_prompt_left - 1];                          // greedy continuation of the last prompt token
+        m->n_consumed += n_prompt_left; m->n_past += n_prompt_left; step += n_prompt_left;
+    } else {
+        cur = m->lastGeneratedToken;                                   // the prompt went through thk_model_prefill; its pick is already emitted
+        step += 0;
+    }
+    auto emit = [&](tk_llama_token t) {
+        m->lastGeneratedToken = t;
+        if (t == tk_llama_token_eos()) return false;
+        const char* str = tk_llama_token_to_str(m, t);
+        if (str) { m->generatedMessage += str; if (m->onNewToken) m->onNewToken(str, m->generatedMessage); }
+        m->last_n_tokens.erase(m->last_n_tokens.begin());
+        m->last_n_tokens.push_back(t);
+        return true;
+    };
+    if (n_prompt_left > 0 && !emit(cur)) return true;
+    while (step < kMaxOutputTokens && m->n_past < n_ctx) {
+        const int chunk = (int)std::min<int64_t>(std::min<int64_t>(8, kMaxOutputTokens - step), n_ctx - m->n_past);
+        if (thk_model_seq_set(m->dev, 0, cur, m->n_past) != THK_OK) return false;
+        if (thk_model_decode_steps(m->dev, 0, chunk, 1) != THK_OK) return false;
+        int32_t toks[8], n_log = 0, pos = 0;
+        if (thk_model_seq_get(m->dev, 0, toks, chunk, &n_log, &pos) != THK_OK || n_log != chunk) return false;
+        for (int i = 0; i < chunk; ++i) {
+            m->n_past += 1; step += 1;
+            if (!emit(toks[i])) return true;                           // EOS: tokens the device produced beyond it are discarded
+        }
+        cur = toks[chunk - 1];
+    }
+    return true;
 }
 
 // do_inference (th-llama.cpp:111-168) + sync_continue_inference (:199-238): prepend ' ' on a fresh
@@ -154,10 +201,13 @@ void do_inference(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, std::string promp
     int64_t step = 0;
     const int n_prompt = (int)m->embd_inp.size();
     if (m->prefillPrompt && n_prompt >= 2 && m->n_past + n_prompt <= n_ctx && n_prompt <= kMaxOutputTokens) {
-        // Batched prompt ingestion: one thk_model_prefill call replaces n_prompt steps of the loop below.  Equivalent
-        // by construction: same KV rows, logits of the last prompt token, every prompt token pushed through
-        // last_n_tokens, and one discarded sampler draw per earlier prompt token (the loop samples after every token
-        // and throws the result away while the prompt is being consumed).
+        // Batched prompt ingestion: one thk_model_prefill call replaces n_prompt steps of the loop below: same KV rows,
+        // logits of the last prompt token, every prompt token pushed through last_n_tokens.  The sampler's random stream
+        // is advanced by one draw per earlier prompt token (the loop samples after every token and throws the result
+        // away while the prompt is consumed).  With temp > 0 this reproduces the token-by-token text EXCEPT when a
+        // discarded step would have sampled from a single candidate (top_k == 1, or top_p cutting to one entry):
+        // libstdc++'s discrete_distribution draws nothing for one weight, so the streams differ from there on.
+        // Greedy sampling (temp <= 0) is exactly equivalent.
         for (int i = 0; i < n_prompt; ++i) { m->last_n_tokens.erase(m->last_n_tokens.begin()); m->last_n_tokens.push_back(m->embd_inp[i]); }
         m->logits.resize((size_t)m->n_vocab);
         std::vector<int32_t> ids(m->embd_inp.begin(), m->embd_inp.end());
@@ -187,6 +237,11 @@ void do_inference(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, std::string promp
             step = kMaxOutputTokens;                                    // EOS straight after the prompt
         }
     }
+    if (m->greedyDeviceLoop && m->sampler.temp <= 0 && step < kMaxOutputTokens && m->n_past < n_ctx) {
+        if (!greedy_device_loop(m, n_ctx, step)) report_error(*m, std::string("greedy decode loop failed: ") + thk_last_error(m->ctx));
+        if (m->onInferenceComplete) m->onInferenceComplete(m->generatedMessage);
+        return;
+    }
     for (; step < kMaxOutputTokens && m->n_past < n_ctx; ++step) {
         tk_llama_token in;
         const bool from_prompt = m->n_consumed < (int)m->embd_inp.size();
@@ -198,6 +253,7 @@ void do_inference(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, std::string promp
             in = m->lastGeneratedToken;
         }
         m->lastGeneratedToken = th_eval(ctx, m, &in, 1, m->n_past);
+        if (m->lastGeneratedToken < 0) break;                           // evaluation failed (already reported): do not feed garbage back
         m->n_past += 1;
         if (m->n_consumed < (int)m->embd_inp.size()) continue;          // still consuming the prompt
         if (m->lastGeneratedToken == tk_llama_token_eos()) break;

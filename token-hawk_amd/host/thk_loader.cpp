@@ -120,8 +120,11 @@ bool load_weights(LlamaModel* m, thk_ctx* ctx, const void* data, int64_t dataSiz
         if (!parse_tensor_record((const char*)data + off, dataSize - off, originalFileOffset + off, &ti, &err)) {
             fail_load(m, "load_weights: " + err); return false;
         }
-        const int rc = thk_model_set_tensor(m->dev, ti.name.c_str(), ti.type == TensorType_F16 ? THK_F16 : THK_F32, ti.ne0, ti.ne1,
-                                            (const char*)data + off + ti.data_offset);
+        // as the reference (th-llama-loader.cpp:121-265): every tensor goes to the device through a TensorBuffer; the device
+        // model then takes it over with one device-to-device copy and the (move-only) buffer is released at scope end
+        TensorBuffer tb((const char*)data + off + ti.data_offset, ti.shape, ti.type, /*backup=*/false, ctx);
+        if (!tb.is_valid() || !tb.gpu) { fail_load(m, std::string("load_weights: device upload of '") + ti.name + "' failed: " + thk_last_error(ctx)); return false; }
+        const int rc = thk_model_set_tensor_dev(m->dev, ti.name.c_str(), ti.type == TensorType_F16 ? THK_F16 : THK_F32, ti.ne0, ti.ne1, tb.device_ptr());
         if (rc != THK_OK) { fail_load(m, std::string("load_weights: ") + thk_last_error(ctx)); return false; }
         m->loadedNames.push_back(ti.name);
         m->numTensorsLoaded += 1;
@@ -163,6 +166,12 @@ std::shared_ptr<LlamaModel> load_llama_file(thk_ctx* ctx, const std::string& fil
     std::vector<char> buf;
     int64_t consumed = 0;
     {
+        // magic + version are checked on the first 8 bytes BEFORE any growing read: a multi-GB file that is not ggjt v1 is
+        // rejected at once instead of being pulled into RAM prefix by prefix
+        char head8[8];
+        if (file_size < 8 || fread(head8, 1, 8, f) != 8) { fail_load(m.get(), "load_llama_file: file too short for a ggjt header"); return {}; }
+        uint32_t magic, version; memcpy(&magic, head8, 4); memcpy(&version, head8 + 4, 4);
+        if (magic != kMagicGgjt || version != kFileVersion) { load_header(m.get(), head8, 8, &consumed); return {}; }   // reports "bad magic" / "bad version"
         int64_t want = std::min<int64_t>(file_size, 1 << 20);
         for (;;) {
             buf.resize((size_t)want);
@@ -179,22 +188,32 @@ std::shared_ptr<LlamaModel> load_llama_file(thk_ctx* ctx, const std::string& fil
     // tensors: read each record [header | padding | data] and hand it to load_weights, as the reference does (:571-621)
     int64_t pos = consumed;
     while (pos < file_size) {
-        char hdr[12 + 3 * 4 + 512];
+        char hdr[12 + 3 * 4 + 512] = {0};
         fseek(f, pos, SEEK_SET);
         const size_t got = fread(hdr, 1, sizeof hdr, f);
         if (got < 12) break;
         int32_t n_dims, name_len;
         memcpy(&n_dims, hdr, 4); memcpy(&name_len, hdr + 4, 4);
         if (n_dims < 1 || n_dims > 3 || name_len < 0 || name_len > 512) { fail_load(m.get(), "load_llama_file: malformed tensor header"); return {}; }
+        const int64_t head = 12 + 4 * n_dims + name_len;
+        if ((int64_t)got < head) { fail_load(m.get(), "load_llama_file: truncated tensor header"); return {}; }
         int64_t ne[3] = {1, 1, 1};
         int32_t ftype; memcpy(&ftype, hdr + 8, 4);
-        for (int i = 0; i < n_dims; ++i) { int32_t v; memcpy(&v, hdr + 12 + 4 * i, 4); ne[i] = v; }
         const int64_t elt = ftype == kftype_f32 ? 4 : ftype == kftype_f16 ? 2 : 0;
         if (elt == 0) { fail_load(m.get(), "load_llama_file: quantized formats are not supported"); return {}; }
-        const int64_t head = 12 + 4 * n_dims + name_len;
+        // every dimension positive, and the element count bounded by what the file can hold BEFORE multiplying: a negative
+        // or huge dim can neither slip past the size check as a negative record length nor overflow the int64 product
+        int64_t count = 1;
+        bool dims_ok = true;
+        for (int i = 0; i < n_dims; ++i) {
+            int32_t v; memcpy(&v, hdr + 12 + 4 * i, 4); ne[i] = v;
+            if (v <= 0 || count > file_size / elt / v) { dims_ok = false; break; }
+            count *= v;
+        }
+        if (!dims_ok) { fail_load(m.get(), "load_llama_file: tensor dimensions are non-positive or exceed the file size"); return {}; }
         const int64_t data_at = (pos + head + 31) & ~(int64_t)31;
-        const int64_t rec = (data_at - pos) + ne[0] * ne[1] * ne[2] * elt;
-        if (pos + rec > file_size) { fail_load(m.get(), "load_llama_file: truncated tensor data"); return {}; }
+        const int64_t rec = (data_at - pos) + count * elt;
+        if (rec <= 0 || pos + rec > file_size) { fail_load(m.get(), "load_llama_file: truncated tensor data"); return {}; }
         buf.resize((size_t)rec);
         fseek(f, pos, SEEK_SET);
         if ((int64_t)fread(buf.data(), 1, (size_t)rec, f) != rec) { fail_load(m.get(), "load_llama_file: short read"); return {}; }
