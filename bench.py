@@ -51,6 +51,8 @@ def parse():
                    help="run the N>1 code path (process group, HipStage, ring driver with a self send/recv) even with one rank; plumbing check")
     p.add_argument("--transport", default="native", choices=["torch", "native"],
                    help="N>1 hidden-state hand-off: torch.distributed P2P ops (backend nccl = RCCL) or libthk's thk_pp_* (RCCL directly)")
+    p.add_argument("--kv", default="f32", choices=["f32", "f16"],
+                   help="KV-cache storage: f32 as the reference (default, the headline configuration) or the optional binary16 cache (s_kv = 2 in bytes/token)")
     p.add_argument("--cpu-baseline-layers", type=int, default=0,
                    help="layers of the CPU baseline model (0 = the full model when host RAM allows, else a 4-layer sample scaled up and labelled so)")
     p.add_argument("--master-port", type=int, default=29533, help="rendezvous port when bench.py launches its own ranks (--gpus N without torchrun)")
@@ -231,6 +233,8 @@ def main():
         for kv in args.tunable:
             k, v = kv.split("=")
             ctx.set_tunable(k, int(v))
+        if args.kv == "f16":
+            ctx.set_tunable("kv_f16", 1)
         info = ctx.device_info()
         from token_hawk_amd.pipeline import HipStage, PipelineDriver, layer_range
         S = N
@@ -347,7 +351,8 @@ def main():
             allst = [torch.zeros_like(st_ms) for _ in range(N)]
             dist.all_gather(allst, st_ms)
             stage_ms = [round(float(t.item()), 4) for t in allst]
-        b_tok = shape.bytes_per_token(T)                       # whole-model algorithmic bytes per token
+        kv_bytes = 2 if ctx.get_tunable("kv_f16") else 4
+        b_tok = shape.bytes_per_token(T, kv_bytes=kv_bytes)    # whole-model algorithmic bytes per token (s_kv = 4 | 2)
         step_gbs = b_tok * value / 1e9 / N                     # per-GPU achieved GB/s over the whole step
         result = {
             "metric": "decode tokens/sec, LLaMA-7B f16, 512-ctx, 1/2/4/8 MI355X; % HBM roofline",
@@ -358,7 +363,7 @@ def main():
             "config": {"workload": f"LLaMA-{args.model.upper()} f16, {T}-ctx single-token greedy decode (n_past={T - 1}), "
                                    f"{'1 sequence' if N == 1 else f'{S} sequences in flight, layers pipelined over {N} GPUs (RCCL p2p)'}",
                        "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single", "transport": args.transport if PIPE else None,
-                       "lmhead_mode": args.lmhead, "numerics": "f16 GGML weights x f32 activations, f32 accumulate, f32 KV cache (as the reference)",
+                       "lmhead_mode": args.lmhead, "numerics": "f16 GGML weights x f32 activations, f32 accumulate, " + ("f32 KV cache (as the reference)" if kv_bytes == 4 else "binary16 KV cache (OPTION, not the reference's: s_kv = 2 in bytes/token)"),
                        "decode_path": "persistent engine (1 launch/step)" if model.uses_engine() else "5 fused launches per layer, hipGraph replay (8/4/2/1-step graphs)",
                        "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "attn_waves", "use_graph", "engine")}},
             "bytes_per_token": b_tok,

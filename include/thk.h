@@ -274,7 +274,9 @@ int thk_pp_recv_token(thk_pp* pp, thk_model* m, int32_t seq, int peer);
  * per call.  Unknown names return THK_ERR_NOTFOUND.
  *   decode : gemv_blocks_per_cu; gemv_bpc_{qkv,wo,w13,w2,head} and gemv_variant_{...}
  *            (-1 = per-shape default, 0 = generic, >0 explicit); attn_splits (1|2|4|8);
- *            attn_waves (4|8); use_graph; engine (1 = persistent loader/consumer launch per step when the
+ *            attn_waves (4|8); use_graph; kv_f16 (1 = K/V caches stored as binary16, rounded RNE at the append: half the
+ *            KV bytes, thk_model_bytes_per_token then counts s_kv = 2; default 0 = f32 like the reference,
+ *            th-llama-loader.cpp:335); engine (1 = persistent loader/consumer launch per step when the
  *            shape allows, 0 = launches); experiments kept off: fuse_attn_wo, attn_combine;
  *            measure_skip_kernel (1..6: that kernel is not launched -- bench.py's marginal-cost
  *            measurement; results are garbage; REFUSED unless the environment has THK_MEASURE_HOOKS=1)

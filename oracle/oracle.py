@@ -18,6 +18,7 @@ _LIB_PATH = os.path.join(_HERE, "libthk_oracle.so")
 
 FAITHFUL_ORDER = 1  # reference strip+tree summation order, transposes, K9 tiles
 LM_FAITHFUL = 2     # reproduce lm-head combine defect Q1
+KV_F16 = 4          # K/V rounded to binary16 as they are appended (checker for the build's optional f16 KV cache)
 
 
 def build(force: bool = False) -> str:

@@ -542,7 +542,7 @@ static void mv_faithful(const float* a, const uint16_t* b, float* c, int64_t R, 
 /* faithful=1: reference kernels incl. the transposes and K9 tile order.      */
 /* faithful=0: fast flavour (direct cache indexing, any-order sums).          */
 /* ------------------------------------------------------------------------- */
-static void layer_forward(orc_model* m, int l, int seq, float* x, int n_past, int faithful) {
+static void layer_forward(orc_model* m, int l, int seq, float* x, int n_past, int faithful, int kv_f16) {
     const int64_t E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, T = n_past + 1;
     orc_layer* y = &m->layers[l];
     matvec_fn mv = faithful ? mv_faithful : orc_matvec_f16_fast;
@@ -556,6 +556,9 @@ static void layer_forward(orc_model* m, int l, int seq, float* x, int n_past, in
     orc_rope(q, 1, H, D, n_past); orc_rope(k, 1, H, D, n_past);
     /* 4: append to caches at row n_past (:332-339) */
     float *Kc = y->key_cache[seq], *Vc = y->value_cache[seq];
+    if (kv_f16) {   /* optional f16 KV cache of the build: k, v are rounded to binary16 (RNE) as they are appended */
+        for (int64_t i = 0; i < E; ++i) { k[i] = orc_fp16_to_fp32(orc_fp32_to_fp16(k[i])); v[i] = orc_fp16_to_fp32(orc_fp32_to_fp16(v[i])); }
+    }
     memcpy(Kc + (int64_t)n_past * E, k, (size_t)E * 4); memcpy(Vc + (int64_t)n_past * E, v, (size_t)E * 4);
     float* o = m->inp[2]; /* keyBuf is reused for the attention output (:380) */
     if (faithful) {
@@ -628,7 +631,8 @@ static void head_forward(orc_model* m, const float* x, float* logits, int faithf
 /*   token >= 0 : x = embedding(token); else x = hidden_inout on entry        */
 /*   runs layers [l0,l1); writes x back to hidden_inout (if non-NULL)         */
 /*   logits != NULL : final norm + lm-head into logits[V]                     */
-/* flags: bit0 faithful summation order, bit1 lm-head Q1-faithful combine.    */
+/* flags: bit0 faithful summation order, bit1 lm-head Q1-faithful combine,     */
+/*        bit2 K/V rounded to f16 at the append (the build's f16-KV option).  */
 /* ------------------------------------------------------------------------- */
 ORC_API int orc_model_eval(orc_model* m, int seq, int32_t token, int n_past, int l0, int l1,
                            float* hidden_inout, float* logits, int flags) {
@@ -636,7 +640,7 @@ ORC_API int orc_model_eval(orc_model* m, int seq, int32_t token, int n_past, int
     if (n_past < 0 || n_past >= m->hp.n_ctx || seq < 0 || seq >= m->n_seq) return -1;
     float* x = (float*)malloc((size_t)E * 4);
     if (token >= 0) orc_embed(m, token, x); else if (hidden_inout) memcpy(x, hidden_inout, (size_t)E * 4); else { free(x); return -2; }
-    for (int l = l0; l < l1; ++l) layer_forward(m, l, seq, x, n_past, flags & 1);
+    for (int l = l0; l < l1; ++l) layer_forward(m, l, seq, x, n_past, flags & 1, (flags >> 2) & 1);
     if (hidden_inout) memcpy(hidden_inout, x, (size_t)E * 4);
     if (logits) head_forward(m, x, logits, flags & 1, (flags >> 1) & 1);
     free(x);
@@ -654,7 +658,7 @@ ORC_API int orc_model_time_decode(orc_model* m, int n_past, int n_layers_sample,
     for (int s = 0; s < steps; ++s) {
         orc_embed(m, 1 + s, x);
         double t0 = omp_get_wtime();
-        for (int l = 0; l < n_layers_sample; ++l) layer_forward(m, l, 0, x, n_past, 0);
+        for (int l = 0; l < n_layers_sample; ++l) layer_forward(m, l, 0, x, n_past, 0, 0);
         double t1 = omp_get_wtime();
         head_forward(m, x, lg, 0, 0);
         double t2 = omp_get_wtime();

@@ -462,3 +462,62 @@ def test_measure_hook_is_refused_without_env(thk, ctx, monkeypatch):
     monkeypatch.setenv("THK_MEASURE_HOOKS", "1")
     ctx.set_tunable("measure_skip_kernel", 4)
     ctx.set_tunable("measure_skip_kernel", 0)
+
+
+# ------------------------------------------------------------------ optional f16 KV cache
+KV16_TOL = 1e-3   # vs the oracle that rounds k, v to binary16 at the append: same tolerance as the f32 path
+
+
+@pytest.mark.parametrize("use_graph", [0, 1])
+def test_f16_kv_cache_vs_oracle_rounded_at_append(thk, orc, ctx, use_graph):
+    """tunable kv_f16 = 1: caches stored as binary16 (RNE at the append), decode attention widens them on load.  Checked
+    against the oracle with K/V rounded to f16 at the append (flag KV_F16); the default stays f32 like the reference
+    (th-llama-loader.cpp:335) and the two really differ."""
+    m, om = make_pair(thk, orc, ctx, "TINY", tunables={"kv_f16": 1, "use_graph": use_graph})
+    ref = thk.Model(ctx, thk.TINY); ref.fill_synthetic(); ref.finalize()
+    rng = np.random.default_rng(16)
+    toks = [1] + rng.integers(3, 2048, 40).tolist()
+    differs = 0.0
+    for i, t in enumerate(toks):
+        lg, _ = m.eval([t], i)
+        lo, _ = om.eval(t, i, flags=orc.FAITHFUL_ORDER | orc.KV_F16)
+        l32, _ = ref.eval([t], i)
+        assert np.abs(lg - lo).max() < KV16_TOL, i
+        differs = max(differs, float(np.abs(lg - l32).max()))
+    assert differs > 1e-5                       # the option is really on (f16 rounding of K/V is visible in the logits)
+    T = 41
+    assert m.bytes_per_token(T) == thk.TINY.bytes_per_token(T, kv_bytes=2) < ref.bytes_per_token(T) == thk.TINY.bytes_per_token(T, kv_bytes=4)
+    m.close(); ref.close(); om.close()
+
+
+def test_f16_kv_prefill_and_decode_continue(thk, orc, ctx):
+    """Prefill writes the f16 cache (RNE, same as the decode append) and its MFMA attention reads it; decode continues on it."""
+    m, om = make_pair(thk, orc, ctx, "TINY", tunables={"kv_f16": 1})
+    rng = np.random.default_rng(17)
+    toks = [1] + rng.integers(3, 2048, 40).tolist()
+    lp = m.prefill(toks[:33], 0)
+    for i in range(33):
+        lo, _ = om.eval(toks[i], i, flags=orc.KV_F16)
+    assert np.abs(lp - lo).max() < KV16_TOL and int(lp.argmax()) == orc.greedy(lo)
+    for i in range(33, 41):
+        lg, _ = m.eval([toks[i]], i); lo, _ = om.eval(toks[i], i, flags=orc.KV_F16)
+        assert np.abs(lg - lo).max() < KV16_TOL, i
+    m.close(); om.close()
+
+
+def test_f16_kv_full_width_7b_layers(thk, orc, ctx):
+    """7B row geometry (D = 128, H = 32) with the f16 cache at a few hundred positions of context."""
+    shape = thk.ModelShape(n_embd=4096, n_head=32, n_layer=1)
+    ctx.set_tunable("kv_f16", 1)
+    try:
+        m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    finally:
+        ctx.set_tunable("kv_f16", 0)
+    om = orc.OracleModel(orc.ModelShape(n_embd=4096, n_head=32, n_layer=1)); om.fill_synthetic()
+    rng = np.random.default_rng(18)
+    toks = [1] + rng.integers(3, 32000, 7).tolist()
+    for i, t in enumerate(toks):
+        lg, _ = m.eval([t], i); lo, _ = om.eval(t, i, flags=orc.KV_F16)
+        assert np.abs(lg - lo).max() < KV16_TOL, i
+    assert not m.uses_engine()
+    m.close(); om.close()

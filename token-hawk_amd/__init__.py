@@ -53,12 +53,13 @@ class ModelShape:
         E, F, V = self.n_embd, self.n_ff, self.n_vocab
         return (l1 - l0) * (4 * E * E + 3 * E * F) * 2 + (V * E * 2 if head else 0)
 
-    def bytes_per_token(self, T: int, l0: int = 0, l1: int | None = None, head: bool = True) -> int:
-        """Algorithmic HBM bytes of one decode step: W + KVr(T) + KVw + G."""
+    def bytes_per_token(self, T: int, l0: int = 0, l1: int | None = None, head: bool = True, kv_bytes: int = 4) -> int:
+        """Algorithmic HBM bytes of one decode step: W + KVr(T) + KVw + G; kv_bytes = s_kv (4 = f32 cache
+        as the reference, 2 = the optional binary16 cache)."""
         l1 = self.n_layer if l1 is None else l1
         E = self.n_embd
         nl = l1 - l0
-        return self.weight_bytes(l0, l1, head) + nl * (2 * T * E * 4 + 2 * E * 4 + 2 * E * 4) + (E * 4 if head else 0)
+        return self.weight_bytes(l0, l1, head) + nl * (2 * T * E * kv_bytes + 2 * E * kv_bytes + 2 * E * 4) + (E * 4 if head else 0)
 
 
 LLAMA_7B = ModelShape()

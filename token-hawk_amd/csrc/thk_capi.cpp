@@ -49,7 +49,7 @@ struct LayerW {
 };
 
 struct SeqBuf {
-    float* kv = nullptr;             // [n_local_layers][2][n_ctx*E] f32
+    float* kv = nullptr;             // [n_local_layers][2][n_ctx*E] f32 (or binary16 when the model was finalized with kv_f16)
     SeqState* st = nullptr;          // device
     int32_t* gen_log = nullptr;      // device, kGenLogCap
     float* hidden_in = nullptr;      // device f32[E]
@@ -97,6 +97,7 @@ struct thk_model {
     unsigned* head_ticket = nullptr;   // [H] counters of the in-launch split combine
     unsigned* fuse_counters = nullptr;   // [n_local_layers] then [1] error
     // persistent loader/consumer engine (thk_engine.hip): one launch per decode step instead of 5 per layer
+    int kv_f16 = 0;                      // tunable kv_f16 at finalize: K/V caches stored as binary16 (default 0 = f32, as the reference)
     int engine = 0;                      // resolved at finalize (tunable "engine" and shape eligibility)
     int eng_NS = 0, eng_v0 = 0, eng_v1 = 0, eng_nsplit = 1, eng_tc = 0;
     unsigned long long* eng_gran = nullptr;   // all granule arrays: XG[2][E] | QG[3E] | OG[E] | UG[F] | PG[H*S*(D+2)]
@@ -141,6 +142,7 @@ static void default_tunables(thk_ctx* ctx) {
     ctx->tun["fuse_attn_wo"] = 0;         // attention splits + wo mat-vec in one launch (in-launch hand-off)
     ctx->tun["measure_skip_kernel"] = 0;  // bench.py: marginal cost of one kernel = step time with minus without it (results are garbage then);
                                           // refused unless the process runs with THK_MEASURE_HOOKS=1 (never in a product)
+    ctx->tun["kv_f16"] = 0;               // 1 = K/V caches stored as binary16 (half the KV bytes; k, v are rounded RNE at the append); default f32 as the reference
     ctx->tun["engine_park"] = 1;          // engine variant whose waiting consumer waves park one landed ring slot in registers (more loader run-ahead)
     ctx->tun["engine_trace"] = 0;         // development: per-op s_memtime timeline of the engine (thk_model_engine_trace)
     ctx->tun["engine"] = 0;               // 1 = decode step as ONE persistent loader/consumer launch (thk_engine.hip) when the shape allows; default 0 = 5
@@ -410,9 +412,10 @@ extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache
     return THK_OK;
 }
 // MFMA tile kernel for D = 64 | 128 (tunable prefill_attn_mfma, default on); otherwise one workgroup per (head, query)
-static hipError_t attn_prefill_dispatch(thk_ctx* ctx, const float* q, const float* kc, const float* vc, int n_past, int M, int H, int D, float* out) {
-    if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) return launch_attn_prefill_mfma(q, kc, vc, n_past, M, H, D, out, nullptr, ctx->stream);
+static hipError_t attn_prefill_dispatch(thk_ctx* ctx, const float* q, const float* kc, const float* vc, int n_past, int M, int H, int D, float* out, bool kv_f16 = false) {
+    if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) return launch_attn_prefill_mfma(q, kc, vc, kv_f16, n_past, M, H, D, out, nullptr, ctx->stream);
     AttnArgs a{};
+    a.kv_f16 = kv_f16 ? 1 : 0;
     a.q = q; a.kcache = kc; a.vcache = vc; a.pos_ptr = nullptr; a.pos_val = n_past; a.H = H; a.D = D;
     a.nsplit = 1; a.tc = n_past + M; a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = M; a.out = out;
     return launch_attn_decode(a, ctx->stream);
@@ -678,6 +681,16 @@ extern "C" int thk_model_set_lmhead_mode(thk_model* m, int mode) {
     return THK_OK;
 }
 
+// K / V cache of local layer i (rows of E elements, f32 or binary16): byte arithmetic, typed as float* for the kernel args
+static inline float* kcache_of(const thk_model* m, const SeqBuf& sb, int i) {
+    const size_t row = (size_t)m->hp.n_ctx * m->hp.n_embd * (m->kv_f16 ? 2 : 4);
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(sb.kv) + (size_t)i * 2 * row);
+}
+static inline float* vcache_of(const thk_model* m, const SeqBuf& sb, int i) {
+    const size_t row = (size_t)m->hp.n_ctx * m->hp.n_embd * (m->kv_f16 ? 2 : 4);
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(sb.kv) + ((size_t)i * 2 + 1) * row);
+}
+
 // ----- one decode step of this stage, enqueued on the ctx stream (eager or under capture)
 struct StepProf {
     std::vector<std::string> names;
@@ -731,14 +744,14 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
     }
     for (int i = 0; i < nl; ++i) {
         const LayerW& L = m->layers[i];
-        float* kc = sb.kv + (size_t)i * 2 * T * E;
-        float* vc = kc + (size_t)T * E;
+        float* kc = kcache_of(m, sb, i);
+        float* vc = vcache_of(m, sb, i);
         const float* xr_in = i == 0 ? xin : m->x;
         {   // rms_norm*gain -> wq,wk,wv -> RoPE -> K/V append   (steps 1-4, th-llama.cpp:299-339)
             GemvArgs a{};
             a.W[0] = L.wq; a.W[1] = L.wk; a.W[2] = L.wv; a.R = E; a.C = E; a.n_groups = 3 * E / 2;
             a.x = xr_in; a.gain = L.attention_norm; a.y = m->q;
-            a.kcache = kc; a.vcache = vc; a.rope_tab = m->rope_tab; a.pos_ptr = &sb.st->pos; a.E = E; a.D = D;
+            a.kcache = kc; a.vcache = vc; a.rope_tab = m->rope_tab; a.pos_ptr = &sb.st->pos; a.E = E; a.D = D; a.kv_f16 = m->kv_f16;
             MARK("norm_qkv_rope_kv");
             if (m->skip_kernel != 1) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_ROPE_KV, m->var_qkv, a, m->grid_qkv, nt, st));
         }
@@ -746,7 +759,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             // split combine -> wo -> + residual (steps 10-11, th-llama.cpp:401-413)
             AttnArgs t{};
             t.q = m->q; t.kcache = kc; t.vcache = vc; t.pos_ptr = &sb.st->pos; t.H = H; t.D = D; t.nsplit = m->nsplit; t.tc = m->tc;
-            t.scale = 1.0f / sqrtf((float)D); t.waves = m->attn_waves;
+            t.scale = 1.0f / sqrtf((float)D); t.waves = m->attn_waves; t.kv_f16 = m->kv_f16;
             const bool combined = m->attn_combine && !m->fuse_attn_wo;      // attention writes the finished vector itself
             t.out = (m->nsplit == 1 || combined) ? m->attn_out : nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml;
             t.head_ticket = combined ? m->head_ticket : nullptr;
@@ -843,7 +856,7 @@ static bool engine_plan(thk_model* m) {
     if (D != 64 && D != 128) return false;
     if (E % 512 != 0 || F % 256 != 0 || E > 6144 || (V & 1)) return false;            // row pairs, one-sweep norm gather, whole pieces
     if ((m->flags & THK_STAGE_HEAD) && m->lm_mode != THK_LMHEAD_CORRECT) return false;  // the Q1-faithful combine stays on the launch path
-    if (m->skip_kernel || m->fuse_attn_wo || H > ctx->n_cu) return false;
+    if (m->skip_kernel || m->fuse_attn_wo || m->kv_f16 || H > ctx->n_cu) return false;   // the engine reads the reference's f32 cache
     int S = 1;
     while (S * 2 <= kMaxSplit && S * 2 * H <= ctx->n_cu) S *= 2;
     const int v1 = ((E + 511) / 512) * 2048, v0 = ((std::max(E, F) + 511) / 512) * 2048;
@@ -871,8 +884,8 @@ static int engine_build_program(thk_model* m, SeqBuf& sb) {
     int prev_w2 = -1;
     for (int i = 0; i < nl; ++i) {
         const LayerW& L = m->layers[i];
-        float* kc = sb.kv + (size_t)i * 2 * T * E;
-        float* vc = kc + (size_t)T * E;
+        float* kc = kcache_of(m, sb, i);
+        float* vc = vcache_of(m, sb, i);
         EngOp q{};    // rms_norm*gain -> wq,wk,wv -> RoPE -> K/V append (th-llama.cpp:299-339)
         q.kind = EOP_QKV; q.n_units = 3 * E / 2; q.C = E; eng_unit_geometry(q);
         q.W[0] = L.wq; q.W[1] = L.wk; q.W[2] = L.wv; q.gain = L.attention_norm;
@@ -929,7 +942,8 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->skip_kernel = (int)tun(ctx, "measure_skip_kernel");
     m->attn_waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
     m->attn_combine = tun(ctx, "attn_combine") != 0 && m->nsplit > 1;
-    m->fuse_attn_wo = tun(ctx, "fuse_attn_wo") != 0 && m->nsplit > 1 && (D == 64 || D == 128);
+    m->kv_f16 = tun(ctx, "kv_f16") != 0;
+    m->fuse_attn_wo = tun(ctx, "fuse_attn_wo") != 0 && m->nsplit > 1 && (D == 64 || D == 128) && !m->kv_f16;
     m->var_qkv = resolve_variant(ctx, "qkv", (int)E); m->var_wo = resolve_variant(ctx, "wo", (int)E);
     m->var_w13 = resolve_variant(ctx, "w13", (int)E); m->var_w2 = resolve_variant(ctx, "w2", (int)E); m->var_head = resolve_variant(ctx, "head", (int)E);
     m->grid_qkv = grid_for(ctx, "gemv_bpc_qkv", (int)(3 * E / 2), (int)E);
@@ -958,7 +972,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
     }
     m->seqs.resize(m->n_seq);
     for (auto& s : m->seqs) {
-        ALLOCZ(s.kv, (size_t)nl * 2 * T * E * 4);
+        ALLOCZ(s.kv, (size_t)nl * 2 * T * E * (m->kv_f16 ? 2 : 4));
         ALLOCZ(s.st, sizeof(SeqState)); ALLOCZ(s.gen_log, (size_t)kGenLogCap * 4);
         ALLOCZ(s.hidden_in, E * 4); ALLOCZ(s.hidden_out, E * 4); ALLOCZ(s.advance, 4);
         if (m->flags & THK_STAGE_HEAD) ALLOCZ(s.logits, V * 4);
@@ -1023,7 +1037,7 @@ extern "C" int thk_model_reset_kv(thk_model* m, int32_t seq) {
     thk_ctx* ctx = m->ctx;
     REQUIRE(ctx, m->finalized, "thk_model_reset_kv before thk_model_finalize");
     REQUIRE(ctx, seq >= 0 && seq < m->n_seq, "bad sequence %d", seq);
-    const size_t bytes = (size_t)(m->l1 - m->l0) * 2 * m->hp.n_ctx * m->hp.n_embd * 4;
+    const size_t bytes = (size_t)(m->l1 - m->l0) * 2 * m->hp.n_ctx * m->hp.n_embd * (m->kv_f16 ? 2 : 4);
     HIPCHK(ctx, hipMemsetAsync(m->seqs[seq].kv, 0, bytes, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(m->seqs[seq].st, 0, sizeof(SeqState), ctx->stream));
     m->seqs[seq].pos_host = 0;
@@ -1166,9 +1180,10 @@ extern "C" int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out,
 extern "C" int64_t thk_model_bytes_per_token(const thk_model* m, int32_t T) {
     if (!m) return 0;
     const int64_t E = m->hp.n_embd, F = m->n_ff, V = m->hp.n_vocab, nl = m->l1 - m->l0;
+    const int64_t s_kv = m->kv_f16 ? 2 : 4;          // a build that stores KV as f16 must say so and use s_kv = 2
     int64_t b = nl * ((4 * E * E + 3 * E * F) * 2      // f16 weights
-                      + 2 * (int64_t)T * E * 4          // f32 K,V read
-                      + 2 * E * 4                       // K,V row written
+                      + 2 * (int64_t)T * E * s_kv       // K,V read
+                      + 2 * E * s_kv                    // K,V row written
                       + 2 * E * 4);                     // two norm gains
     if (m->flags & THK_STAGE_HEAD) b += V * E * 2 + E * 4;
     return b;
@@ -1246,17 +1261,17 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
     HIPCHK(ctx, launch_embed_rows(m->tok_embeddings, b.tok, M, E, b.X, st));
     for (int i = 0; i < m->l1 - m->l0; ++i) {
         const LayerW& L = m->layers[i];
-        float* kc = sb.kv + (size_t)i * 2 * T * E;
-        float* vc = kc + (size_t)T * E;
+        float* kc = kcache_of(m, sb, i);
+        float* vc = vcache_of(m, sb, i);
         const uint16_t* wqkv[3] = {L.wq, L.wk, L.wv};
         const uint16_t* w13[2] = {L.w1, L.w3};
         HIPCHK(ctx, launch_prefill_ximg(b.X, L.attention_norm, M, E, b.imgE, st));
         HIPCHK(ctx, launch_prefill_gemm(wqkv, pq, b.imgE, b.part, st));
-        HIPCHK(ctx, launch_prefill_reduce_qkv(b.part, pq, m->rope_tab, n_past, D, b.Q, kc, vc, st));
+        HIPCHK(ctx, launch_prefill_reduce_qkv(b.part, pq, m->rope_tab, n_past, D, b.Q, kc, vc, m->kv_f16 != 0, st));
         if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) {
-            HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, n_past, M, H, D, nullptr, b.imgE, st));   // writes wo's X image directly
+            HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, m->kv_f16 != 0, n_past, M, H, D, nullptr, b.imgE, st));   // writes wo's X image directly
         } else {
-            HIPCHK(ctx, attn_prefill_dispatch(ctx, b.Q, kc, vc, n_past, M, H, D, b.ATT));
+            HIPCHK(ctx, attn_prefill_dispatch(ctx, b.Q, kc, vc, n_past, M, H, D, b.ATT, m->kv_f16 != 0));
             HIPCHK(ctx, launch_prefill_ximg(b.ATT, nullptr, M, E, b.imgE, st));
         }
         HIPCHK(ctx, launch_prefill_gemm(&L.wo, po, b.imgE, b.part, st));

@@ -431,8 +431,13 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
                     const float t0 = y0 * cs - y1 * sn, t1 = y0 * sn + y1 * cs;
                     y0 = t0; y1 = t1;
                 }
-                float* dst = which == 0 ? a.y : (which == 1 ? a.kcache + (size_t)pos * a.E : a.vcache + (size_t)pos * a.E);
-                dst[rr] = y0; dst[rr + 1] = y1;
+                if (which != 0 && a.kv_f16) {     // optional f16 cache: RNE rounding at the append (v_cvt_f16_f32)
+                    _Float16* dh = reinterpret_cast<_Float16*>(which == 1 ? a.kcache : a.vcache) + (size_t)pos * a.E;
+                    dh[rr] = (_Float16)y0; dh[rr + 1] = (_Float16)y1;
+                } else {
+                    float* dst = which == 0 ? a.y : (which == 1 ? a.kcache + (size_t)pos * a.E : a.vcache + (size_t)pos * a.E);
+                    dst[rr] = y0; dst[rr + 1] = y1;
+                }
             }
         } else if (EPI == EPI_SWIGLU) {      // K12 th.cpp:2706-2707, K13 :2512-2524
             if (lane == 0) { const float u1 = acc[0]; a.y[g] = (u1 / (1.0f + expf(-u1))) * acc[1 % NR]; }
@@ -649,7 +654,17 @@ hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, b
 // softmax K10 th.cpp:1901-1957.
 // WAVES waves per block share one (head, split): more waves = fewer positions per wave, so every
 // wave needs a single load batch (one HBM round trip) at T = 512 with 4 splits.
-template <int D, int WAVES, bool PUBLISH>
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+// one position's 4-element slice for this lane: f32 cache (16 bytes) or f16 cache (8 bytes, widened by v_cvt_f32_f16)
+template <bool KVH>
+__device__ __forceinline__ f4 ld_kv4(const float* base, size_t elem_off) {
+    if (KVH) {
+        const h4 h = __builtin_nontemporal_load(reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(base) + elem_off));
+        return f4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    }
+    return __builtin_nontemporal_load(reinterpret_cast<const f4*>(base + elem_off));
+}
+template <int D, int WAVES, bool PUBLISH, bool KVH = false>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     constexpr int LPP = D / 4;          // lanes per position
     constexpr int PPW = 64 / LPP;       // positions per wave-instruction
@@ -669,8 +684,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     const int t0 = s * a.tc, t1 = min(t0 + a.tc, T);
 
     const f4 q = *reinterpret_cast<const f4*>(a.q + (size_t)qi * E + h * D + li * 4);
-    const float* kb = a.kcache + h * D + li * 4;
-    const float* vb = a.vcache + h * D + li * 4;
+    const size_t hoff = (size_t)(h * D + li * 4);      // element offset of this lane's slice inside a cache row
 
     float m = -INFINITY, l = 0.f;
     f4 o = {0.f, 0.f, 0.f, 0.f};
@@ -681,12 +695,12 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int t = min(tb + u * PPW + grp, t1 - 1);
-            kv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(kb + (size_t)t * E));
+            kv[u] = ld_kv4<KVH>(a.kcache, (size_t)t * E + hoff);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int t = min(tb + u * PPW + grp, t1 - 1);
-            vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(vb + (size_t)t * E));
+            vv[u] = ld_kv4<KVH>(a.vcache, (size_t)t * E + hoff);
         }
         __builtin_amdgcn_sched_barrier(0);
         float sc[UB];
@@ -784,9 +798,9 @@ __device__ __forceinline__ void attn_last_arriver_combine(const AttnArgs& a, con
     if (threadIdx.x == 0) __hip_atomic_store(a.head_ticket + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int D, int WAVES>
+template <int D, int WAVES, bool KVH>
 __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(const AttnArgs a) {
-    attn_body<D, WAVES, false>(a, blockIdx.x);
+    attn_body<D, WAVES, false, KVH>(a, blockIdx.x);
     if (a.head_ticket) attn_last_arriver_combine<D>(a, blockIdx.x);
 }
 
@@ -810,8 +824,11 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     const bool w8 = a.waves == 8;
 #define THK_ATTN(d)                                                                                           \
     case d:                                                                                                   \
-        if (w8) hipLaunchKernelGGL((attn_decode_kernel<d, 8>), dim3(grid), dim3(512), 0, st, a);              \
-        else hipLaunchKernelGGL((attn_decode_kernel<d, 4>), dim3(grid), dim3(256), 0, st, a);                 \
+        if (a.kv_f16) {                                                                                        \
+            if (w8) hipLaunchKernelGGL((attn_decode_kernel<d, 8, true>), dim3(grid), dim3(512), 0, st, a);    \
+            else hipLaunchKernelGGL((attn_decode_kernel<d, 4, true>), dim3(grid), dim3(256), 0, st, a);       \
+        } else if (w8) hipLaunchKernelGGL((attn_decode_kernel<d, 8, false>), dim3(grid), dim3(512), 0, st, a); \
+        else hipLaunchKernelGGL((attn_decode_kernel<d, 4, false>), dim3(grid), dim3(256), 0, st, a);          \
         break;
     switch (a.D) {
         THK_ATTN(64) THK_ATTN(128) THK_ATTN(256)
@@ -868,7 +885,7 @@ static hipError_t launch_attn_wo_d(int NR, int U, const AttnArgs& t, const GemvA
     }
 }
 hipError_t launch_attn_wo(const AttnArgs& t, const GemvArgs& g, int nru, int grid_wo, bool nt, hipStream_t st) {
-    if (g.C != t.H * t.D || g.C < 256 || g.C % 256 != 0 || t.out != nullptr) return hipErrorInvalidValue;
+    if (g.C != t.H * t.D || g.C < 256 || g.C % 256 != 0 || t.out != nullptr || t.kv_f16) return hipErrorInvalidValue;
     int NR, U; gemv_variant(g.C, GEMV_EPI_RESID, nru, &NR, &U);
     switch (t.D) {
         case 64: return launch_attn_wo_d<64>(NR, U, t, g, grid_wo, nt, st);

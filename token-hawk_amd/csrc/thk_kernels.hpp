@@ -45,6 +45,7 @@ struct GemvArgs {
     const float* resid;     // EPI_RESID
     // EPI_ROPE_KV
     float* kcache; float* vcache; const float* rope_tab; const int32_t* pos_ptr; int pos_val; int E; int D;
+    int kv_f16;             // caches hold binary16 [n_ctx, H, D] (optional; the reference's and the default are f32)
     // PRO_ATTN
     const float* part_o; const float* part_ml; int H; int nsplit;
     // EPI_HEAD
@@ -61,6 +62,7 @@ struct AttnArgs {
     int H, D, nsplit, tc;      // tc = positions per split
     int waves;                 // waves per block of the stand-alone kernel (4 or 8)
     int nq;                    // causal queries in this launch (prefill); 0/1 = single decode query
+    int kv_f16;                // the caches hold binary16 (kcache / vcache then point to _Float16 data)
     float scale;               // 1/sqrtf(D)
     float* out;                // finished output [H*D]: nsplit == 1, or the last-arriver combine (head_ticket != NULL)
     unsigned* head_ticket;     // [H] arrival counters for the in-launch split combine (NULL = partials only)
@@ -151,9 +153,9 @@ PrefillPlan prefill_plan(int M, int R, int nmat, int C, int G /* workgroups; 0 =
 hipError_t launch_prefill_ximg(const float* X, const float* gain_or_null, int M, int C, void* ximg, hipStream_t st);
 hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, const void* ximg, float* part, hipStream_t st);
 hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st);
-hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, float* kcache, float* vcache, hipStream_t st);
+hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, void* kcache, void* vcache, bool kv_f16, hipStream_t st);
 // causal attention for the M queries of a slab (D = 64 | 128), f32-class accuracy on MFMA
-hipError_t launch_attn_prefill_mfma(const float* Q, const float* Kc, const float* Vc, int n_past, int M, int H, int D, float* out /* [M,H*D] or null */,
+hipError_t launch_attn_prefill_mfma(const float* Q, const void* Kc, const void* Vc, bool kv_f16, int n_past, int M, int H, int D, float* out /* [M,H*D] or null */,
                                     void* ximg /* if out is null: the X image of the consuming GEMM */, hipStream_t st);
 hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st);
 

@@ -320,8 +320,9 @@ __global__ __launch_bounds__(256) void reduce_store_kernel(const float* __restri
     *dst = s;
 }
 // q -> RoPE -> Q[tok];  k -> RoPE -> K-cache row n_past+tok;  v -> V-cache row  (K6, th-llama.cpp:318-339)
+template <bool KVH>
 __global__ __launch_bounds__(256) void reduce_qkv_kernel(const float* __restrict__ part, PrefillPlan p, const float* __restrict__ tab, int n_past, int D,
-                                                         float* __restrict__ Q, float* __restrict__ kc, float* __restrict__ vc) {
+                                                         float* __restrict__ Q, void* __restrict__ kc, void* __restrict__ vc) {
     const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;
     const FragPos fp = frag_decode(q, p.MT);
     const int mat = rbk / p.rb_per_mat, r = (rbk % p.rb_per_mat) * p.tile_rows + fp.row, tok = fp.tok;
@@ -333,8 +334,13 @@ __global__ __launch_bounds__(256) void reduce_qkv_kernel(const float* __restrict
         const f4 cs = *reinterpret_cast<const f4*>(tab + ((size_t)pos * half + jp) * 2);     // cos0 sin0 cos1 sin1
         s = f4{s[0] * cs[0] - s[1] * cs[1], s[0] * cs[1] + s[1] * cs[0], s[2] * cs[2] - s[3] * cs[3], s[2] * cs[3] + s[3] * cs[2]};
     }
-    float* dst = mat == 0 ? Q + (size_t)tok * p.R + r : (mat == 1 ? kc : vc) + (size_t)pos * p.R + r;
-    *reinterpret_cast<f4*>(dst) = s;
+    if (mat == 0) { *reinterpret_cast<f4*>(Q + (size_t)tok * p.R + r) = s; return; }
+    if (KVH) {          // optional f16 cache: the same RNE rounding as the decode path's append
+        typedef _Float16 h4c __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<h4c*>(reinterpret_cast<_Float16*>(mat == 1 ? kc : vc) + (size_t)pos * p.R + r) = h4c{(_Float16)s[0], (_Float16)s[1], (_Float16)s[2], (_Float16)s[3]};
+    } else {
+        *reinterpret_cast<f4*>(reinterpret_cast<float*>(mat == 1 ? kc : vc) + (size_t)pos * p.R + r) = s;
+    }
 }
 // hidden = silu(w1 x) * (w3 x)  (K10, K11) written straight into the X image of the w2 GEMM (C = R of this plan);
 // a thread owns 4 columns = half of a 16-byte image piece
@@ -397,8 +403,9 @@ hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, 
     hipLaunchKernelGGL(reduce_store_kernel, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, Y, residual ? 1 : 0);
     return hipGetLastError();
 }
-hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, float* kcache, float* vcache, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_qkv_kernel, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache);
+hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, void* kcache, void* vcache, bool kv_f16, hipStream_t st) {
+    if (kv_f16) hipLaunchKernelGGL(reduce_qkv_kernel<true>, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache);
+    else hipLaunchKernelGGL(reduce_qkv_kernel<false>, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache);
     return hipGetLastError();
 }
 hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st) {
@@ -429,14 +436,19 @@ __device__ __forceinline__ void split4(const f4 v, h4v& hi, h4v& lo) {
 // segment, hipcc waits vmcnt(0) after every load, 32 serialized L2 round trips per tile = 17 us) ...
 template <int D>
 struct AttnTileRegs { f4 v[32 * (D / 4) / 64]; };
-template <int D>
-__device__ __forceinline__ void attn_load_tile(AttnTileRegs<D>& r, const float* __restrict__ cache, int p0, int p_last, int E, int hcol, int lane) {
+template <int D, bool KVH>
+__device__ __forceinline__ void attn_load_tile(AttnTileRegs<D>& r, const void* __restrict__ cache, int p0, int p_last, int E, int hcol, int lane) {
     constexpr int SPR = D / 4;                          // float4 segments per row
 #pragma unroll
     for (int i = 0; i < 32 * SPR / 64; ++i) {
         const int idx = i * 64 + lane, row = idx / SPR, seg = idx % SPR;
         const int prow = p0 + row < p_last ? p0 + row : p_last;          // rows past the context repeat the last cached row (masked later)
-        r.v[i] = *reinterpret_cast<const f4*>(cache + (size_t)prow * E + hcol + seg * 4);
+        if (KVH) {
+            const h4v h = *reinterpret_cast<const h4v*>(reinterpret_cast<const _Float16*>(cache) + (size_t)prow * E + hcol + seg * 4);
+            r.v[i] = f4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        } else {
+            r.v[i] = *reinterpret_cast<const f4*>(reinterpret_cast<const float*>(cache) + (size_t)prow * E + hcol + seg * 4);
+        }
     }
 }
 // ... -> hi/lo f16 in the wave's LDS tile, rows of D halfs; SWZ: 16-byte pieces XOR-swizzled by the row (fragment reads)
@@ -454,8 +466,8 @@ __device__ __forceinline__ void attn_store_tile(const AttnTileRegs<D>& r, int la
     }
 }
 // IMG: instead of out[M, E] f32, write the hi/lo X image of the wo GEMM directly (one launch and one 2 MB round trip less)
-template <int D, bool IMG>
-__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ Kc, const float* __restrict__ Vc,
+template <int D, bool IMG, bool KVH>
+__global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __restrict__ Q, const void* __restrict__ Kc, const void* __restrict__ Vc,
                                                                 int n_past, int M, int H, float scale, float* __restrict__ out, char* __restrict__ img) {
     constexpr int KS = D / 16, DB = D / 32;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // 4 waves x {hi, lo} x 32 x D halfs; reused for the merge
@@ -493,11 +505,11 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
     for (int t = wave; t < ntiles; t += 4) {
         const int p0 = t * 32;
         AttnTileRegs<D> tr;
-        attn_load_tile<D>(tr, Kc, p0, p_last, E, hcol, lane);
+        attn_load_tile<D, KVH>(tr, Kc, p0, p_last, E, hcol, lane);
         __builtin_amdgcn_sched_barrier(0);
         attn_store_tile<D, true>(tr, lane, t_hi, t_lo);
         __builtin_amdgcn_sched_barrier(0);
-        attn_load_tile<D>(tr, Vc, p0, p_last, E, hcol, lane);           // V's round trip runs under the S^T / softmax phase
+        attn_load_tile<D, KVH>(tr, Vc, p0, p_last, E, hcol, lane);           // V's round trip runs under the S^T / softmax phase
         __builtin_amdgcn_sched_barrier(0);
         f16v s;
 #pragma unroll
@@ -589,22 +601,27 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
     }
 }
 
-template <int D, bool IMG>
-static hipError_t launch_attn_prefill_t(const float* Q, const float* Kc, const float* Vc, int n_past, int M, int H, float* out, char* img, hipStream_t st) {
+template <int D, bool IMG, bool KVH>
+static hipError_t launch_attn_prefill_t(const float* Q, const void* Kc, const void* Vc, int n_past, int M, int H, float* out, char* img, hipStream_t st) {
     const int grid = H * ((M + 31) / 32);
     const size_t lds = (size_t)4 * 2 * 32 * D * 2;
     hipError_t e = hipSuccess;
     static bool done[kMaxDevices] = {};                 // the attribute is per device (64 KB dynamic + the static arrays)
     const int dev = current_device();
-    if (!done[dev]) { e = hipFuncSetAttribute((const void*)attn_prefill_mfma_kernel<D, IMG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[dev] = (e == hipSuccess); }
-    if (e == hipSuccess) hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, IMG>), dim3(grid), dim3(256), lds, st, Q, Kc, Vc, n_past, M, H, 1.0f / sqrtf((float)D), out, img);
+    if (!done[dev]) { e = hipFuncSetAttribute((const void*)attn_prefill_mfma_kernel<D, IMG, KVH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[dev] = (e == hipSuccess); }
+    if (e == hipSuccess) hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, IMG, KVH>), dim3(grid), dim3(256), lds, st, Q, Kc, Vc, n_past, M, H, 1.0f / sqrtf((float)D), out, img);
     return e != hipSuccess ? e : hipGetLastError();
 }
-// out != null: out[M, H*D] f32;  otherwise ximg = the hi/lo X image (C = H*D, M <= 128) of the GEMM that consumes the attention output
-hipError_t launch_attn_prefill_mfma(const float* Q, const float* Kc, const float* Vc, int n_past, int M, int H, int D, float* out, void* ximg, hipStream_t st) {
+template <int D, bool KVH>
+static hipError_t launch_attn_prefill_d(const float* Q, const void* Kc, const void* Vc, int n_past, int M, int H, float* out, void* ximg, hipStream_t st) {
+    return out ? launch_attn_prefill_t<D, false, KVH>(Q, Kc, Vc, n_past, M, H, out, nullptr, st) : launch_attn_prefill_t<D, true, KVH>(Q, Kc, Vc, n_past, M, H, nullptr, (char*)ximg, st);
+}
+// out != null: out[M, H*D] f32;  otherwise ximg = the hi/lo X image (C = H*D, M <= 128) of the GEMM that consumes the attention output.
+// kv_f16: the caches hold binary16 rows (optional f16 KV cache); the tiles are widened to f32 as they are loaded.
+hipError_t launch_attn_prefill_mfma(const float* Q, const void* Kc, const void* Vc, bool kv_f16, int n_past, int M, int H, int D, float* out, void* ximg, hipStream_t st) {
     if ((D != 64 && D != 128) || (!out && (!ximg || M > 128 || (H * D) % kKC != 0))) return hipErrorInvalidValue;
-    if (D == 128) return out ? launch_attn_prefill_t<128, false>(Q, Kc, Vc, n_past, M, H, out, nullptr, st) : launch_attn_prefill_t<128, true>(Q, Kc, Vc, n_past, M, H, nullptr, (char*)ximg, st);
-    return out ? launch_attn_prefill_t<64, false>(Q, Kc, Vc, n_past, M, H, out, nullptr, st) : launch_attn_prefill_t<64, true>(Q, Kc, Vc, n_past, M, H, nullptr, (char*)ximg, st);
+    if (D == 128) return kv_f16 ? launch_attn_prefill_d<128, true>(Q, Kc, Vc, n_past, M, H, out, ximg, st) : launch_attn_prefill_d<128, false>(Q, Kc, Vc, n_past, M, H, out, ximg, st);
+    return kv_f16 ? launch_attn_prefill_d<64, true>(Q, Kc, Vc, n_past, M, H, out, ximg, st) : launch_attn_prefill_d<64, false>(Q, Kc, Vc, n_past, M, H, out, ximg, st);
 }
 
 size_t gemm_prefill_workspace_bytes(int M, int R, int C) {
