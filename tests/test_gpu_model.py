@@ -521,3 +521,63 @@ def test_f16_kv_full_width_7b_layers(thk, orc, ctx):
         assert np.abs(lg - lo).max() < KV16_TOL, i
     assert not m.uses_engine()
     m.close(); om.close()
+
+
+# ------------------------------------------------------------------ full-size configurations (BASELINE.json configs 3 and 5)
+def test_7b_full_model_prefill_128_vs_token_by_token(thk, ctx):
+    """BASELINE config 3 at FULL size: the 128-token prompt through all 32 layers of the MFMA prefill path gives the
+    logits of the same prompt fed token by token through the decode path (prefill parity is defined against decode,
+    SURVEY.md Q5), the same greedy token, and a cache from which decode continues to the same next logits."""
+    shape = thk.LLAMA_7B
+    rng = np.random.default_rng(128)
+    toks = np.concatenate([[1], rng.integers(3, shape.n_vocab, 128)]).astype(np.int32)
+    a = thk.Model(ctx, shape); a.fill_synthetic(); a.finalize()
+    lp = a.prefill(toks[:128], 0)
+    la_next, _ = a.eval([int(toks[128])], 128)
+    a.close()
+    b = thk.Model(ctx, shape); b.fill_synthetic(); b.finalize()
+    ld, _ = b.eval(toks[:128], 0)
+    lb_next, _ = b.eval([int(toks[128])], 128)
+    b.close()
+    assert np.isfinite(lp).all()
+    assert np.abs(lp - ld).max() < LOGIT_TOL and int(lp.argmax()) == int(ld.argmax())
+    assert np.abs(la_next - lb_next).max() < LOGIT_TOL
+
+
+def test_13b_full_model_properties(thk, ctx):
+    """BASELINE config 5 at FULL size (LLaMA-13B, 25.7 GB of synthetic f16 weights, E=5120 H=40 L=40 F=13824) at T=512:
+    determinism, hold-position idempotence at the last cache slot, device loop == eval-path greedy tokens, two chained
+    half-model stages == the full model (mirrors test_7b_full_model_properties)."""
+    shape = thk.LLAMA_13B
+    m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    rng = np.random.default_rng(13)
+    prompt = [1] + rng.integers(3, 32000, 11).tolist()
+    lg1, h1 = m.eval(prompt, 0, want_hidden=True)
+    assert np.isfinite(lg1).all() and np.isfinite(h1).all()
+    m.reset_kv(0)
+    lg2, _ = m.eval(prompt, 0)
+    assert (lg1 == lg2).all()
+    toks_host, lg = [], lg1
+    for i in range(3):
+        t = int(lg.argmax()); toks_host.append(t)
+        lg, _ = m.eval([t], len(prompt) + i)
+    m.reset_kv(0)
+    m.eval(prompt[:-1], 0, want_logits=False)
+    m.seq_set(0, prompt[-1], len(prompt) - 1)
+    m.decode_steps(3, 0, advance=True)
+    gen, n, pos = m.seq_get(0)
+    assert gen.tolist() == toks_host and pos == len(prompt) + 2
+    m.seq_set(0, 5, 511)
+    m.decode_step(0, advance=False); a, _, _ = m.seq_get(0)
+    m.seq_set(0, 5, 511)
+    m.decode_step(0, advance=False); b, _, _ = m.seq_get(0)
+    assert a[0] == b[0]
+    assert m.bytes_per_token(512) == 26545377280          # SURVEY.md 8(d) canonical 13B figure
+    m.close()
+    s0 = thk.Model(ctx, shape, 0, 20, flags=thk.THK_STAGE_EMBED); s0.fill_synthetic(); s0.finalize()
+    s1 = thk.Model(ctx, shape, 20, 40, flags=thk.THK_STAGE_HEAD); s1.fill_synthetic(); s1.finalize()
+    for i, t in enumerate(prompt):
+        _, h = s0.eval([t], i, want_logits=False, want_hidden=True)
+        lgp, _ = s1.eval(None, i, hidden=h)
+    assert np.abs(lgp - lg1).max() < 1e-5
+    s0.close(); s1.close()

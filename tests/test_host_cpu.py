@@ -297,3 +297,18 @@ def test_load_llama_file_rejects_non_ggjt_without_reading_it(host, tmp_path):
     with open(path, "r+b") as f:
         f.write(bytes.fromhex("746a6767") + b"\x02\x00\x00\x00")    # right magic, wrong version
     assert lib.thh_load_file(None, path.encode(), 0) == 0
+
+
+def test_host_fp16_converters_match_reference_fixture(host):
+    """The host layer's ggml_compute_fp16_to_fp32 / fp32_to_fp16 against the outputs of the REFERENCE's own functions
+    (tests/golden/ref_fp16.npz, generated by tools/make_ref_fp16_golden.py from th.cpp:294-359)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_fp16.npz"))
+    h = np.arange(65536, dtype=np.uint16)
+    out = np.empty(65536, np.float32)
+    host.thh_fp16_to_fp32(P(h), P(out), C.c_int64(h.size))
+    nan = ((h & 0x7C00) == 0x7C00) & ((h & 0x3FF) != 0)
+    assert (out.view(np.uint32)[~nan] == g["h2f_bits"][~nan]).all() and np.isnan(out[nan]).all()
+    f = np.ascontiguousarray(g["f_in_bits"].view(np.float32))
+    got = np.empty(f.size, np.uint16)
+    host.thh_fp32_to_fp16(P(f), P(got), C.c_int64(f.size))
+    assert (got == g["f2h"]).all()

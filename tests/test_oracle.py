@@ -230,3 +230,40 @@ def test_kv_cache_layout(orc):
     assert np.abs(k[0]).sum() > 0 and np.abs(k[1]).sum() > 0 and np.abs(k[2:]).sum() == 0
     m.reset_kv(0)
     assert np.abs(m.kv(0, 0, 0)).sum() == 0
+
+
+# ------------------------------------------------------------------ A17 pinned by the reference's own functions
+REF_FP16 = os.path.join(os.path.dirname(__file__), "golden", "ref_fp16.npz")
+
+
+def test_fp16_converters_match_reference_fixture(orc):
+    """tests/golden/ref_fp16.npz holds the outputs of the REFERENCE's ggml_compute_fp16_to_fp32 / fp32_to_fp16
+    (th.cpp:294-359, compiled from /root/reference by `make -C oracle _ref`, generator tools/make_ref_fp16_golden.py):
+    every binary16 pattern widened, and ~45k f32 inputs narrowed.  The oracle's restatement must reproduce them bit for bit."""
+    g = np.load(REF_FP16)
+    h = np.arange(65536, dtype=np.uint16)
+    got = orc.fp16_to_fp32(h).view(np.uint32)
+    ref = g["h2f_bits"]
+    nan = ((h & 0x7C00) == 0x7C00) & ((h & 0x3FF) != 0)
+    assert (got[~nan] == ref[~nan]).all()                               # every non-NaN pattern: identical bits (inf and denormals included)
+    assert np.isnan(got[nan].view(np.float32)).all() and np.isnan(ref[nan].view(np.float32)).all()
+    f = g["f_in_bits"].view(np.float32)
+    assert (orc.fp32_to_fp16(f) == g["f2h"]).all()
+
+
+def test_reference_fp16_library_when_present(orc):
+    """In the build container (where /root/reference exists) the compiled reference functions are called directly."""
+    import ctypes as C
+    path = os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "_ref", "libth_ref_fp16.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built here (no /root/reference)")
+    lib = C.CDLL(path)
+    lib.ggml_compute_fp16_to_fp32.restype = C.c_float; lib.ggml_compute_fp16_to_fp32.argtypes = [C.c_uint16]
+    lib.ggml_compute_fp32_to_fp16.restype = C.c_uint16; lib.ggml_compute_fp32_to_fp16.argtypes = [C.c_float]
+    hs = np.arange(0, 65536, 37, dtype=np.uint16)
+    mine = orc.fp16_to_fp32(hs)
+    for h, v in zip(hs.tolist(), mine.tolist()):
+        r = lib.ggml_compute_fp16_to_fp32(h)
+        assert (np.isnan(r) and np.isnan(v)) or np.float32(r).view(np.uint32) == np.float32(v).view(np.uint32)
+    xs = (np.random.default_rng(9).standard_normal(4000) * 50).astype(np.float32)
+    assert [lib.ggml_compute_fp32_to_fp16(float(x)) for x in xs] == orc.fp32_to_fp16(xs).tolist()
