@@ -1,0 +1,128 @@
+// thk_internal.hpp — shared by the three translation units that implement include/thk.h:
+//   thk_ctx.cpp    context, tunables, buffers (TensorBuffer's GPU half, th.cpp:150-229)
+//   thk_ops.cpp    one operator per reference kernel (the 16 cmdbuf_* encoders, th.cpp:617-4351)
+//   thk_model.cpp  model level: th_eval_gpu (th-llama.cpp:464-660) as graph replays / the engine, prefill, pipeline stages
+// Internal; not part of the ABI.
+#pragma once
+#include "../../include/thk.h"
+#include "thk_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace thk;
+
+// ---------------------------------------------------------------- objects
+struct thk_buf {
+    void* ptr = nullptr;
+    size_t size = 0;
+};
+
+struct thk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err = "";
+    std::map<std::string, int64_t> tun;
+    int n_cu = 256;
+    size_t hbm_bytes = 0;
+    std::string dev_name;
+    void* scratch = nullptr;        // operator-API scratch (attention partials, arg-max keys)
+    size_t scratch_bytes = 0;
+    float* rope_tab = nullptr;      // operator-API RoPE table
+    size_t rope_tab_floats = 0;
+};
+
+struct LayerW {
+    uint16_t *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
+    float *attention_norm = nullptr, *ffn_norm = nullptr;
+};
+
+struct SeqBuf {
+    float* kv = nullptr;             // [n_local_layers][2][n_ctx*E] f32 (or binary16 when the model was finalized with kv_f16)
+    SeqState* st = nullptr;          // device
+    int32_t* gen_log = nullptr;      // device, kGenLogCap
+    float* hidden_in = nullptr;      // device f32[E]
+    float* hidden_out = nullptr;     // device f32[E]
+    float* logits = nullptr;         // device f32[V] (head stage)
+    int32_t* advance = nullptr;      // device flag read by the finishing kernel
+    int advance_host = -1;           // last value written
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipGraph_t graph_multi[3] = {nullptr, nullptr, nullptr};        // 2, 4 and 8 decode steps in one graph (thk_model_prepare_steps / first use)
+    hipGraphExec_t exec_multi[3] = {nullptr, nullptr, nullptr};
+    int pos_host = 0;                // position the NEXT step evaluates (every change goes through this API, so the host knows it exactly)
+    EngOp* eng_ops = nullptr;        // device: this sequence's engine program (cache / hidden-state pointers differ per sequence)
+    int eng_n_ops = 0;
+};
+
+static const int kGenLogCap = 4096;
+static const int kMultiSteps[3] = {2, 4, 8};
+static const size_t kFuseStride = 1024;   // words per layer: counter line + kFuseFlags flag lines, padded
+
+struct thk_model {
+    thk_ctx* ctx = nullptr;
+    thk_hparams hp{};
+    int n_ff = 0, l0 = 0, l1 = 0, n_seq = 1;
+    uint32_t flags = 0;
+    int lm_mode = THK_LMHEAD_CORRECT;
+    bool finalized = false;
+    std::vector<LayerW> layers;       // local layers
+    uint16_t* tok_embeddings = nullptr;
+    float* norm = nullptr;
+    uint16_t* output = nullptr;
+    std::vector<SeqBuf> seqs;
+    // working buffers shared by all sequences (steps run back to back on one stream)
+    float *x = nullptr, *q = nullptr, *u = nullptr, *attn_out = nullptr, *part_o = nullptr, *part_ml = nullptr;
+    unsigned long long* block_best = nullptr;
+    float* rope_tab = nullptr;        // [n_ctx][D/2][2]
+    // launch geometry resolved at finalize
+    int nsplit = 4, tc = 128, nt = 1, use_graph = 1;
+    int var_qkv = 0, var_wo = 0, var_w13 = 0, var_w2 = 0, var_head = 0;
+    int grid_qkv = 0, grid_wo = 0, grid_w13 = 0, grid_w2 = 0, grid_head = 0;
+    void* prefill_ws = nullptr; size_t prefill_ws_bytes = 0;
+    // fused attention+wo launch: per-layer arrival counters (zeroed at the start of every step) + error word
+    int fuse_attn_wo = 0, fuse_initial_sleeps = 0, attn_waves = 8, attn_combine = 0;
+    int skip_kernel = 0;   // measurement aid (tunable measure_skip_kernel): 1 qkv, 2 attention, 3 wo, 4 w13, 5 w2, 6 lm-head are NOT launched
+    unsigned* head_ticket = nullptr;   // [H] counters of the in-launch split combine
+    unsigned* fuse_counters = nullptr;   // [n_local_layers] then [1] error
+    // persistent loader/consumer engine (thk_engine.hip): one launch per decode step instead of 5 per layer
+    int kv_f16 = 0;                      // tunable kv_f16 at finalize: K/V caches stored as binary16 (default 0 = f32, as the reference)
+    int engine = 0;                      // resolved at finalize (tunable "engine" and shape eligibility)
+    int eng_NS = 0, eng_v0 = 0, eng_v1 = 0, eng_nsplit = 1, eng_tc = 0;
+    unsigned long long* eng_gran = nullptr;   // all granule arrays: XG[2][E] | QG[3E] | OG[E] | UG[F] | PG[H*S*(D+2)]
+    unsigned* eng_words = nullptr;       // [0] epoch, [32] error word
+    unsigned long long* eng_trace = nullptr;   // development timeline (tunable engine_trace), [n_cu][n_ops][8]
+};
+
+// ---------------------------------------------------------------- helpers (thk_ctx.cpp)
+int fail(thk_ctx* ctx, int code, const char* fmt, ...);
+#define HIPCHK(ctx, call)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) return fail((ctx), THK_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define REQUIRE(ctx, cond, ...) do { if (!(cond)) return fail((ctx), THK_ERR_INVALID, __VA_ARGS__); } while (0)
+int64_t tun(thk_ctx* ctx, const char* name);
+void default_tunables(thk_ctx* ctx);
+struct Geo { int bpc, var; };
+Geo auto_geometry(const char* kernel, int n_embd);
+int resolve_variant(thk_ctx* ctx, const char* kernel, int n_embd);
+int grid_for(thk_ctx* ctx, const char* specific, int n_groups, int n_embd = 4096);
+int ensure_scratch(thk_ctx* ctx, size_t bytes);
+void build_rope_table(std::vector<float>& tab, int D, int p0, int n);
+uint64_t synth_key(const char* name, uint64_t seed);
+float synth_scale(float sigma);
+// operators shared with the model level (thk_ops.cpp)
+int valid_head_dim(int64_t D);
+int valid_splits(int64_t s);
+void q1_constants(int V, int* split, int* cov);
+hipError_t attn_prefill_dispatch(thk_ctx* ctx, const float* q, const float* kc, const float* vc, int n_past, int M, int H, int D, float* out, bool kv_f16 = false);

@@ -1,4 +1,4 @@
-// thk_kernels.hpp — launch interface between the C-ABI layer (thk_capi.cpp) and the
+// thk_kernels.hpp — launch interface between the C-ABI layer (thk_ctx.cpp, thk_ops.cpp, thk_model.cpp) and the
 // HIP kernels (thk_kernels.hip, thk_prefill.hip).  Internal; not part of the ABI.
 #pragma once
 #include <hip/hip_runtime.h>

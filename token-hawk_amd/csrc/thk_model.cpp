@@ -1,514 +1,7 @@
-// thk_capi.cpp — implementation of the C-ABI in include/thk.h on top of the HIP
-// runtime and the kernels in thk_kernels.hip / thk_prefill.hip.
-//
-// Replaces the reference's WebGPU dispatch layer: TensorBuffer's GPU half
-// (th.cpp:150-229), the 16 cmdbuf_* encoders (th.cpp:617-4351) and th_eval_gpu
-// (th-llama.cpp:464-660).  One decode step = ONE hipGraph replay (embed, 5 fused
-// kernels per layer, lm-head + greedy pick) instead of 773 dispatches, 129 copies and
-// a blocking map-read per token.
-#include "../../include/thk.h"
-#include "thk_kernels.hpp"
-
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
-#include <algorithm>
-#include <map>
-#include <string>
-#include <vector>
-
-using namespace thk;
-
-// ---------------------------------------------------------------- objects
-struct thk_buf {
-    void* ptr = nullptr;
-    size_t size = 0;
-};
-
-struct thk_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    std::string err = "";
-    std::map<std::string, int64_t> tun;
-    int n_cu = 256;
-    size_t hbm_bytes = 0;
-    std::string dev_name;
-    void* scratch = nullptr;        // operator-API scratch (attention partials, arg-max keys)
-    size_t scratch_bytes = 0;
-    float* rope_tab = nullptr;      // operator-API RoPE table
-    size_t rope_tab_floats = 0;
-};
-
-struct LayerW {
-    uint16_t *wq = nullptr, *wk = nullptr, *wv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr, *w3 = nullptr;
-    float *attention_norm = nullptr, *ffn_norm = nullptr;
-};
-
-struct SeqBuf {
-    float* kv = nullptr;             // [n_local_layers][2][n_ctx*E] f32 (or binary16 when the model was finalized with kv_f16)
-    SeqState* st = nullptr;          // device
-    int32_t* gen_log = nullptr;      // device, kGenLogCap
-    float* hidden_in = nullptr;      // device f32[E]
-    float* hidden_out = nullptr;     // device f32[E]
-    float* logits = nullptr;         // device f32[V] (head stage)
-    int32_t* advance = nullptr;      // device flag read by the finishing kernel
-    int advance_host = -1;           // last value written
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-    hipGraph_t graph_multi[3] = {nullptr, nullptr, nullptr};        // 2, 4 and 8 decode steps in one graph (thk_model_prepare_steps / first use)
-    hipGraphExec_t exec_multi[3] = {nullptr, nullptr, nullptr};
-    int pos_host = 0;                // position the NEXT step evaluates (every change goes through this API, so the host knows it exactly)
-    EngOp* eng_ops = nullptr;        // device: this sequence's engine program (cache / hidden-state pointers differ per sequence)
-    int eng_n_ops = 0;
-};
-
-static const int kGenLogCap = 4096;
-static const int kMultiSteps[3] = {2, 4, 8};
-static const size_t kFuseStride = 1024;   // words per layer: counter line + kFuseFlags flag lines, padded
-
-struct thk_model {
-    thk_ctx* ctx = nullptr;
-    thk_hparams hp{};
-    int n_ff = 0, l0 = 0, l1 = 0, n_seq = 1;
-    uint32_t flags = 0;
-    int lm_mode = THK_LMHEAD_CORRECT;
-    bool finalized = false;
-    std::vector<LayerW> layers;       // local layers
-    uint16_t* tok_embeddings = nullptr;
-    float* norm = nullptr;
-    uint16_t* output = nullptr;
-    std::vector<SeqBuf> seqs;
-    // working buffers shared by all sequences (steps run back to back on one stream)
-    float *x = nullptr, *q = nullptr, *u = nullptr, *attn_out = nullptr, *part_o = nullptr, *part_ml = nullptr;
-    unsigned long long* block_best = nullptr;
-    float* rope_tab = nullptr;        // [n_ctx][D/2][2]
-    // launch geometry resolved at finalize
-    int nsplit = 4, tc = 128, nt = 1, use_graph = 1;
-    int var_qkv = 0, var_wo = 0, var_w13 = 0, var_w2 = 0, var_head = 0;
-    int grid_qkv = 0, grid_wo = 0, grid_w13 = 0, grid_w2 = 0, grid_head = 0;
-    void* prefill_ws = nullptr; size_t prefill_ws_bytes = 0;
-    // fused attention+wo launch: per-layer arrival counters (zeroed at the start of every step) + error word
-    int fuse_attn_wo = 0, fuse_initial_sleeps = 0, attn_waves = 8, attn_combine = 0;
-    int skip_kernel = 0;   // measurement aid (tunable measure_skip_kernel): 1 qkv, 2 attention, 3 wo, 4 w13, 5 w2, 6 lm-head are NOT launched
-    unsigned* head_ticket = nullptr;   // [H] counters of the in-launch split combine
-    unsigned* fuse_counters = nullptr;   // [n_local_layers] then [1] error
-    // persistent loader/consumer engine (thk_engine.hip): one launch per decode step instead of 5 per layer
-    int kv_f16 = 0;                      // tunable kv_f16 at finalize: K/V caches stored as binary16 (default 0 = f32, as the reference)
-    int engine = 0;                      // resolved at finalize (tunable "engine" and shape eligibility)
-    int eng_NS = 0, eng_v0 = 0, eng_v1 = 0, eng_nsplit = 1, eng_tc = 0;
-    unsigned long long* eng_gran = nullptr;   // all granule arrays: XG[2][E] | QG[3E] | OG[E] | UG[F] | PG[H*S*(D+2)]
-    unsigned* eng_words = nullptr;       // [0] epoch, [32] error word
-    unsigned long long* eng_trace = nullptr;   // development timeline (tunable engine_trace), [n_cu][n_ops][8]
-};
-
-// ---------------------------------------------------------------- helpers
-static int fail(thk_ctx* ctx, int code, const char* fmt, ...) {
-    char buf[512];
-    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
-    if (ctx) ctx->err = buf;
-    return code;
-}
-#define HIPCHK(ctx, call)                                                                                  \
-    do {                                                                                                   \
-        hipError_t e_ = (call);                                                                            \
-        if (e_ != hipSuccess) return fail((ctx), THK_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
-#define REQUIRE(ctx, cond, ...) do { if (!(cond)) return fail((ctx), THK_ERR_INVALID, __VA_ARGS__); } while (0)
-
-static int64_t tun(thk_ctx* ctx, const char* name) {
-    auto it = ctx->tun.find(name);
-    return it == ctx->tun.end() ? 0 : it->second;
-}
-static void default_tunables(thk_ctx* ctx) {
-    ctx->tun["gemv_blocks_per_cu"] = 4;   // resident 256-thread workgroups per CU for the streaming mat-vecs
-    // per-kernel launch geometry: -1 = auto (table below, from tools/sweep.py on MI355X, profiles/r01_sweep_*.json),
-    // 0 = gemv_blocks_per_cu / variant 0, > 0 = explicit
-    // workgroups per prefill GEMM launch (<= 256): fewer = fewer K-splits = less partial-tile traffic, but fewer CUs streaming
-    for (const char* k : {"qkv", "wo", "w13", "w2"}) { ctx->tun[std::string("prefill_blocks_") + k] = 256; ctx->tun[std::string("prefill_tile_") + k] = 256; }   // tile rows: 128 | 256
-    ctx->tun["prefill_attn_mfma"] = 1;
-    ctx->tun["prefill_tile_wo"] = 128; ctx->tun["prefill_tile_w2"] = 128;   // 16 row-blocks only: halve the 16-way split-K partials (-3 %)
-    for (const char* k : {"qkv", "wo", "w13", "w2", "head"}) {
-        ctx->tun[std::string("gemv_bpc_") + k] = -1;
-        ctx->tun[std::string("gemv_variant_") + k] = -1;   // (rows/iteration, slots/batch) variant, see gemv_variant()
-    }
-    ctx->tun["attn_splits"] = 4;          // context splits per head (1,2,4,8)
-    ctx->tun["attn_waves"] = 8;           // waves per attention block (4 or 8)
-    ctx->tun["attn_combine"] = 0;         // last-arriving split block of a head merges the partials inside the attention launch (measured: slower)
-    ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
-    ctx->tun["fuse_attn_wo"] = 0;         // attention splits + wo mat-vec in one launch (in-launch hand-off)
-    ctx->tun["measure_skip_kernel"] = 0;  // bench.py: marginal cost of one kernel = step time with minus without it (results are garbage then);
-                                          // refused unless the process runs with THK_MEASURE_HOOKS=1 (never in a product)
-    ctx->tun["kv_f16"] = 0;               // 1 = K/V caches stored as binary16 (half the KV bytes; k, v are rounded RNE at the append); default f32 as the reference
-    ctx->tun["engine_park"] = 1;          // engine variant whose waiting consumer waves park one landed ring slot in registers (more loader run-ahead)
-    ctx->tun["engine_trace"] = 0;         // development: per-op s_memtime timeline of the engine (thk_model_engine_trace)
-    ctx->tun["engine"] = 0;               // 1 = decode step as ONE persistent loader/consumer launch (thk_engine.hip) when the shape allows; default 0 = 5
-                                          // launches per layer: measured on MI355X the engine streams at 6.9-7.0 TB/s but every in-launch all-to-all hand-off
-                                          // costs ~7 us against ~3.5 us for a kernel boundary (profiles/r02_engine_*.txt), 3.4 vs 2.5 ms per 7B token
-    ctx->tun["fuse_initial_sleeps"] = 0;  // consumer s_sleep(32) repetitions (~0.85 us each) before the first poll
-}
-// Auto launch geometry per (kernel, n_embd): {blocks per CU, variant}.  7B and 13B rows are swept values; other
-// widths take the 7B row.
-struct Geo { int bpc, var; };
-static Geo auto_geometry(const char* kernel, int n_embd) {
-    const bool w13b = n_embd == 5120;
-    if (!strcmp(kernel, "qkv")) return w13b ? Geo{3, 3} : Geo{3, 0};
-    if (!strcmp(kernel, "wo")) return w13b ? Geo{2, 0} : Geo{2, 3};   // 7B: variant 3 is +0.5 % in graph mode (profiles/r01_sweep_graph_7b.json)
-    if (!strcmp(kernel, "w13")) return w13b ? Geo{8, 1} : Geo{8, 0};
-    if (!strcmp(kernel, "w2")) return Geo{2, 2};
-    if (!strcmp(kernel, "head")) return w13b ? Geo{8, 2} : Geo{8, 1};
-    return Geo{4, 0};
-}
-static int resolve_variant(thk_ctx* ctx, const char* kernel, int n_embd) {
-    const int64_t v = tun(ctx, (std::string("gemv_variant_") + kernel).c_str());
-    return v < 0 ? auto_geometry(kernel, n_embd).var : (int)v;
-}
-static int grid_for(thk_ctx* ctx, const char* specific, int n_groups, int n_embd = 4096) {
-    int64_t bpc = tun(ctx, specific);
-    if (bpc < 0 && !strncmp(specific, "gemv_bpc_", 9)) bpc = auto_geometry(specific + 9, n_embd).bpc;
-    if (bpc <= 0) bpc = tun(ctx, "gemv_blocks_per_cu");
-    if (bpc <= 0) bpc = 4;
-    int64_t g = (int64_t)ctx->n_cu * bpc;
-    const int64_t need = (n_groups + kWaves - 1) / kWaves;
-    if (g > need) g = need;
-    if (g < 1) g = 1;
-    return (int)g;
-}
-static int ensure_scratch(thk_ctx* ctx, size_t bytes) {
-    if (ctx->scratch_bytes >= bytes) return THK_OK;
-    if (ctx->scratch) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratch_bytes = 0; }
-    HIPCHK(ctx, hipMalloc(&ctx->scratch, bytes));
-    ctx->scratch_bytes = bytes;
-    return THK_OK;
-}
-// RoPE table for positions [p0, p0+n): (cos, sin) of p * 10000^(-j/D), j even — the f32
-// libm evaluation order of oracle orc_rope_angles (th.cpp:1476-1484).
-static void build_rope_table(std::vector<float>& tab, int D, int p0, int n) {
-    const int half = D / 2;
-    tab.resize((size_t)n * half * 2);
-    for (int p = 0; p < n; ++p)
-        for (int jp = 0; jp < half; ++jp) {
-            const float theta = powf(10000.0f, (-(float)(2 * jp)) / (float)D);
-            const float pf = (float)(p0 + p);
-            tab[((size_t)p * half + jp) * 2] = cosf(pf * theta);
-            tab[((size_t)p * half + jp) * 2 + 1] = sinf(pf * theta);
-        }
-}
-static uint64_t splitmix64_h(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-static uint64_t synth_key(const char* name, uint64_t seed) {
-    uint64_t h = 0xCBF29CE484222325ull;
-    for (const unsigned char* p = (const unsigned char*)name; *p; ++p) { h ^= *p; h *= 0x100000001B3ull; }
-    return h ^ splitmix64_h(seed);
-}
-static float synth_scale(float sigma) { return (float)((double)sigma / 37837.2275); }
-
-// hooks for thk_pp.cpp (same library, different translation unit)
-namespace thk {
-int ctx_fail(thk_ctx* ctx, int code, const char* msg) { return fail(ctx, code, "%s", msg); }
-int ctx_device(thk_ctx* ctx) { return ctx ? ctx->device : 0; }
-}
-
-// ---------------------------------------------------------------- context
-extern "C" int thk_abi_version(void) { return THK_ABI_VERSION; }
-
-static int ctx_create_common(int device, hipStream_t stream, bool own, thk_ctx** out) {
-    if (!out) return THK_ERR_INVALID;
-    *out = nullptr;
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return THK_ERR_HIP;
-    if (device < 0 || device >= count) return THK_ERR_INVALID;
-    thk_ctx* ctx = new thk_ctx();
-    ctx->device = device;
-    if (hipSetDevice(device) != hipSuccess) { delete ctx; return THK_ERR_HIP; }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
-        ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        ctx->hbm_bytes = prop.totalGlobalMem;
-        ctx->dev_name = prop.name;
-    }
-    if (own) {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return THK_ERR_HIP; }
-        ctx->own_stream = true;
-    } else {
-        ctx->stream = stream;
-    }
-    default_tunables(ctx);
-    *out = ctx;
-    return THK_OK;
-}
-extern "C" int thk_ctx_create(int device_ordinal, thk_ctx** out) { return ctx_create_common(device_ordinal, nullptr, true, out); }
-extern "C" int thk_ctx_create_on_stream(int device_ordinal, void* hip_stream, thk_ctx** out) {
-    return ctx_create_common(device_ordinal, (hipStream_t)hip_stream, false, out);
-}
-extern "C" int thk_ctx_destroy(thk_ctx* ctx) {
-    if (!ctx) return THK_OK;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    if (ctx->scratch) hipFree(ctx->scratch);
-    if (ctx->rope_tab) hipFree(ctx->rope_tab);
-    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
-    delete ctx;
-    return THK_OK;
-}
-extern "C" int thk_sync(thk_ctx* ctx) {
-    if (!ctx) return THK_ERR_INVALID;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return THK_OK;
-}
-extern "C" const char* thk_last_error(thk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-extern "C" void* thk_ctx_stream(thk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
-extern "C" int thk_ctx_device_info(thk_ctx* ctx, char* name, size_t name_cap, int* n_cu, size_t* hbm_bytes) {
-    if (!ctx) return THK_ERR_INVALID;
-    if (name && name_cap) { strncpy(name, ctx->dev_name.c_str(), name_cap - 1); name[name_cap - 1] = 0; }
-    if (n_cu) *n_cu = ctx->n_cu;
-    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
-    return THK_OK;
-}
-extern "C" int thk_set_tunable(thk_ctx* ctx, const char* name, int64_t value) {
-    if (!ctx || !name) return THK_ERR_INVALID;
-    auto it = ctx->tun.find(name);
-    if (it == ctx->tun.end()) return fail(ctx, THK_ERR_NOTFOUND, "unknown tunable '%s'", name);
-    if (!strcmp(name, "measure_skip_kernel") && value != 0) {
-        const char* hook = getenv("THK_MEASURE_HOOKS");
-        if (!hook || strcmp(hook, "1")) return fail(ctx, THK_ERR_INVALID, "measure_skip_kernel makes a model skip work; it is only accepted with THK_MEASURE_HOOKS=1 in the environment");
-    }
-    it->second = value;
-    return THK_OK;
-}
-extern "C" int thk_get_tunable(thk_ctx* ctx, const char* name, int64_t* value) {
-    if (!ctx || !name || !value) return THK_ERR_INVALID;
-    auto it = ctx->tun.find(name);
-    if (it == ctx->tun.end()) return fail(ctx, THK_ERR_NOTFOUND, "unknown tunable '%s'", name);
-    *value = it->second;
-    return THK_OK;
-}
-
-// ---------------------------------------------------------------- buffers
-extern "C" int thk_buf_alloc(thk_ctx* ctx, size_t bytes, thk_buf** out) {
-    if (!ctx || !out) return THK_ERR_INVALID;
-    *out = nullptr;
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    thk_buf* b = new thk_buf();
-    b->size = bytes;
-    hipError_t e = hipMalloc(&b->ptr, bytes ? bytes : 1);
-    if (e != hipSuccess) { delete b; return fail(ctx, e == hipErrorOutOfMemory ? THK_ERR_OOM : THK_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
-    e = hipMemsetAsync(b->ptr, 0, bytes ? bytes : 1, ctx->stream);
-    if (e != hipSuccess) { hipFree(b->ptr); delete b; return fail(ctx, THK_ERR_HIP, "hipMemsetAsync: %s", hipGetErrorString(e)); }
-    *out = b;
-    return THK_OK;
-}
-extern "C" int thk_buf_free(thk_ctx* ctx, thk_buf* buf) {
-    if (!buf) return THK_OK;
-    if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
-    if (buf->ptr) hipFree(buf->ptr);
-    delete buf;
-    return THK_OK;
-}
-extern "C" void* thk_buf_ptr(thk_buf* buf) { return buf ? buf->ptr : nullptr; }
-extern "C" size_t thk_buf_size(thk_buf* buf) { return buf ? buf->size : 0; }
-extern "C" int thk_buf_upload(thk_ctx* ctx, thk_buf* dst, size_t dst_off, const void* host, size_t bytes) {
-    if (!ctx || !dst || (!host && bytes)) return THK_ERR_INVALID;
-    REQUIRE(ctx, dst_off + bytes <= dst->size, "upload of %zu bytes at %zu exceeds buffer of %zu", bytes, dst_off, dst->size);
-    HIPCHK(ctx, hipMemcpyAsync((char*)dst->ptr + dst_off, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_buf_download(thk_ctx* ctx, thk_buf* src, size_t src_off, void* host, size_t bytes) {
-    if (!ctx || !src || (!host && bytes)) return THK_ERR_INVALID;
-    REQUIRE(ctx, src_off + bytes <= src->size, "download of %zu bytes at %zu exceeds buffer of %zu", bytes, src_off, src->size);
-    HIPCHK(ctx, hipMemcpyAsync(host, (const char*)src->ptr + src_off, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_buf_copy(thk_ctx* ctx, thk_buf* dst, size_t dst_off, thk_buf* src, size_t src_off, size_t bytes) {
-    if (!ctx || !dst || !src) return THK_ERR_INVALID;
-    REQUIRE(ctx, dst_off + bytes <= dst->size && src_off + bytes <= src->size, "copy range out of bounds");
-    HIPCHK(ctx, hipMemcpyAsync((char*)dst->ptr + dst_off, (const char*)src->ptr + src_off, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    return THK_OK;
-}
-
-// ---------------------------------------------------------------- operators
-static int gemv_simple(thk_ctx* ctx, int pro, int epi, const char* var_name, const char* bpc_name, GemvArgs& a, int rows) {
-    int nru = (int)tun(ctx, var_name);
-    if (nru < 0) nru = auto_geometry(var_name + 13 /* past "gemv_variant_" */, a.C == 5120 ? 5120 : 4096).var;
-    const int NR = gemv_rows_per_group(a.C, epi, nru);
-    a.n_groups = (rows + NR - 1) / NR;
-    const int grid = grid_for(ctx, bpc_name, a.n_groups, a.C == 5120 ? 5120 : 4096);
-    HIPCHK(ctx, launch_gemv(pro, epi, nru, a, grid, true, ctx->stream));
-    return grid;
-}
-
-extern "C" int thk_matvec_f16(thk_ctx* ctx, const void* W, int64_t R, int64_t C, const float* x, float* y) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, W && x && y && R > 0, "thk_matvec_f16: null pointer or empty matrix");
-    REQUIRE(ctx, C >= 256 && C % 256 == 0, "thk_matvec_f16: C=%lld must be a multiple of 256 (th.cpp:2996-3006)", (long long)C);
-    REQUIRE(ctx, C <= 32768 && R <= 0x7FFFFFFF, "thk_matvec_f16: shape too large");
-    GemvArgs a{}; a.W[0] = (const uint16_t*)W; a.R = (int)R; a.C = (int)C; a.x = x; a.y = y;
-    const int rc = gemv_simple(ctx, GEMV_PRO_COPY, GEMV_EPI_STORE, C > 8192 ? "gemv_variant_w2" : "gemv_variant_wo", "gemv_blocks_per_cu", a, (int)R);
-    return rc < 0 ? rc : THK_OK;
-}
-extern "C" int thk_rms_norm(thk_ctx* ctx, float* x, int64_t rows, int64_t N) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, x && rows > 0 && N > 0, "thk_rms_norm: bad arguments");
-    REQUIRE(ctx, N % 256 == 0, "thk_rms_norm: N=%lld must be a multiple of 256 (th.cpp:1155)", (long long)N);
-    HIPCHK(ctx, launch_rms_norm(x, (int)rows, (int)N, ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_row_element_multiply(thk_ctx* ctx, float* x, const float* gain, int64_t rows, int64_t N) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, x && gain && rows > 0 && N > 0, "thk_row_element_multiply: bad arguments");
-    HIPCHK(ctx, launch_row_mul(x, gain, (int)rows, (int)N, ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_rope(thk_ctx* ctx, float* x, int64_t n_tok, int64_t H, int64_t D, int64_t n_past) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, x && n_tok > 0 && H > 0 && D > 0 && D % 2 == 0 && n_past >= 0, "thk_rope: bad arguments");
-    std::vector<float> tab;
-    build_rope_table(tab, (int)D, (int)n_past, (int)n_tok);
-    if (ctx->rope_tab_floats < tab.size()) {
-        if (ctx->rope_tab) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(ctx->rope_tab)); ctx->rope_tab = nullptr; }
-        HIPCHK(ctx, hipMalloc((void**)&ctx->rope_tab, tab.size() * 4));
-        ctx->rope_tab_floats = tab.size();
-    }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->rope_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // tab is a stack-lifetime host buffer
-    HIPCHK(ctx, launch_rope(x, ctx->rope_tab, (int)n_tok, (int)H, (int)D, 0, ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_kv_append(thk_ctx* ctx, float* kcache, float* vcache, const float* k, const float* v, int64_t pos, int64_t H, int64_t D) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, kcache && vcache && k && v && pos >= 0 && H > 0 && D > 0, "thk_kv_append: bad arguments");
-    HIPCHK(ctx, launch_kv_append(kcache, vcache, k, v, (int)pos, (int)(H * D), ctx->stream));
-    return THK_OK;
-}
-static int valid_head_dim(int64_t D) { return D == 64 || D == 128 || D == 256; }
-static int valid_splits(int64_t s) { return s == 1 || s == 2 || s == 4 || s == 8; }
-
-extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache, const float* vcache, int64_t T, int64_t H, int64_t D, float* out) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, q && kcache && vcache && out && T > 0 && H > 0, "thk_attn_decode: bad arguments");
-    REQUIRE(ctx, valid_head_dim(D), "thk_attn_decode: head dim %lld not in {64,128,256}", (long long)D);
-    int nsplit = (int)tun(ctx, "attn_splits");
-    REQUIRE(ctx, valid_splits(nsplit), "attn_splits must be 1, 2, 4 or 8");
-    const size_t need = (size_t)H * nsplit * (D + 2) * 4;
-    int rc = ensure_scratch(ctx, need < (1u << 20) ? (1u << 20) : need);
-    if (rc != THK_OK) return rc;
-    AttnArgs a{};
-    a.q = q; a.kcache = kcache; a.vcache = vcache; a.pos_ptr = nullptr; a.pos_val = (int)T - 1;
-    a.H = (int)H; a.D = (int)D; a.nsplit = nsplit; a.tc = (int)((T + nsplit - 1) / nsplit);
-    a.scale = 1.0f / sqrtf((float)D); a.waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
-    a.part_o = (float*)ctx->scratch; a.part_ml = a.part_o + (size_t)H * nsplit * D;
-    a.out = nsplit == 1 ? out : nullptr;
-    HIPCHK(ctx, launch_attn_decode(a, ctx->stream));
-    if (nsplit > 1) HIPCHK(ctx, launch_attn_combine(a.part_o, a.part_ml, out, (int)H, (int)D, nsplit, ctx->stream));
-    return THK_OK;
-}
-// MFMA tile kernel for D = 64 | 128 (tunable prefill_attn_mfma, default on); otherwise one workgroup per (head, query)
-static hipError_t attn_prefill_dispatch(thk_ctx* ctx, const float* q, const float* kc, const float* vc, int n_past, int M, int H, int D, float* out, bool kv_f16 = false) {
-    if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) return launch_attn_prefill_mfma(q, kc, vc, kv_f16, n_past, M, H, D, out, nullptr, ctx->stream);
-    AttnArgs a{};
-    a.kv_f16 = kv_f16 ? 1 : 0;
-    a.q = q; a.kcache = kc; a.vcache = vc; a.pos_ptr = nullptr; a.pos_val = n_past; a.H = H; a.D = D;
-    a.nsplit = 1; a.tc = n_past + M; a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = M; a.out = out;
-    return launch_attn_decode(a, ctx->stream);
-}
-extern "C" int thk_attn_prefill(thk_ctx* ctx, const float* q, const float* kcache, const float* vcache, int64_t n_past, int64_t M, int64_t H, int64_t D, float* out) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, q && kcache && vcache && out && M > 0 && H > 0 && n_past >= 0, "thk_attn_prefill: bad arguments");
-    REQUIRE(ctx, valid_head_dim(D), "thk_attn_prefill: head dim %lld not in {64,128,256}", (long long)D);
-    REQUIRE(ctx, n_past + M <= 0x7FFFFFFF / (H * D), "thk_attn_prefill: shape too large");
-    HIPCHK(ctx, attn_prefill_dispatch(ctx, q, kcache, vcache, (int)n_past, (int)M, (int)H, (int)D, out));
-    return THK_OK;
-}
-extern "C" int thk_row_softmax(thk_ctx* ctx, float* x, int64_t rows, int64_t N) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, x && rows > 0 && N > 0, "thk_row_softmax: bad arguments");
-    HIPCHK(ctx, launch_row_softmax(x, (int)rows, (int)N, ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_add(thk_ctx* ctx, const float* a, const float* b, float* c, int64_t n) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, a && b && c && n > 0, "thk_add: bad arguments");
-    HIPCHK(ctx, launch_add(a, b, c, (size_t)n, ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_silu(thk_ctx* ctx, float* x, int64_t n) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, x && n > 0, "thk_silu: bad arguments");
-    HIPCHK(ctx, launch_silu(x, (size_t)n, ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_mul_inplace(thk_ctx* ctx, float* a, const float* b, int64_t n) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, a && b && n > 0, "thk_mul_inplace: bad arguments");
-    HIPCHK(ctx, launch_mul(a, b, (size_t)n, ctx->stream));
-    return THK_OK;
-}
-static void q1_constants(int V, int* split, int* cov) {   // th.cpp:3990-3996 with numSplits = 8 (th-llama.cpp:262)
-    int s = V / 8; if (s < 1) s = 1;
-    int kTile = s / 256; if (kTile == 0) kTile = 1;
-    int c = 256 * kTile; if (c > s) c = s;
-    *split = s; *cov = c;
-}
-extern "C" int thk_lmhead_f16(thk_ctx* ctx, const void* W, int64_t V, int64_t E, const float* x, float* logits, int mode) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, W && x && logits && V > 0, "thk_lmhead_f16: bad arguments");
-    REQUIRE(ctx, E >= 512 && E % 512 == 0, "thk_lmhead_f16: E=%lld must be a multiple of 512 (th.cpp:3728-3739)", (long long)E);
-    REQUIRE(ctx, mode == THK_LMHEAD_CORRECT || mode == THK_LMHEAD_FAITHFUL, "thk_lmhead_f16: bad mode");
-    int rc = ensure_scratch(ctx, 1u << 20);
-    if (rc != THK_OK) return rc;
-    GemvArgs a{}; a.W[0] = (const uint16_t*)W; a.R = (int)V; a.C = (int)E; a.x = x; a.y = logits;
-    a.lm_faithful = mode == THK_LMHEAD_FAITHFUL; q1_constants((int)V, &a.q1_split, &a.q1_cov);
-    a.block_best = (unsigned long long*)ctx->scratch;
-    rc = gemv_simple(ctx, GEMV_PRO_COPY, GEMV_EPI_HEAD, "gemv_variant_head", "gemv_bpc_head", a, (int)V);
-    return rc < 0 ? rc : THK_OK;
-}
-extern "C" int thk_argmax(thk_ctx* ctx, const float* logits, int64_t V, int32_t* id_out) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, logits && id_out && V > 0, "thk_argmax: bad arguments");
-    int rc = ensure_scratch(ctx, 1u << 20);
-    if (rc != THK_OK) return rc;
-    int nblocks = (int)((V + kBlock - 1) / kBlock); if (nblocks > 256) nblocks = 256;
-    HIPCHK(ctx, launch_argmax(logits, (int)V, (unsigned long long*)ctx->scratch, nblocks, ctx->stream));
-    HIPCHK(ctx, launch_finish_token((const unsigned long long*)ctx->scratch, nblocks, nullptr, nullptr, 0, nullptr, id_out, 0, nullptr, ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_embed_f16(thk_ctx* ctx, const void* table, int64_t E, int32_t token, float* x) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, table && x && E > 0 && token >= 0, "thk_embed_f16: bad arguments");
-    HIPCHK(ctx, launch_embed((const uint16_t*)table, nullptr, token, (int)E, x, ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_synth_f16(thk_ctx* ctx, const char* name, uint64_t seed, float sigma, int64_t n, void* out) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, name && out && n > 0, "thk_synth_f16: bad arguments");
-    HIPCHK(ctx, launch_synth_f16(synth_key(name, seed), synth_scale(sigma), (size_t)n, out, ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_synth_gain_f32(thk_ctx* ctx, const char* name, uint64_t seed, float sigma, int64_t n, float* out) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, name && out && n > 0, "thk_synth_gain_f32: bad arguments");
-    HIPCHK(ctx, launch_synth_gain(synth_key(name, seed), synth_scale(sigma), (size_t)n, out, ctx->stream));
-    return THK_OK;
-}
-extern "C" int thk_gemm_f16_prefill(thk_ctx* ctx, const void* W, int64_t R, int64_t C, const float* X, int64_t M, float* Y) {
-    if (!ctx) return THK_ERR_INVALID;
-    REQUIRE(ctx, W && X && Y && R > 0 && M > 0, "thk_gemm_f16_prefill: bad arguments");
-    REQUIRE(ctx, C >= 32 && C % 32 == 0, "thk_gemm_f16_prefill: C=%lld must be a multiple of 32", (long long)C);
-    const size_t ws = gemm_prefill_workspace_bytes((int)M, (int)R, (int)C);
-    int rc = ensure_scratch(ctx, ws < (1u << 20) ? (1u << 20) : ws);
-    if (rc != THK_OK) return rc;
-    HIPCHK(ctx, launch_gemm_f16_prefill((const uint16_t*)W, (int)R, (int)C, X, (int)M, Y, ctx->scratch, ctx->stream));
-    return THK_OK;
-}
+// thk_model.cpp — the model level of the C-ABI: th_eval_gpu (th-llama.cpp:464-660) as ONE hipGraph replay per decode step
+// (embed, 5 fused kernels per layer, lm-head + greedy pick; reference: 773 dispatches, 129 copies and a blocking map-read
+// per token) or as one persistent engine launch (thk_engine.hip), the MFMA prompt prefill, layer-range pipeline stages.
+#include "thk_internal.hpp"
 
 // ---------------------------------------------------------------- model
 static int n_ff_of(const thk_hparams& hp) { return ((2 * (4 * hp.n_embd) / 3 + hp.n_mult - 1) / hp.n_mult) * hp.n_mult; }   // loader :349

@@ -17,7 +17,7 @@
 #include <string.h>
 #include <string>
 
-struct thk_ctx;   // defined in thk_capi.cpp
+struct thk_ctx;   // defined in thk_internal.hpp
 extern "C" void* thk_ctx_stream(thk_ctx* ctx);
 namespace thk { int ctx_fail(thk_ctx* ctx, int code, const char* msg); int ctx_device(thk_ctx* ctx); }
 

@@ -197,7 +197,6 @@ std::shared_ptr<LlamaModel> load_llama_file(thk_ctx* ctx, const std::string& fil
         if (n_dims < 1 || n_dims > 3 || name_len < 0 || name_len > 512) { fail_load(m.get(), "load_llama_file: malformed tensor header"); return {}; }
         const int64_t head = 12 + 4 * n_dims + name_len;
         if ((int64_t)got < head) { fail_load(m.get(), "load_llama_file: truncated tensor header"); return {}; }
-        int64_t ne[3] = {1, 1, 1};
         int32_t ftype; memcpy(&ftype, hdr + 8, 4);
         const int64_t elt = ftype == kftype_f32 ? 4 : ftype == kftype_f16 ? 2 : 0;
         if (elt == 0) { fail_load(m.get(), "load_llama_file: quantized formats are not supported"); return {}; }
@@ -206,7 +205,7 @@ std::shared_ptr<LlamaModel> load_llama_file(thk_ctx* ctx, const std::string& fil
         int64_t count = 1;
         bool dims_ok = true;
         for (int i = 0; i < n_dims; ++i) {
-            int32_t v; memcpy(&v, hdr + 12 + 4 * i, 4); ne[i] = v;
+            int32_t v; memcpy(&v, hdr + 12 + 4 * i, 4);
             if (v <= 0 || count > file_size / elt / v) { dims_ok = false; break; }
             count *= v;
         }
