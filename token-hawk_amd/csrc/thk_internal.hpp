@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <array>
 #include <vector>
 
 using namespace thk;
@@ -89,6 +90,12 @@ struct thk_model {
     int var_qkv = 0, var_wo = 0, var_w13 = 0, var_w2 = 0, var_head = 0;
     int grid_qkv = 0, grid_wo = 0, grid_w13 = 0, grid_w2 = 0, grid_head = 0;
     void* prefill_ws = nullptr; size_t prefill_ws_bytes = 0;
+    // tile images of the layer matrices for the prefill GEMM (tunable prefill_packed; built on the first prefill call, one slab for
+    // the whole stage = a second copy of the layer weights): pk_w[layer][wq wk wv wo w1 w2 w3]
+    void* prefill_pk = nullptr; size_t prefill_pk_bytes = 0;
+    int pk_tiles[4] = {0, 0, 0, 0};      // tile rows (qkv, wo, w13, w2) the images were made with; 0 = none
+    bool pk_failed = false;              // the slab did not fit once: stay on row-major weights
+    std::vector<std::array<const uint16_t*, 7>> pk_w;
     // fused attention+wo launch: per-layer arrival counters (zeroed at the start of every step) + error word
     int fuse_attn_wo = 0, fuse_initial_sleeps = 0, attn_waves = 8, attn_combine = 0;
     int skip_kernel = 0;   // measurement aid (tunable measure_skip_kernel): 1 qkv, 2 attention, 3 wo, 4 w13, 5 w2, 6 lm-head are NOT launched

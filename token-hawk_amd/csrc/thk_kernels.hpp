@@ -147,11 +147,14 @@ size_t gemm_prefill_workspace_bytes(int M, int R, int C);
 // kernel that carries the fused epilogue.  M <= 128 tokens per call.
 struct PrefillPlan {
     int M, MT, Mpad, R, Rpad, nmat, C, nchunks, rb_per_mat, rb_total, per, maxseg, G, tile_rows;
+    int packed;         // 1: W[] point at tile images made by launch_prefill_pack with this plan's tile_rows (linear `nt` stream), 0: row-major matrices
     size_t ximg_bytes, slot_floats, part_floats;
 };
 PrefillPlan prefill_plan(int M, int R, int nmat, int C, int G /* workgroups; 0 = default (256) */, int tile_rows /* 128 | 256 (default) */);
 hipError_t launch_prefill_ximg(const float* X, const float* gain_or_null, int M, int C, void* ximg, hipStream_t st);
 hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, const void* ximg, float* part, hipStream_t st);
+size_t prefill_pack_bytes(int R, int C, int tile_rows);
+hipError_t launch_prefill_pack(const uint16_t* W, int R, int C, int tile_rows, void* out, hipStream_t st);
 hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st);
 hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, void* kcache, void* vcache, bool kv_f16, hipStream_t st);
 // causal attention for the M queries of a slab (D = 64 | 128), f32-class accuracy on MFMA

@@ -52,7 +52,8 @@ static void free_working(thk_model* m) {
     for (auto& s : m->seqs) free_seq(s);
     m->seqs.clear();
     hipFree(m->x); hipFree(m->q); hipFree(m->u); hipFree(m->attn_out); hipFree(m->part_o); hipFree(m->part_ml); hipFree(m->block_best); hipFree(m->rope_tab);
-    hipFree(m->prefill_ws); hipFree(m->fuse_counters); m->fuse_counters = nullptr; hipFree(m->head_ticket); m->head_ticket = nullptr;
+    hipFree(m->prefill_ws); hipFree(m->prefill_pk); m->prefill_pk = nullptr; m->prefill_pk_bytes = 0; m->pk_w.clear(); m->pk_tiles[0] = 0; m->pk_failed = false;
+    hipFree(m->fuse_counters); m->fuse_counters = nullptr; hipFree(m->head_ticket); m->head_ticket = nullptr;
     hipFree(m->eng_trace); m->eng_trace = nullptr;
     hipFree(m->eng_gran); m->eng_gran = nullptr; hipFree(m->eng_words); m->eng_words = nullptr; m->engine = 0;
     m->x = m->q = m->u = m->attn_out = m->part_o = m->part_ml = nullptr; m->block_best = nullptr; m->rope_tab = nullptr;
@@ -118,6 +119,7 @@ extern "C" int thk_model_set_tensor(thk_model* m, const char* name, int dtype, i
     REQUIRE(ctx, t == dtype, "tensor '%s': dtype %d expected %d (only GGML f16 models are supported, README.md:5)", name, dtype, t);
     if (rc == 1) return THK_OK;   // another stage owns it
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    m->pk_tiles[0] = 0; m->pk_w.clear();   // the prefill tile images are stale now
     HIPCHK(ctx, hipMemcpyAsync(dst, host, (size_t)(c * r) * (t == THK_F16 ? 2 : 4), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return THK_OK;
@@ -135,6 +137,7 @@ extern "C" int thk_model_set_tensor_dev(thk_model* m, const char* name, int dtyp
     REQUIRE(ctx, t == dtype, "tensor '%s': dtype %d expected %d (only GGML f16 models are supported, README.md:5)", name, dtype, t);
     if (rc == 1) return THK_OK;   // another stage owns it
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    m->pk_tiles[0] = 0; m->pk_w.clear();
     HIPCHK(ctx, hipMemcpyAsync(dst, dev_ptr, (size_t)(c * r) * (t == THK_F16 ? 2 : 4), hipMemcpyDeviceToDevice, ctx->stream));
     return THK_OK;
 }
@@ -145,6 +148,7 @@ extern "C" int thk_model_fill_synthetic(thk_model* m, uint64_t seed, float sigma
     const float sc = synth_scale(sigma);
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    m->pk_tiles[0] = 0; m->pk_w.clear();
     if (m->tok_embeddings) HIPCHK(ctx, launch_synth_f16(synth_key("tok_embeddings.weight", seed), sc, V * E, m->tok_embeddings, st));
     if (m->norm) HIPCHK(ctx, launch_synth_gain(synth_key("norm.weight", seed), sc, E, m->norm, st));
     if (m->output) HIPCHK(ctx, launch_synth_f16(synth_key("output.weight", seed), sc, V * E, m->output, st));
@@ -740,6 +744,41 @@ static int prefill_workspace(thk_model* m, PrefillBufs* b) {
     return THK_OK;
 }
 
+// Tile images of this stage's layer matrices (thk_prefill.hip, pack_w_kernel): made on the first prefill call and again when a
+// prefill_tile_* tunable changes.  Costs a second copy of the layer weights in HBM (12.4 GB for 7B of 288); if that does not
+// fit the GEMMs stay on the row-major matrices (still the HIP path, ~20 % slower).
+static int ensure_prefill_pack(thk_model* m) {
+    thk_ctx* ctx = m->ctx;
+    if (tun(ctx, "prefill_packed") == 0 || m->pk_failed) return THK_OK;
+    const int E = m->hp.n_embd, F = m->n_ff, nl = m->l1 - m->l0;
+    const int tiles[4] = {(int)tun(ctx, "prefill_tile_qkv") == 128 ? 128 : 256, (int)tun(ctx, "prefill_tile_wo") == 128 ? 128 : 256,
+                          (int)tun(ctx, "prefill_tile_w13") == 128 ? 128 : 256, (int)tun(ctx, "prefill_tile_w2") == 128 ? 128 : 256};
+    if (m->prefill_pk && !m->pk_w.empty() && !memcmp(tiles, m->pk_tiles, sizeof tiles)) return THK_OK;
+    // wq wk wv wo w1 w2 w3: (rows, cols, tile)
+    const int R[7] = {E, E, E, E, F, E, F}, C[7] = {E, E, E, E, E, F, E}, T[7] = {tiles[0], tiles[0], tiles[0], tiles[1], tiles[2], tiles[3], tiles[2]};
+    size_t per_layer = 0, off[7];
+    for (int k = 0; k < 7; ++k) { off[k] = per_layer; per_layer += (prefill_pack_bytes(R[k], C[k], T[k]) + 255) / 256 * 256; }
+    const size_t bytes = per_layer * nl;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (m->prefill_pk_bytes < bytes) {
+        hipFree(m->prefill_pk); m->prefill_pk = nullptr; m->prefill_pk_bytes = 0;
+        if (hipMalloc(&m->prefill_pk, bytes) != hipSuccess) { (void)hipGetLastError(); m->prefill_pk = nullptr; m->pk_failed = true; m->pk_w.clear(); m->pk_tiles[0] = 0; return THK_OK; }
+        m->prefill_pk_bytes = bytes;
+    }
+    m->pk_w.assign(nl, {});
+    for (int i = 0; i < nl; ++i) {
+        const LayerW& L = m->layers[i];
+        const uint16_t* src[7] = {L.wq, L.wk, L.wv, L.wo, L.w1, L.w2, L.w3};
+        for (int k = 0; k < 7; ++k) {
+            char* dst = (char*)m->prefill_pk + (size_t)i * per_layer + off[k];
+            HIPCHK(ctx, launch_prefill_pack(src[k], R[k], C[k], T[k], dst, ctx->stream));
+            m->pk_w[i][k] = reinterpret_cast<const uint16_t*>(dst);
+        }
+    }
+    memcpy(m->pk_tiles, tiles, sizeof tiles);
+    return THK_OK;
+}
+
 // one slab of M <= 128 prompt tokens at positions [n_past, n_past + M) through every layer
 static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const int32_t* tokens, int M, int n_past) {
     thk_ctx* ctx = m->ctx;
@@ -748,7 +787,9 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
     const int g_qkv = (int)tun(ctx, "prefill_blocks_qkv"), g_wo = (int)tun(ctx, "prefill_blocks_wo"), g_w13 = (int)tun(ctx, "prefill_blocks_w13"), g_w2 = (int)tun(ctx, "prefill_blocks_w2");
     REQUIRE(ctx, g_qkv >= 1 && g_qkv <= 256 && g_wo >= 1 && g_wo <= 256 && g_w13 >= 1 && g_w13 <= 256 && g_w2 >= 1 && g_w2 <= 256, "prefill_blocks_* tunables must be in [1, 256]");
     const int t_qkv = (int)tun(ctx, "prefill_tile_qkv"), t_wo = (int)tun(ctx, "prefill_tile_wo"), t_w13 = (int)tun(ctx, "prefill_tile_w13"), t_w2 = (int)tun(ctx, "prefill_tile_w2");
-    const PrefillPlan pq = prefill_plan(M, E, 3, E, g_qkv, t_qkv), po = prefill_plan(M, E, 1, E, g_wo, t_wo), p13 = prefill_plan(M, F, 2, E, g_w13, t_w13), p2 = prefill_plan(M, E, 1, F, g_w2, t_w2);
+    PrefillPlan pq = prefill_plan(M, E, 3, E, g_qkv, t_qkv), po = prefill_plan(M, E, 1, E, g_wo, t_wo), p13 = prefill_plan(M, F, 2, E, g_w13, t_w13), p2 = prefill_plan(M, E, 1, F, g_w2, t_w2);
+    const bool pk = !m->pk_w.empty() && m->pk_tiles[0] == pq.tile_rows && m->pk_tiles[1] == po.tile_rows && m->pk_tiles[2] == p13.tile_rows && m->pk_tiles[3] == p2.tile_rows;
+    pq.packed = po.packed = p13.packed = p2.packed = pk ? 1 : 0;
     HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));   // tokens may be a stack buffer
     HIPCHK(ctx, launch_embed_rows(m->tok_embeddings, b.tok, M, E, b.X, st));
@@ -756,8 +797,10 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
         const LayerW& L = m->layers[i];
         float* kc = kcache_of(m, sb, i);
         float* vc = vcache_of(m, sb, i);
-        const uint16_t* wqkv[3] = {L.wq, L.wk, L.wv};
-        const uint16_t* w13[2] = {L.w1, L.w3};
+        const uint16_t* wqkv[3] = {pk ? m->pk_w[i][0] : L.wq, pk ? m->pk_w[i][1] : L.wk, pk ? m->pk_w[i][2] : L.wv};
+        const uint16_t* w13[2] = {pk ? m->pk_w[i][4] : L.w1, pk ? m->pk_w[i][6] : L.w3};
+        const uint16_t* wo = pk ? m->pk_w[i][3] : L.wo;
+        const uint16_t* w2 = pk ? m->pk_w[i][5] : L.w2;
         HIPCHK(ctx, launch_prefill_ximg(b.X, L.attention_norm, M, E, b.imgE, st));
         HIPCHK(ctx, launch_prefill_gemm(wqkv, pq, b.imgE, b.part, st));
         HIPCHK(ctx, launch_prefill_reduce_qkv(b.part, pq, m->rope_tab, n_past, D, b.Q, kc, vc, m->kv_f16 != 0, st));
@@ -767,12 +810,12 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
             HIPCHK(ctx, attn_prefill_dispatch(ctx, b.Q, kc, vc, n_past, M, H, D, b.ATT, m->kv_f16 != 0));
             HIPCHK(ctx, launch_prefill_ximg(b.ATT, nullptr, M, E, b.imgE, st));
         }
-        HIPCHK(ctx, launch_prefill_gemm(&L.wo, po, b.imgE, b.part, st));
+        HIPCHK(ctx, launch_prefill_gemm(&wo, po, b.imgE, b.part, st));
         HIPCHK(ctx, launch_prefill_reduce_store(b.part, po, b.X, true, st));
         HIPCHK(ctx, launch_prefill_ximg(b.X, L.ffn_norm, M, E, b.imgE, st));
         HIPCHK(ctx, launch_prefill_gemm(w13, p13, b.imgE, b.part, st));
         HIPCHK(ctx, launch_prefill_reduce_swiglu(b.part, p13, b.imgF, st));
-        HIPCHK(ctx, launch_prefill_gemm(&L.w2, p2, b.imgF, b.part, st));
+        HIPCHK(ctx, launch_prefill_gemm(&w2, p2, b.imgF, b.part, st));
         HIPCHK(ctx, launch_prefill_reduce_store(b.part, p2, b.X, true, st));
     }
     return THK_OK;
@@ -791,6 +834,7 @@ extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* token
     PrefillBufs b{};
     int rc = prefill_workspace(m, &b);
     if (rc != THK_OK) return rc;
+    if ((rc = ensure_prefill_pack(m)) != THK_OK) return rc;
     hipStream_t st = ctx->stream;
     SeqBuf& sb = m->seqs[seq];
     const int E = m->hp.n_embd, V = m->hp.n_vocab, M = n_tokens;

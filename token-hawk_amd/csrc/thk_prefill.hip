@@ -116,8 +116,38 @@ __device__ __forceinline__ void v3_issue_chunk(char* sb, const char* xs /* image
         glds16(wcol + (size_t)row * C, sb + XI + (wave * 2 * NF + j) * 1024);
     }
 }
+// The same chunk when the matrix has been repacked into tile images (pack_w_kernel below): the W half of the stage is one
+// contiguous TR x 64-byte block in global memory, so the loader is a linear copy of full 128-byte lines that nobody else
+// reads => `nt`.  (Row-major weights make every instruction touch 16 rows = 16 DRAM pages, 64 bytes each, and the chip
+// keeps 65536 rows in rotation: the stream tops out at ~4.7 TB/s, profiles/r01_glds_rate_probe.txt.)
+template <int MT, int NF>
+__device__ __forceinline__ void v3_issue_chunk_packed(char* sb, const char* xs, const char* wtile /* tile image of (row-block, chunk) + lane*16 */, int wave) {
+    constexpr int XI = MT * 32 * 64 * 2;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) glds16(xs + (wave + 4 * i) * 1024, sb + (wave + 4 * i) * 1024);
+#pragma unroll
+    for (int j = 0; j < 2 * NF; ++j) glds16<2>(wtile + (wave * 2 * NF + j) * 1024, sb + XI + (wave * 2 * NF + j) * 1024);
+}
 
-template <int MT, int NF /* 32-row fragments per wave: 2 (256-row tile) or 1 (128-row tile) */, int NST = kNST>
+// load number k (0 .. MT + 2 NF - 1) of a chunk, same destinations as the two functions above
+template <int MT, int NF, bool PK>
+__device__ __forceinline__ void v3_issue_one(int k, char* sb, const char* xs, const char* wsrc /* PK: tile image + lane*16; else matrix + chunk column + piece */,
+                                             int row0, int R, int C, int wave) {
+    constexpr int XI = MT * 32 * 64 * 2;
+    if (k < MT) { glds16(xs + (wave + 4 * k) * 1024, sb + (wave + 4 * k) * 1024); return; }
+    const int j = k - MT;
+    if (PK) { glds16<2>(wsrc + (wave * 2 * NF + j) * 1024, sb + XI + (wave * 2 * NF + j) * 1024); return; }
+    int row = row0 + 16 * j; row = row < R ? row : R - 1;
+    glds16(reinterpret_cast<const _Float16*>(wsrc) + (size_t)row * C, sb + XI + (wave * 2 * NF + j) * 1024);
+}
+
+#ifdef THK_PREFILL_TRACE   // development build only (tools/dev/prefill_trace.py): per-wave cycle totals of the main loop's phases
+__device__ unsigned long long g_pf_trace[4 * 256 * 4 * 8];   // [launch index mod 4][workgroup][wave][phase]
+#define PF_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tr_[i] += now_ - tlast_; tlast_ = now_; }
+#else
+#define PF_T(i)
+#endif
+template <int MT, int NF /* 32-row fragments per wave: 2 (256-row tile) or 1 (128-row tile) */, bool PK /* weights are tile images */, int NST = kNST>
 __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16* __restrict__ w0, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
                                                                  const char* __restrict__ ximg, float* __restrict__ part, const PrefillPlan plan) {
     extern __shared__ __attribute__((aligned(1024))) char lds[];
@@ -147,7 +177,9 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
 #define THK_ISSUE_NEXT()                                                                         \
     {                                                                                            \
         const _Float16* wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);                           \
-        v3_issue_chunk<MT, NF>(lds + i_buf * ST, ximg + (size_t)i_ch * XI + lane * 16, wm + (size_t)i_ch * kKC + ld_piece * 8, \
+        if (PK) v3_issue_chunk_packed<MT, NF>(lds + i_buf * ST, ximg + (size_t)i_ch * XI + lane * 16,                  \
+                                              reinterpret_cast<const char*>(wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16, wave); \
+        else v3_issue_chunk<MT, NF>(lds + i_buf * ST, ximg + (size_t)i_ch * XI + lane * 16, wm + (size_t)i_ch * kKC + ld_piece * 8, \
                                i_rbl * TR + wave * 32 * NF + (lane >> 2), R, C, wave);                                  \
         ++issued;                                                                                \
         i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;                                                \
@@ -166,9 +198,14 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
     };
 
     int issued = g0;
+#ifdef THK_PREFILL_TRACE
+    unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_readcyclecounter();
+    const unsigned long long tstart_ = tlast_;
+#endif
 #pragma unroll
     for (int s = 0; s < NST - 1; ++s)
         if (issued < g1) THK_ISSUE_NEXT()
+    PF_T(0)
     int buf = 0, rbk = rbk_first;
     for (int s0 = g0; s0 < g1; ++rbk) {                // one pass per row-block this share touches
         const int rb_end = (rbk + 1) * nchunks, s1 = rb_end < g1 ? rb_end : g1;
@@ -185,8 +222,25 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
             else if (NST >= 4 && rem >= 2) wait_vmcnt<2 * LPS>();
             else if (NST >= 3 && rem >= 1) wait_vmcnt<LPS>();
             else wait_vmcnt<0>();
+            PF_T(1)
             __builtin_amdgcn_s_barrier();              // every wave's loads of chunk g have landed; stage (buf-1) is free
-            if (issued < g1) THK_ISSUE_NEXT()
+            PF_T(2)
+            // The next chunk's LPS loads are NOT issued here in one burst: right after the barrier all four waves would hit the
+            // CU's one texture-address unit together (32 x ~16 clk, measured 450 cycles per chunk in which no MFMA runs, r02 trace).
+            // They are dealt out one at a time between the MFMAs below instead, where their issue hides under the matrix pipe.
+            const bool more = issued < g1;                       // uniform
+            const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);
+            char* const nx_sb = lds + i_buf * ST;
+            const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;
+            const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16
+                                        : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);
+            const int nx_row0 = i_rbl * TR + wave * 32 * NF + (lane >> 2);
+            if (more) {
+                ++issued;
+                i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;
+                if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }
+            }
+            PF_T(3)
             const char* sb = lds + buf * ST;
             // Fragment reads of k-step 1 are issued right behind the first MFMA of k-step 0 and land under the
             // others; hipcc only ever waits lgkmcnt(0) here, so the order is pinned by hand.
@@ -201,36 +255,72 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
                     bl[ks][t] = *reinterpret_cast<const h8*>(rp + XI / 2 + t * 2048);
                 }
             };
-            auto mfma_kstep = [&](const int ks, const int t_begin) __attribute__((always_inline)) {   // (f, hi/lo) for tokens t_begin.., minus the hoisted first one
-#pragma unroll
-                for (int t = t_begin; t < MT; ++t) {
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][f], bh[ks][t], acc[f][t], 0, 0, 0);
-#pragma unroll
-                    for (int f = 0; f < NF; ++f) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][f], bl[ks][t], acc[f][t], 0, 0, 0);
-                }
+            // MFMA number i of the chunk: k-step, token tile, hi|lo, row fragment (the accumulation order per accumulator is
+            // ks0.hi, ks0.lo, ks1.hi, ks1.lo — fixed, results do not depend on the interleave)
+            auto mfma_i = [&](const int i) __attribute__((always_inline)) {
+                const int ks = i / (2 * NF * MT), j = i % (2 * NF * MT), t = j / (2 * NF), r = j % (2 * NF), f = r % NF;
+                acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][f], r < NF ? bh[ks][t] : bl[ks][t], acc[f][t], 0, 0, 0);
             };
             read_frags(0);
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][0], bh[0][0], acc[0][0], 0, 0, 0);
+            mfma_i(0);
             __builtin_amdgcn_sched_barrier(0);
             read_frags(1);
             __builtin_amdgcn_sched_barrier(0);
+            constexpr int NM = 4 * NF * MT;                      // MFMAs per chunk per wave
 #pragma unroll
-            for (int f = 1; f < NF; ++f) acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][f], bh[0][0], acc[f][0], 0, 0, 0);
+            for (int i = 1; i < NM; ++i) {
+                mfma_i(i);
 #pragma unroll
-            for (int f = 0; f < NF; ++f) acc[f][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][f], bl[0][0], acc[f][0], 0, 0, 0);
-            mfma_kstep(0, 1);
+                for (int k = 0; k < LPS; ++k)
+                    if (1 + k * (NM - 1) / LPS == i) {          // load k goes out behind MFMA i
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (more) v3_issue_one<MT, NF, PK>(k, nx_sb, nx_xs, nx_w, nx_row0, R, C, wave);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+            }
             __builtin_amdgcn_sched_barrier(0);
-            mfma_kstep(1, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            PF_T(4)
             buf = buf + 1 == NST ? 0 : buf + 1;
         }
         flush(acc, rbk - rbk_first);                   // end of the row-block (or of this share): spill the tile
+        PF_T(5)
         wait_vmcnt<0>();                               // stores share the counter with the DMA queue: drain, then count afresh
+        PF_T(6)
         s0 = s1;
     }
+#ifdef THK_PREFILL_TRACE
+    tr_[7] = __builtin_readcyclecounter() - tstart_;
+    if (lane == 0) for (int i = 0; i < 8; ++i) g_pf_trace[((((plan.packed >> 8) & 3) * 256 + blockIdx.x) * 4 + wave) * 8 + i] = tr_[i];
+#endif
 #undef THK_ISSUE_NEXT
+}
+
+// ---- weight tile images ------------------------------------------------------------------------
+// A row-major f16 matrix [R][C] rewritten as the sequence of LDS images the GEMM loads: for row-block rb (tile_rows rows)
+// and K-chunk ch (32 columns) one contiguous block of tile_rows x 64 bytes, row r_in_tile at r_in_tile*64, its four
+// 16-byte pieces at position  piece ^ ((r_in_tile >> 2) & 3)  (the swizzle of swz_pos).  Rows past R are zeros.
+// One thread per 16-byte piece; reads are row-contiguous, writes are 64-byte segments.
+__global__ __launch_bounds__(256) void pack_w_kernel(const _Float16* __restrict__ W, int R, int C, int TR, int Rpad, char* __restrict__ out) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int ppr = C >> 3;                                   // pieces per row
+    if (idx >= (size_t)Rpad * ppr) return;
+    const int row = (int)(idx / ppr), pc = (int)(idx % ppr);
+    const int rb = row / TR, rit = row % TR, ch = pc >> 2, piece = pc & 3;
+    h8 v = h8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (row < R) v = *reinterpret_cast<const h8*>(W + (size_t)row * C + (size_t)pc * 8);
+    *reinterpret_cast<h8*>(out + (((size_t)rb * (C / kKC) + ch) * TR + rit) * 64 + (size_t)swz_pos(rit, piece) * 16) = v;
+}
+size_t prefill_pack_bytes(int R, int C, int tile_rows) {
+    const int TR = tile_rows == 128 ? 128 : kV3Rows;
+    return (size_t)((R + TR - 1) / TR * TR) * C * 2;
+}
+hipError_t launch_prefill_pack(const uint16_t* W, int R, int C, int tile_rows, void* out, hipStream_t st) {
+    if (R < 1 || C % kKC != 0) return hipErrorInvalidValue;
+    const int TR = tile_rows == 128 ? 128 : kV3Rows, Rpad = (R + TR - 1) / TR * TR;
+    const size_t n = (size_t)Rpad * (C / 8);
+    hipLaunchKernelGGL(pack_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const _Float16*>(W), R, C, TR, Rpad, (char*)out);
+    return hipGetLastError();
 }
 
 // ---- X-image writers -------------------------------------------------------------------------
@@ -364,6 +454,11 @@ __global__ __launch_bounds__(256) void reduce_swiglu_ximg_kernel(const float* __
     *reinterpret_cast<h4*>(img + ximg_off(p.MT, 1, tok, r) + sub) = lo;
 }
 
+#ifdef THK_PREFILL_TRACE
+extern "C" __attribute__((visibility("default"))) int thk_debug_prefill_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pf_trace), sizeof(unsigned long long) * 4 * 256 * 4 * 8);
+}
+#endif
 hipError_t launch_prefill_ximg(const float* X, const float* gain, int M, int C, void* ximg, hipStream_t st) {
     const int MT = (M + 31) / 32;
     if (M < 1 || M > 128 || C % kKC != 0) return hipErrorInvalidValue;
@@ -371,20 +466,25 @@ hipError_t launch_prefill_ximg(const float* X, const float* gain, int M, int C, 
     else hipLaunchKernelGGL(ximg_from_rows_kernel<false>, dim3(MT * 32), dim3(256), 0, st, X, gain, M, MT, C, (char*)ximg);
     return hipGetLastError();
 }
-hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, const void* ximg, float* part, hipStream_t st) {
+hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& plan_in, const void* ximg, float* part, hipStream_t st) {
+    PrefillPlan p = plan_in;
+#ifdef THK_PREFILL_TRACE
+    { static int n_launch = 0; p.packed = (p.packed & 1) | ((n_launch++ & 3) << 8); }
+#endif
     if (p.M < 1 || p.M > 128 || p.C % kKC != 0 || p.R % 4 != 0 || p.nmat < 1 || p.nmat > 3) return hipErrorInvalidValue;
     const _Float16* w0 = reinterpret_cast<const _Float16*>(W[0]);
     const _Float16* w1 = reinterpret_cast<const _Float16*>(W[p.nmat > 1 ? 1 : 0]);
     const _Float16* w2 = reinterpret_cast<const _Float16*>(W[p.nmat > 2 ? 2 : 0]);
     hipError_t e = hipSuccess;
-#define THK_V3(MTV, NFV)                                                                                                 \
+#define THK_V3K(MTV, NFV, PKV)                                                                                           \
     {                                                                                                                    \
         const size_t lds = (ximg_stage_bytes(MTV) + (size_t)NFV * 8192) * kNST;                                          \
         static bool attr_done[kMaxDevices] = {};     /* the attribute is per device */                                   \
         const int dev = current_device();                                                                                \
-        if (!attr_done[dev]) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3_kernel<MTV, NFV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[dev] = (e == hipSuccess); } \
-        if (e == hipSuccess) hipLaunchKernelGGL((gemm_prefill_v3_kernel<MTV, NFV>), dim3(p.G), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, part, p); \
+        if (!attr_done[dev]) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3_kernel<MTV, NFV, PKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[dev] = (e == hipSuccess); } \
+        if (e == hipSuccess) hipLaunchKernelGGL((gemm_prefill_v3_kernel<MTV, NFV, PKV>), dim3(p.G), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, part, p); \
     }
+#define THK_V3(MTV, NFV) { if (p.packed & 1) THK_V3K(MTV, NFV, true) else THK_V3K(MTV, NFV, false) }
     if (p.tile_rows == 128) switch (p.MT) {
         case 1: THK_V3(1, 1) break;
         case 2: THK_V3(2, 1) break;
@@ -397,6 +497,7 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, c
         default: THK_V3(4, 2) break;
     }
 #undef THK_V3
+#undef THK_V3K
     return e != hipSuccess ? e : hipGetLastError();
 }
 hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st) {

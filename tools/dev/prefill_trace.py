@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""dev: where a prefill GEMM wave spends its cycles.  Needs libthk.so built with -DTHK_PREFILL_TRACE
+(tools/dev/call_pftrace.sh does that).  Runs ONE layer-shaped GEMM per kind through thk_gemm_f16_prefill and prints the
+per-wave mean of each phase in cycles."""
+import ctypes, sys, os
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft
+thk = graft.load_package()
+lib = ctypes.CDLL(os.path.join(ROOT, "token-hawk_amd", "libthk.so"))
+names = ["prologue issue", "wait vmcnt", "barrier", "issue next chunk", "frag reads + MFMA", "flush stores", "drain", "TOTAL"]
+shape = thk.LLAMA_7B
+M = 128
+rng = np.random.default_rng(0)
+toks = np.concatenate([[1], rng.integers(3, shape.n_vocab, M - 1)]).astype(np.int32)
+with thk.Context(0) as ctx:
+    for kv in sys.argv[1:]:
+        k, v = kv.split("="); ctx.set_tunable(k, int(v))
+    import dataclasses
+    sh = dataclasses.replace(shape, n_layer=1)
+    m = thk.Model(ctx, sh); m.fill_synthetic(); m.finalize()
+    for _ in range(3): m.reset_kv(0); m.prefill(toks, 0)          # 4 GEMM launches per prefill: launch index mod 4 = qkv, wo, w13, w2
+    buf = (ctypes.c_ulonglong * (4 * 256 * 4 * 8))()
+    rc = lib.thk_debug_prefill_trace(buf)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(4, 256, 4, 8).astype(np.float64)
+    for k, kind in enumerate(["qkv", "wo", "w13", "w2"]):
+        print(kind, "rc", rc)
+        for i, n in enumerate(names):
+            print("   %-20s mean %9.0f   min %9.0f   max %9.0f cycles" % (n, a[k, :, :, i].mean(), a[k, :, :, i].min(), a[k, :, :, i].max()))
+    m.close()
