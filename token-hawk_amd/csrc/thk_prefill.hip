@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "thk_kernels.hpp"
+#include <type_traits>
 
 namespace thk {
 
@@ -59,6 +60,10 @@ static int current_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 &
 //     most `maxseg` row-blocks; each span goes to its own partial slot and the reducers below sum
 //     the slots of a row-block in workgroup order (deterministic, no atomics) and apply the fused
 //     epilogue (store | residual add | RoPE + KV-cache write | SwiGLU + hi/lo image for w2).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 constexpr int kV3Rows = 256;       // default weight rows per workgroup (4 waves x 64); 128 (4 x 32) halves the partial-tile bytes
 constexpr int kNST = 4;            // LDS stages
 constexpr int kG = 256;            // default workgroups per launch: a constant, so results do not depend on the CU count
@@ -129,16 +134,19 @@ __device__ __forceinline__ void v3_issue_chunk_packed(char* sb, const char* xs, 
     for (int j = 0; j < 2 * NF; ++j) glds16<2>(wtile + (wave * 2 * NF + j) * 1024, sb + XI + (wave * 2 * NF + j) * 1024);
 }
 
-// load number k (0 .. MT + 2 NF - 1) of a chunk, same destinations as the two functions above
+// load number k (0 .. MT + 2 NF - 1) of a chunk, same destinations as the two functions above.  `real` false (no chunk left to
+// fetch): every lane reads the first 16 bytes of the X image instead — one L2 hit, nobody reads the stage — so that the
+// number of loads per step, and with it every s_waitcnt vmcnt in the pipeline, is a constant and the step has no branches.
 template <int MT, int NF, bool PK>
-__device__ __forceinline__ void v3_issue_one(int k, char* sb, const char* xs, const char* wsrc /* PK: tile image + lane*16; else matrix + chunk column + piece */,
+__device__ __forceinline__ void v3_issue_one(int k, bool real, const char* dummy, char* sb, const char* xs, const char* wsrc /* PK: tile image + lane*16; else matrix + chunk column + piece */,
                                              int row0, int R, int C, int wave) {
     constexpr int XI = MT * 32 * 64 * 2;
-    if (k < MT) { glds16(xs + (wave + 4 * k) * 1024, sb + (wave + 4 * k) * 1024); return; }
+    if (k < MT) { const char* src = xs + (wave + 4 * k) * 1024; glds16(real ? src : dummy, sb + (wave + 4 * k) * 1024); return; }
     const int j = k - MT;
-    if (PK) { glds16<2>(wsrc + (wave * 2 * NF + j) * 1024, sb + XI + (wave * 2 * NF + j) * 1024); return; }
+    if (PK) { const char* src = wsrc + (wave * 2 * NF + j) * 1024; glds16<2>(real ? src : dummy, sb + XI + (wave * 2 * NF + j) * 1024); return; }
     int row = row0 + 16 * j; row = row < R ? row : R - 1;
-    glds16(reinterpret_cast<const _Float16*>(wsrc) + (size_t)row * C, sb + XI + (wave * 2 * NF + j) * 1024);
+    const char* src = reinterpret_cast<const char*>(reinterpret_cast<const _Float16*>(wsrc) + (size_t)row * C);
+    glds16(real ? src : dummy, sb + XI + (wave * 2 * NF + j) * 1024);
 }
 
 #ifdef THK_PREFILL_TRACE   // development build only (tools/dev/prefill_trace.py): per-wave cycle totals of the main loop's phases
@@ -174,17 +182,6 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
     // issue cursor: (matrix, row-block in matrix, chunk) of the next flattened chunk to load
     const int rbk_first = g0 / nchunks;
     int i_mat = rbk_first / rb_per_mat, i_rbl = rbk_first % rb_per_mat, i_ch = g0 % nchunks, i_buf = 0;
-#define THK_ISSUE_NEXT()                                                                         \
-    {                                                                                            \
-        const _Float16* wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);                           \
-        if (PK) v3_issue_chunk_packed<MT, NF>(lds + i_buf * ST, ximg + (size_t)i_ch * XI + lane * 16,                  \
-                                              reinterpret_cast<const char*>(wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16, wave); \
-        else v3_issue_chunk<MT, NF>(lds + i_buf * ST, ximg + (size_t)i_ch * XI + lane * 16, wm + (size_t)i_ch * kKC + ld_piece * 8, \
-                               i_rbl * TR + wave * 32 * NF + (lane >> 2), R, C, wave);                                  \
-        ++issued;                                                                                \
-        i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;                                                \
-        if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }  \
-    }
     auto flush = [&](f16v (&acc)[NF][MT], int seg) __attribute__((always_inline)) {    // accumulators -> partial slot
         float* slot = part + ((size_t)blockIdx.x * maxseg + seg) * slot_floats;
 #pragma unroll
@@ -197,103 +194,163 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
                         f4{acc[f][t][4 * g], acc[f][t][4 * g + 1], acc[f][t][4 * g + 2], acc[f][t][4 * g + 3]};
     };
 
+    // ---- software pipeline across chunks --------------------------------------------------------------------------
+    // While the matrix pipe works through chunk g out of REGISTERS (fragment set `cur`), the same instruction stream, between
+    // the MFMAs, (1) waits for chunk g+1's DMA and meets the other waves at the one barrier per chunk, (2) reads chunk g+1's
+    // fragments into the other register set, (3) issues the DMA of chunk g+NST into the stage chunk g just vacated.
+    // The r02 phase trace of the unpipelined loop (profiles/r02_prefill_phase_trace.txt): per chunk 1024 cycles of MFMA but
+    // ~450 of DMA issue (all four waves hit the CU's one address unit together after the barrier), ~250 of exposed
+    // fragment-read latency and ~300 of waitcnt + barrier, none of it overlapped with the matrix pipe (one wave per SIMD).
+    // ---- software pipeline across chunks --------------------------------------------------------------------------
+    // While the matrix pipe works through chunk g out of REGISTERS (one fragment set), the same instruction stream, between
+    // the MFMAs, (1) waits for chunk g+1's DMA and meets the other waves at the one barrier per chunk, (2) reads chunk g+1's
+    // fragments into the other register set, (3) issues the DMA of chunk g+NST into the stage chunk g just vacated.
+    // The r02 phase trace of the unpipelined loop (profiles/r02_prefill_phase_trace.txt): per chunk 1024 cycles of MFMA but
+    // ~450 of DMA issue (all four waves hit the CU's one address unit together after the barrier), ~250 of exposed
+    // fragment-read latency and ~300 of waitcnt + barrier, none of it overlapped with the matrix pipe (one wave per SIMD).
     int issued = g0;
 #ifdef THK_PREFILL_TRACE
     unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_readcyclecounter();
-    const unsigned long long tstart_ = tlast_;
+    const unsigned long long tstart_ = tlast_, wstart_ = wall_clock64();
 #endif
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-        if (issued < g1) THK_ISSUE_NEXT()
-    PF_T(0)
-    int buf = 0, rbk = rbk_first;
-    for (int s0 = g0; s0 < g1; ++rbk) {                // one pass per row-block this share touches
-        const int rb_end = (rbk + 1) * nchunks, s1 = rb_end < g1 ? rb_end : g1;
-        f16v acc[NF][MT];
+    for (int s = 0; s < NST; ++s) {                      // the first NST chunks (dummy loads where the share is shorter: constant counts)
+        const bool more = issued < g1;
+        const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);
+        const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;
+        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16
+                                    : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);
 #pragma unroll
-        for (int f = 0; f < NF; ++f)
-#pragma unroll
-            for (int t = 0; t < MT; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[f][t][i] = 0.f;
-        for (int g = s0; g < s1; ++g) {
-            const int rem = g1 - 1 - g;                // chunks issued after g: min(rem, NST-2)
-            if (NST >= 5 && rem >= 3) wait_vmcnt<3 * LPS>();
-            else if (NST >= 4 && rem >= 2) wait_vmcnt<2 * LPS>();
-            else if (NST >= 3 && rem >= 1) wait_vmcnt<LPS>();
-            else wait_vmcnt<0>();
-            PF_T(1)
-            __builtin_amdgcn_s_barrier();              // every wave's loads of chunk g have landed; stage (buf-1) is free
-            PF_T(2)
-            // The next chunk's LPS loads are NOT issued here in one burst: right after the barrier all four waves would hit the
-            // CU's one texture-address unit together (32 x ~16 clk, measured 450 cycles per chunk in which no MFMA runs, r02 trace).
-            // They are dealt out one at a time between the MFMAs below instead, where their issue hides under the matrix pipe.
-            const bool more = issued < g1;                       // uniform
-            const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);
-            char* const nx_sb = lds + i_buf * ST;
-            const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;
-            const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16
-                                        : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);
-            const int nx_row0 = i_rbl * TR + wave * 32 * NF + (lane >> 2);
-            if (more) {
-                ++issued;
-                i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;
-                if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }
-            }
-            PF_T(3)
-            const char* sb = lds + buf * ST;
-            // Fragment reads of k-step 1 are issued right behind the first MFMA of k-step 0 and land under the
-            // others; hipcc only ever waits lgkmcnt(0) here, so the order is pinned by hand.
-            h8 af[2][NF], bh[2][MT], bl[2][MT];
-            auto read_frags = [&](const int ks) __attribute__((always_inline)) {
-                const char* rp = sb + (ks == 0 ? rd0 : rd1);
-#pragma unroll
-                for (int f = 0; f < NF; ++f) af[ks][f] = *reinterpret_cast<const h8*>(rp + XI + (wave * NF + f) * 2048);
-#pragma unroll
-                for (int t = 0; t < MT; ++t) {
-                    bh[ks][t] = *reinterpret_cast<const h8*>(rp + t * 2048);
-                    bl[ks][t] = *reinterpret_cast<const h8*>(rp + XI / 2 + t * 2048);
-                }
-            };
-            // MFMA number i of the chunk: k-step, token tile, hi|lo, row fragment (the accumulation order per accumulator is
-            // ks0.hi, ks0.lo, ks1.hi, ks1.lo — fixed, results do not depend on the interleave)
-            auto mfma_i = [&](const int i) __attribute__((always_inline)) {
-                const int ks = i / (2 * NF * MT), j = i % (2 * NF * MT), t = j / (2 * NF), r = j % (2 * NF), f = r % NF;
-                acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][f], r < NF ? bh[ks][t] : bl[ks][t], acc[f][t], 0, 0, 0);
-            };
-            read_frags(0);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_i(0);
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(1);
-            __builtin_amdgcn_sched_barrier(0);
-            constexpr int NM = 4 * NF * MT;                      // MFMAs per chunk per wave
-#pragma unroll
-            for (int i = 1; i < NM; ++i) {
-                mfma_i(i);
-#pragma unroll
-                for (int k = 0; k < LPS; ++k)
-                    if (1 + k * (NM - 1) / LPS == i) {          // load k goes out behind MFMA i
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (more) v3_issue_one<MT, NF, PK>(k, nx_sb, nx_xs, nx_w, nx_row0, R, C, wave);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            PF_T(4)
-            buf = buf + 1 == NST ? 0 : buf + 1;
+        for (int k = 0; k < LPS; ++k) v3_issue_one<MT, NF, PK>(k, more, ximg, lds + s * ST, nx_xs, nx_w, i_rbl * TR + wave * 32 * NF + (lane >> 2), R, C, wave);
+        if (more) {
+            ++issued;
+            if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }
         }
-        flush(acc, rbk - rbk_first);                   // end of the row-block (or of this share): spill the tile
-        PF_T(5)
-        wait_vmcnt<0>();                               // stores share the counter with the DMA queue: drain, then count afresh
-        PF_T(6)
-        s0 = s1;
+    }
+    i_buf = 0;                                           // NST loads went out: the next one refills stage 0
+    // fragment registers: two sets (the chunk being multiplied, the chunk being fetched)
+    h8 fa[2][2][NF], fbh[2][2][MT], fbl[2][2][MT];
+    constexpr int NM = 4 * NF * MT;                      // MFMAs per chunk per wave
+    constexpr int NR = 2 * (NF + 2 * MT);                // fragment reads per chunk per wave
+    constexpr int SYNC_AT = NM >= 16 ? NM / 4 - 1 : 0;   // the wait + barrier sit behind this MFMA (late enough that chunk g+1 has normally landed)
+    constexpr int SLOTS = NM - 1 - SYNC_AT;              // MFMAs behind the barrier: the loads are dealt out over them,
+    constexpr int RSLOTS = SLOTS * 5 / 8 > 0 ? SLOTS * 5 / 8 : 1;   // the fragment reads over the first 5/8 (they must be back before the next step's first MFMA)
+    // An LDS-DMA instruction costs its wave ~60 cycles of issue among bare MFMAs but 100-185 next to ds_read_b128 traffic
+    // (MI355X_MICROARCH.md, timeline inputs), so the loads keep clear of the reads: the first LT of a chunk go out in the
+    // slots behind the reads, the other LH in the NEXT step's MFMAs before its barrier.
+    constexpr int TSLOTS = SLOTS - RSLOTS;
+    constexpr int LT = SYNC_AT > 0 ? LPS / 2 : LPS, LH = LPS - LT;
+    bool pend_more = false;                              // second half of the previous step's chunk (nothing in the first step: dummy loads)
+    char* pend_sb = lds;
+    const char *pend_xs = ximg, *pend_w = ximg;
+    int pend_row0 = 0;
+    f16v acc[NF][MT];
+#define THK_PIN_ACC()   /* keep the accumulators in AccVGPRs: left alone the allocator parks tiles in VGPRs across the loop edge and moves them back before every MFMA */ \
+    _Pragma("unroll") for (int f = 0; f < NF; ++f)                         \
+    _Pragma("unroll") for (int t = 0; t < MT; ++t) asm volatile("" : "+a"(acc[f][t]));
+#define THK_ZERO_ACC()                                                     \
+    _Pragma("unroll") for (int f = 0; f < NF; ++f)                         \
+    _Pragma("unroll") for (int t = 0; t < MT; ++t)                         \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[f][t][i] = 0.f;     \
+    THK_PIN_ACC()
+    int buf = 0;                                         // stage of the current chunk
+    // fragment read number RR of a chunk (k-step, then the NF row fragments, then hi/lo of each token tile) into set S
+#define THK_READ_ONE(SB, S, RR)                                                                                        \
+    {                                                                                                                  \
+        const int ks_ = (RR) / (NF + 2 * MT), q_ = (RR) % (NF + 2 * MT);                                               \
+        const char* rp_ = (SB) + (ks_ == 0 ? rd0 : rd1);                                                               \
+        if (q_ < NF) fa[S][ks_][q_ < NF ? q_ : 0] = *reinterpret_cast<const h8*>(rp_ + XI + (wave * NF + q_) * 2048);  \
+        else if (((q_ - NF) & 1) == 0) fbh[S][ks_][q_ >= NF ? (q_ - NF) >> 1 : 0] = *reinterpret_cast<const h8*>(rp_ + ((q_ - NF) >> 1) * 2048); \
+        else fbl[S][ks_][q_ >= NF ? (q_ - NF) >> 1 : 0] = *reinterpret_cast<const h8*>(rp_ + XI / 2 + ((q_ - NF) >> 1) * 2048); \
+    }
+    // One chunk: MFMAs from fragment set S; the next chunk's fragments go into set 1 - S.  (A macro expanded twice, not a
+    // lambda taking the arrays: nested by-reference closures leave every captured array in scratch.)
+#define THK_STEP(S)                                                                                                    \
+    {                                                                                                                  \
+        const bool more = issued < g1;                                 /* uniform */                                   \
+        const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);                                              \
+        char* const nx_sb = lds + i_buf * ST;                                                                          \
+        const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;                                                \
+        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16 \
+                                    : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);        \
+        const int nx_row0 = i_rbl * TR + wave * 32 * NF + (lane >> 2);                                                 \
+        i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;                                                                      \
+        if (more) {                                                                                                    \
+            ++issued;                                                                                                  \
+            if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }                    \
+        }                                                                                                              \
+        const int nbuf = buf + 1 == NST ? 0 : buf + 1;                                                                 \
+        const char* const sbn = lds + nbuf * ST;                                                                       \
+        THK_PIN_ACC()                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                               \
+            {   /* MFMA number i: k-step, hi|lo, then a sweep over all NF*MT accumulators, so that an accumulator is touched again only NF*MT \
+                   MFMAs later (back-to-back MFMAs into one accumulator wait out the full pipeline depth: measured ~50 instead of 32 cycles each). \
+                   Per accumulator the order stays ks0.hi ks0.lo ks1.hi ks1.lo: results do not depend on the sweep. */                    \
+                const int ks = i / (2 * NF * MT), j = i % (2 * NF * MT), hl = j / (NF * MT), t = (j % (NF * MT)) / NF, f = j % NF; \
+                if (hl == 0) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][f], fbh[S][ks][t], acc[f][t], 0, 0, 0); \
+                else acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][f], fbl[S][ks][t], acc[f][t], 0, 0, 0); \
+            }                                                                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            if (i < SYNC_AT) {                                                                                         \
+                _Pragma("unroll") for (int k = LT + i * LH / SYNC_AT; k < LT + (i + 1) * LH / SYNC_AT; ++k)            \
+                    v3_issue_one<MT, NF, PK>(k, pend_more, ximg, pend_sb, pend_xs, pend_w, pend_row0, R, C, wave);     \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+            if (i == SYNC_AT) {                                                                                        \
+                PF_T(1)                                                                                                \
+                wait_vmcnt<(NST - 2) * LPS>();                 /* this wave's loads of chunk g+1 have landed (NST-2 chunks, real or dummy, were issued behind them) ... */ \
+                PF_T(2)                                                                                                \
+                __builtin_amdgcn_s_barrier();                  /* ... and everybody's; every wave holds chunk g in registers: its stage is free */ \
+                PF_T(3)                                                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+            if (i >= SYNC_AT && i < NM - 1) {                                                                          \
+                const int sl = i - SYNC_AT;                    /* behind the last chunk these reads fetch stale bytes nobody uses */ \
+                if (sl < RSLOTS) { _Pragma("unroll") for (int rr = sl * NR / RSLOTS; rr < (sl + 1) * NR / RSLOTS; ++rr) THK_READ_ONE(sbn, 1 - S, rr) } \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+                if (sl >= RSLOTS) {                                                                                    \
+                    _Pragma("unroll") for (int k = (sl - RSLOTS) * LT / TSLOTS; k < (sl - RSLOTS + 1) * LT / TSLOTS; ++k) \
+                        v3_issue_one<MT, NF, PK>(k, more, ximg, nx_sb, nx_xs, nx_w, nx_row0, R, C, wave);              \
+                }                                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+        }                                                                                                              \
+        buf = nbuf;                                                                                                    \
+        pend_more = more; pend_sb = nx_sb; pend_xs = nx_xs; pend_w = nx_w; pend_row0 = nx_row0;                         \
+        THK_PIN_ACC()                                                                                                  \
+        PF_T(4)                                                                                                        \
+        if (g + 1 == seg_end) {                            /* end of a row-block (or of the share): spill the tile */   \
+            flush(acc, seg);                                                                                           \
+            wait_vmcnt<0>();                                                                                           \
+            PF_T(0)                               /* stores share the counter with the DMA queue: drain, then count afresh */ \
+            THK_ZERO_ACC()                                                                                             \
+            ++seg;                                                                                                     \
+            seg_end = seg_end + nchunks < g1 ? seg_end + nchunks : g1;                                                 \
+        }                                                                                                              \
+    }
+    int seg = 0, seg_end = (rbk_first + 1) * nchunks < g1 ? (rbk_first + 1) * nchunks : g1;
+    THK_ZERO_ACC()
+    PF_T(0)
+    wait_vmcnt<(NST - 1) * LPS>();                       // chunk g0 is in
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) THK_READ_ONE(lds, 0, rr)
+    for (int g = g0;;) {
+        THK_STEP(0)
+        if (++g >= g1) break;
+        THK_STEP(1)
+        if (++g >= g1) break;
     }
 #ifdef THK_PREFILL_TRACE
     tr_[7] = __builtin_readcyclecounter() - tstart_;
+    tr_[5] = wstart_; tr_[6] = wall_clock64();           // chip-global 100 MHz clock: when this wave started / ended
     if (lane == 0) for (int i = 0; i < 8; ++i) g_pf_trace[((((plan.packed >> 8) & 3) * 256 + blockIdx.x) * 4 + wave) * 8 + i] = tr_[i];
 #endif
-#undef THK_ISSUE_NEXT
+#undef THK_STEP
+#undef THK_READ_ONE
+#undef THK_ZERO_ACC
+#undef THK_PIN_ACC
 }
 
 // ---- weight tile images ------------------------------------------------------------------------

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft
 thk = graft.load_package()
 lib = ctypes.CDLL(os.path.join(ROOT, "token-hawk_amd", "libthk.so"))
-names = ["prologue issue", "wait vmcnt", "barrier", "issue next chunk", "frag reads + MFMA", "flush stores", "drain", "TOTAL"]
+names = ["prologue issue + flush/drain", "step head (MFMAs before sync)", "wait vmcnt", "barrier", "step rest (MFMA+reads+DMA)", "flush stores", "drain", "TOTAL"]
 shape = thk.LLAMA_7B
 M = 128
 rng = np.random.default_rng(0)
@@ -27,5 +27,10 @@ with thk.Context(0) as ctx:
     for k, kind in enumerate(["qkv", "wo", "w13", "w2"]):
         print(kind, "rc", rc)
         for i, n in enumerate(names):
-            print("   %-20s mean %9.0f   min %9.0f   max %9.0f cycles" % (n, a[k, :, :, i].mean(), a[k, :, :, i].min(), a[k, :, :, i].max()))
+            if i in (5, 6): continue
+            print("   %-32s mean %9.0f   min %9.0f   max %9.0f cycles" % (n, a[k, :, :, i].mean(), a[k, :, :, i].min(), a[k, :, :, i].max()))
+        st, en = a[k, :, :, 5], a[k, :, :, 6]
+        t0 = st.min()
+        print("   wave start (10 ns ticks after the first): median %.0f  p90 %.0f  max %.0f ;  wave end: min %.0f  median %.0f  max %.0f" %
+              (np.median(st - t0), np.percentile(st - t0, 90), (st - t0).max(), (en - t0).min(), np.median(en - t0), (en - t0).max()))
     m.close()
