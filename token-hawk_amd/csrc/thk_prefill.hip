@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
 #pragma unroll
                 for (int g = 0; g < 4; ++g)         // fragment order: one contiguous 1 KiB store per (f, t, g); frag_decode() below is the inverse
                     *reinterpret_cast<f4*>(slot + (size_t)(((((wave * NF + f) * MT + t) * 4 + g) * 64 + lane) * 4)) =
-                        f4{acc[f][t][4 * g], acc[f][t][4 * g + 1], acc[f][t][4 * g + 2], acc[f][t][4 * g + 3]};
+                        f4{acc[f][t][4 * g], acc[f][t][4 * g + 1], acc[f][t][4 * g + 2], acc[f][t][4 * g + 3]};   // (sc1 write-through stores: no gain, r02)
     };
 
     // ---- software pipeline across chunks --------------------------------------------------------------------------
