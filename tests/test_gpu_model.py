@@ -363,6 +363,34 @@ def test_prefill_is_bitwise_repeatable(thk, ctx, M):
     m.close()
 
 
+@pytest.mark.parametrize("dims", [(512, 256, 8), (4096, 256, 32)])
+@pytest.mark.parametrize("M", [7, 76, 128, 204])
+def test_prefill_tile_images_equal_row_major(thk, dims, M):
+    """The prefill GEMM streams repacked tile images of the layer matrices (tunable prefill_packed, the default) or the
+    row-major matrices themselves: same MFMA order, so the logits must agree bit for bit.  The narrow model gives every
+    workgroup a one-chunk share (all but one of its pipeline steps issue dummy loads) — the shape that exposed a dummy
+    load landing in a live LDS stage during development."""
+    E, mult, H = dims
+    shape = thk.ModelShape(n_vocab=2048, n_embd=E, n_mult=mult, n_head=H, n_layer=2, n_ctx=256)
+    rng = np.random.default_rng(M + E)
+    toks = np.concatenate([[1], rng.integers(3, 2048, M - 1)]).astype(np.int32)
+    out = []
+    for packed in (0, 1):
+        with thk.Context(0) as c:
+            c.set_tunable("prefill_packed", packed)
+            m = thk.Model(c, shape); m.fill_synthetic(); m.finalize()
+            first = m.prefill(toks, 0).copy()
+            for _ in range(5):
+                m.reset_kv(0)
+                assert np.array_equal(first.view(np.uint32), m.prefill(toks, 0).view(np.uint32))
+            m.reset_kv(0)
+            ld, _ = m.eval(toks, 0)
+            assert np.abs(first - ld).max() < 2e-4          # vs the decode path, token by token
+            out.append(first)
+            m.close()
+    assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
+
+
 def test_prefill_into_second_sequence_and_faithful_head(thk, orc, ctx):
     """Prefill writes the KV rows of the sequence it is given (not sequence 0) and honours the lm-head mode."""
     m, om = make_pair(thk, orc, ctx, "TINY_Q1", n_seq=2, lm_mode=1)     # 1 = THK_LMHEAD_FAITHFUL (defect Q1 reproduced)

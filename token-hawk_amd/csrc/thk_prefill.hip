@@ -135,18 +135,20 @@ __device__ __forceinline__ void v3_issue_chunk_packed(char* sb, const char* xs, 
 }
 
 // load number k (0 .. MT + 2 NF - 1) of a chunk, same destinations as the two functions above.  `real` false (no chunk left to
-// fetch): every lane reads the first 16 bytes of the X image instead — one L2 hit, nobody reads the stage — so that the
+// fetch): every lane reads the first 16 bytes of the X image into this wave's 1 KiB of scratch behind the stages — one L2 hit,
+// no stage is touched (in the first step the "pending" half-chunk does not exist yet and every stage is live) — so that the
 // number of loads per step, and with it every s_waitcnt vmcnt in the pipeline, is a constant and the step has no branches.
 template <int MT, int NF, bool PK>
-__device__ __forceinline__ void v3_issue_one(int k, bool real, const char* dummy, char* sb, const char* xs, const char* wsrc /* PK: tile image + lane*16; else matrix + chunk column + piece */,
-                                             int row0, int R, int C, int wave) {
+__device__ __forceinline__ void v3_issue_one(int k, bool real, const char* dummy_src, char* dummy_dst, char* sb, const char* xs,
+                                             const char* wsrc /* PK: tile image + lane*16; else matrix + chunk column + piece */, int row0, int R, int C, int wave) {
     constexpr int XI = MT * 32 * 64 * 2;
-    if (k < MT) { const char* src = xs + (wave + 4 * k) * 1024; glds16(real ? src : dummy, sb + (wave + 4 * k) * 1024); return; }
+    if (k < MT) { const char* src = xs + (wave + 4 * k) * 1024; glds16(real ? src : dummy_src, real ? sb + (wave + 4 * k) * 1024 : dummy_dst); return; }
     const int j = k - MT;
-    if (PK) { const char* src = wsrc + (wave * 2 * NF + j) * 1024; glds16<2>(real ? src : dummy, sb + XI + (wave * 2 * NF + j) * 1024); return; }
+    char* const dst = sb + XI + (wave * 2 * NF + j) * 1024;
+    if (PK) { const char* src = wsrc + (wave * 2 * NF + j) * 1024; glds16<2>(real ? src : dummy_src, real ? dst : dummy_dst); return; }
     int row = row0 + 16 * j; row = row < R ? row : R - 1;
     const char* src = reinterpret_cast<const char*>(reinterpret_cast<const _Float16*>(wsrc) + (size_t)row * C);
-    glds16(real ? src : dummy, sb + XI + (wave * 2 * NF + j) * 1024);
+    glds16(real ? src : dummy_src, real ? dst : dummy_dst);
 }
 
 #ifdef THK_PREFILL_TRACE   // development build only (tools/dev/prefill_trace.py): per-wave cycle totals of the main loop's phases
@@ -208,6 +210,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
     // The r02 phase trace of the unpipelined loop (profiles/r02_prefill_phase_trace.txt): per chunk 1024 cycles of MFMA but
     // ~450 of DMA issue (all four waves hit the CU's one address unit together after the barrier), ~250 of exposed
     // fragment-read latency and ~300 of waitcnt + barrier, none of it overlapped with the matrix pipe (one wave per SIMD).
+    char* const scratch = lds + NST * ST + wave * 1024;   // where dummy loads land
     int issued = g0;
 #ifdef THK_PREFILL_TRACE
     unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_readcyclecounter();
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
         const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16
                                     : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);
 #pragma unroll
-        for (int k = 0; k < LPS; ++k) v3_issue_one<MT, NF, PK>(k, more, ximg, lds + s * ST, nx_xs, nx_w, i_rbl * TR + wave * 32 * NF + (lane >> 2), R, C, wave);
+        for (int k = 0; k < LPS; ++k) v3_issue_one<MT, NF, PK>(k, more, ximg, scratch, lds + s * ST, nx_xs, nx_w, i_rbl * TR + wave * 32 * NF + (lane >> 2), R, C, wave);
         if (more) {
             ++issued;
             if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }
@@ -294,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
             __builtin_amdgcn_sched_barrier(0);                                                                         \
             if (i < SYNC_AT) {                                                                                         \
                 _Pragma("unroll") for (int k = LT + i * LH / SYNC_AT; k < LT + (i + 1) * LH / SYNC_AT; ++k)            \
-                    v3_issue_one<MT, NF, PK>(k, pend_more, ximg, pend_sb, pend_xs, pend_w, pend_row0, R, C, wave);     \
+                    v3_issue_one<MT, NF, PK>(k, pend_more, ximg, scratch, pend_sb, pend_xs, pend_w, pend_row0, R, C, wave);     \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
             }                                                                                                          \
             if (i == SYNC_AT) {                                                                                        \
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
                 if (sl >= RSLOTS) {                                                                                    \
                     _Pragma("unroll") for (int k = (sl - RSLOTS) * LT / TSLOTS; k < (sl - RSLOTS + 1) * LT / TSLOTS; ++k) \
-                        v3_issue_one<MT, NF, PK>(k, more, ximg, nx_sb, nx_xs, nx_w, nx_row0, R, C, wave);              \
+                        v3_issue_one<MT, NF, PK>(k, more, ximg, scratch, nx_sb, nx_xs, nx_w, nx_row0, R, C, wave);              \
                 }                                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
             }                                                                                                          \
@@ -535,7 +538,7 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& plan
     hipError_t e = hipSuccess;
 #define THK_V3K(MTV, NFV, PKV)                                                                                           \
     {                                                                                                                    \
-        const size_t lds = (ximg_stage_bytes(MTV) + (size_t)NFV * 8192) * kNST;                                          \
+        const size_t lds = (ximg_stage_bytes(MTV) + (size_t)NFV * 8192) * kNST + 4096;   /* + 1 KiB per wave for dummy loads */ \
         static bool attr_done[kMaxDevices] = {};     /* the attribute is per device */                                   \
         const int dev = current_device();                                                                                \
         if (!attr_done[dev]) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3_kernel<MTV, NFV, PKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[dev] = (e == hipSuccess); } \
