@@ -716,20 +716,37 @@ extern "C" int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_ent
 // Per 128-token slab and layer, 11 launches: norm->X image | wq,wk,wv GEMM | reduce + RoPE + KV write | causal
 // attention -> X image | wo GEMM | reduce + residual | norm->X image | w1,w3 GEMM | reduce + SwiGLU -> X image |
 // w2 GEMM | reduce + residual.  (thk_prefill.hip explains the GEMM: LDS-DMA pipeline, stream-K, hi/lo split.)
+// The four GEMM plans of a slab of M tokens (qkv, wo, w13, w2) from the prefill_blocks_* / prefill_tile_* tunables.
+static int slab_plans(thk_model* m, int M, PrefillPlan out[4]) {
+    thk_ctx* ctx = m->ctx;
+    const int E = m->hp.n_embd, F = m->n_ff;
+    static const char* const kind[4] = {"qkv", "wo", "w13", "w2"};
+    const int R[4] = {E, E, F, E}, nmat[4] = {3, 1, 2, 1}, C[4] = {E, E, E, F};
+    for (int k = 0; k < 4; ++k) {
+        const int g = (int)tun(ctx, (std::string("prefill_blocks_") + kind[k]).c_str());
+        const int t = (int)tun(ctx, (std::string("prefill_tile_") + kind[k]).c_str());
+        REQUIRE(ctx, g >= 1 && g <= 256, "prefill_blocks_* tunables must be in [1, 256]");
+        out[k] = prefill_plan(M, R[k], nmat[k], C[k], g, t);
+    }
+    return THK_OK;
+}
 struct PrefillBufs { float *X, *Q, *ATT; int32_t* tok; char *imgE, *imgF; float* part; };
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 static int prefill_workspace(thk_model* m, PrefillBufs* b) {
     thk_ctx* ctx = m->ctx;
-    const int E = m->hp.n_embd, F = m->n_ff;
+    const int E = m->hp.n_embd;
     const size_t per = align256((size_t)128 * E * 4);
     // sized from the SAME plans prefill_slab builds (the prefill_blocks_* / prefill_tile_* tunables are read per call, and
     // part_floats = G * maxseg * slot_floats is not monotonic in G, so a fixed G = 256 bound could be exceeded)
-    const int g_qkv = (int)tun(ctx, "prefill_blocks_qkv"), g_wo = (int)tun(ctx, "prefill_blocks_wo"), g_w13 = (int)tun(ctx, "prefill_blocks_w13"), g_w2 = (int)tun(ctx, "prefill_blocks_w2");
-    REQUIRE(ctx, g_qkv >= 1 && g_qkv <= 256 && g_wo >= 1 && g_wo <= 256 && g_w13 >= 1 && g_w13 <= 256 && g_w2 >= 1 && g_w2 <= 256, "prefill_blocks_* tunables must be in [1, 256]");
-    const int t_qkv = (int)tun(ctx, "prefill_tile_qkv"), t_wo = (int)tun(ctx, "prefill_tile_wo"), t_w13 = (int)tun(ctx, "prefill_tile_w13"), t_w2 = (int)tun(ctx, "prefill_tile_w2");
-    const PrefillPlan pq = prefill_plan(128, E, 3, E, g_qkv, t_qkv), po = prefill_plan(128, E, 1, E, g_wo, t_wo), p13 = prefill_plan(128, F, 2, E, g_w13, t_w13), p2 = prefill_plan(128, E, 1, F, g_w2, t_w2);
-    const size_t part_floats = std::max(std::max(pq.part_floats, po.part_floats), std::max(p13.part_floats, p2.part_floats));
-    const size_t img_e = std::max(std::max(pq.ximg_bytes, po.ximg_bytes), p13.ximg_bytes), img_f = p2.ximg_bytes;
+    size_t part_floats = 0, img_e = 0, img_f = 0;
+    for (int M : {128}) {
+        PrefillPlan pl[4];
+        const int rc = slab_plans(m, M, pl);
+        if (rc != THK_OK) return rc;
+        for (int k = 0; k < 4; ++k) part_floats = std::max(part_floats, pl[k].part_floats);
+        img_e = std::max(img_e, std::max(std::max(pl[0].ximg_bytes, pl[1].ximg_bytes), pl[2].ximg_bytes));
+        img_f = std::max(img_f, pl[3].ximg_bytes);
+    }
     const size_t imgE = align256(img_e), imgF = align256(img_f), part = align256(4 * part_floats);
     const size_t bytes = 3 * per + 1024 + imgE + imgF + part;
     if (m->prefill_ws_bytes < bytes) {
@@ -751,8 +768,13 @@ static int ensure_prefill_pack(thk_model* m) {
     thk_ctx* ctx = m->ctx;
     if (tun(ctx, "prefill_packed") == 0 || m->pk_failed) return THK_OK;
     const int E = m->hp.n_embd, F = m->n_ff, nl = m->l1 - m->l0;
-    const int tiles[4] = {(int)tun(ctx, "prefill_tile_qkv") == 128 ? 128 : 256, (int)tun(ctx, "prefill_tile_wo") == 128 ? 128 : 256,
-                          (int)tun(ctx, "prefill_tile_w13") == 128 ? 128 : 256, (int)tun(ctx, "prefill_tile_w2") == 128 ? 128 : 256};
+    int tiles[4];
+    {
+        PrefillPlan pl[4];
+        const int rc = slab_plans(m, 128, pl);           // the tiles a full slab uses
+        if (rc != THK_OK) return rc;
+        for (int k = 0; k < 4; ++k) tiles[k] = pl[k].tile_rows;
+    }
     if (m->prefill_pk && !m->pk_w.empty() && !memcmp(tiles, m->pk_tiles, sizeof tiles)) return THK_OK;
     // wq wk wv wo w1 w2 w3: (rows, cols, tile)
     const int R[7] = {E, E, E, E, F, E, F}, C[7] = {E, E, E, E, E, F, E}, T[7] = {tiles[0], tiles[0], tiles[0], tiles[1], tiles[2], tiles[3], tiles[2]};
@@ -784,10 +806,12 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
     thk_ctx* ctx = m->ctx;
     hipStream_t st = ctx->stream;
     const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, T = m->hp.n_ctx;
-    const int g_qkv = (int)tun(ctx, "prefill_blocks_qkv"), g_wo = (int)tun(ctx, "prefill_blocks_wo"), g_w13 = (int)tun(ctx, "prefill_blocks_w13"), g_w2 = (int)tun(ctx, "prefill_blocks_w2");
-    REQUIRE(ctx, g_qkv >= 1 && g_qkv <= 256 && g_wo >= 1 && g_wo <= 256 && g_w13 >= 1 && g_w13 <= 256 && g_w2 >= 1 && g_w2 <= 256, "prefill_blocks_* tunables must be in [1, 256]");
-    const int t_qkv = (int)tun(ctx, "prefill_tile_qkv"), t_wo = (int)tun(ctx, "prefill_tile_wo"), t_w13 = (int)tun(ctx, "prefill_tile_w13"), t_w2 = (int)tun(ctx, "prefill_tile_w2");
-    PrefillPlan pq = prefill_plan(M, E, 3, E, g_qkv, t_qkv), po = prefill_plan(M, E, 1, E, g_wo, t_wo), p13 = prefill_plan(M, F, 2, E, g_w13, t_w13), p2 = prefill_plan(M, E, 1, F, g_w2, t_w2);
+    PrefillPlan pl[4];
+    {
+        const int rc = slab_plans(m, M, pl);
+        if (rc != THK_OK) return rc;
+    }
+    PrefillPlan &pq = pl[0], &po = pl[1], &p13 = pl[2], &p2 = pl[3];
     const bool pk = !m->pk_w.empty() && m->pk_tiles[0] == pq.tile_rows && m->pk_tiles[1] == po.tile_rows && m->pk_tiles[2] == p13.tile_rows && m->pk_tiles[3] == p2.tile_rows;
     pq.packed = po.packed = p13.packed = p2.packed = pk ? 1 : 0;
     HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
