@@ -391,6 +391,26 @@ def test_prefill_tile_images_equal_row_major(thk, dims, M):
     assert np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))
 
 
+def test_prefill_tile_images_follow_weight_updates(thk, ctx):
+    """The tile images are a second copy of the layer weights made on the first prefill call: writing a tensor afterwards
+    (set_tensor or a new fill_synthetic) must invalidate them, or prefill would keep multiplying by the old matrix."""
+    shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=256)
+    toks = np.concatenate([[1], np.random.default_rng(5).integers(3, 2048, 127)]).astype(np.int32)
+    m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    before = m.prefill(toks, 0).copy()                              # builds the images
+    w = (np.random.default_rng(6).standard_normal((512, 512)) * 0.02).astype(np.float16)
+    m.set_tensor("layers.1.attention.wo.weight", w.view(np.uint16))
+    m.reset_kv(0)
+    after = m.prefill(toks, 0).copy()
+    m.reset_kv(0)
+    ld, _ = m.eval(toks, 0)                                         # decode path reads the row-major matrix
+    assert np.abs(after - ld).max() < 2e-4
+    assert np.abs(after - before).max() > 1e-3                      # the update is visible at all
+    m.fill_synthetic(); m.reset_kv(0)                               # back to the synthetic weights
+    assert np.array_equal(m.prefill(toks, 0).view(np.uint32), before.view(np.uint32))
+    m.close()
+
+
 def test_prefill_into_second_sequence_and_faithful_head(thk, orc, ctx):
     """Prefill writes the KV rows of the sequence it is given (not sequence 0) and honours the lm-head mode."""
     m, om = make_pair(thk, orc, ctx, "TINY_Q1", n_seq=2, lm_mode=1)     # 1 = THK_LMHEAD_FAITHFUL (defect Q1 reproduced)
