@@ -202,7 +202,8 @@ int thk_model_eval(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_t
                    float* hidden_inout, float* logits_out);
 
 /* Batched prompt prefill (config C3) through the MFMA GEMM path: same contract as
- * thk_model_eval with n_past == 0..; full-model stages only. */
+ * thk_model_eval with n_past == 0..; full-model stages only.  The first call builds the
+ * weight tile images (tunable prefill_packed) and the workspace; later calls reuse them. */
 int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past,
                       float* logits_out);
 
@@ -228,7 +229,7 @@ int thk_model_decode_steps(thk_model* m, int32_t seq, int32_t n_steps, int advan
  * timed call does not pay for stream capture + graph instantiation. */
 int thk_model_prepare_steps(thk_model* m, int32_t seq, int32_t n_steps);
 /* 1 when the finalized model runs a decode step as ONE persistent loader/consumer launch (thk_engine.hip;
- * tunable "engine", default on, shape permitting), 0 when it runs 5 fused launches per layer. */
+ * tunable "engine" = 1, default 0, shape permitting), 0 when it runs 5 fused launches per layer. */
 int thk_model_uses_engine(const thk_model* m);
 /* Development aid (tunable engine_trace=1 before finalize): the last step's per-workgroup, per-op s_memtime stamps,
  * [n_cu][n_ops][8] 64-bit words (slot meaning in thk_engine.hip). */
@@ -281,7 +282,10 @@ int thk_pp_recv_token(thk_pp* pp, thk_model* m, int32_t seq, int peer);
  *            measure_skip_kernel (1..6: that kernel is not launched -- bench.py's marginal-cost
  *            measurement; results are garbage; REFUSED unless the environment has THK_MEASURE_HOOKS=1)
  *   prefill: prefill_blocks_{qkv,wo,w13,w2} (workgroups per GEMM launch, <= 256);
- *            prefill_tile_{...} (weight rows per workgroup, 128|256); prefill_attn_mfma */
+ *            prefill_tile_{...} (weight rows per workgroup, 128|256); prefill_attn_mfma;
+ *            prefill_packed (default 1: the first prefill call makes tile images of the
+ *            layer matrices for the GEMM's linear `nt` stream — a second copy of the layer
+ *            weights in HBM, rebuilt after any tensor write; 0 = stream the row-major matrices) */
 int thk_set_tunable(thk_ctx* ctx, const char* name, int64_t value);
 int thk_get_tunable(thk_ctx* ctx, const char* name, int64_t* value);
 
