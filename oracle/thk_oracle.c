@@ -9,9 +9,13 @@
  *   The reference (kayvr/token-hawk) executes this arithmetic as WGSL shaders
  *   inside Google Dawn, an un-vendored submodule (.gitmodules:1-3, cli/dawn is
  *   empty, no pinned commit recoverable).  All three reference TUs include
- *   <webgpu/webgpu.h>, which this image lacks, so no part of the reference can
- *   be compiled here without writing a stand-in header (forbidden).  The
- *   reference ships no tests, golden vectors or fixtures.  This oracle is
+ *   <webgpu/webgpu.h>, which this image lacks, so no translation unit of the
+ *   reference can be compiled here without writing a stand-in header
+ *   (forbidden).  What IS compiled from the reference where it lies (line ranges
+ *   that touch no WebGPU type, oracle/Makefile target _ref) are the fp16
+ *   converters (A17), the sampler (A21) and the tokenizer (A22); their outputs
+ *   are the fixtures tests/golden/ref_fp16.npz and ref_host.npz.  For the kernel
+ *   arithmetic the reference ships no tests, golden vectors or fixtures.  This oracle is
  *   therefore a line-cited restatement of the WGSL text and host code; it is
  *   cross-checked only against independent implementations (numpy float16 for
  *   all 65,536 half patterns; a float64 numpy LLaMA forward) — see

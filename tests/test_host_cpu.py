@@ -312,3 +312,57 @@ def test_host_fp16_converters_match_reference_fixture(host):
     got = np.empty(f.size, np.uint16)
     host.thh_fp32_to_fp16(P(f), P(got), C.c_int64(f.size))
     assert (got == g["f2h"]).all()
+
+
+# ------------------------------------------------------------------ reference-held pins for A22 / A21
+# tests/golden/ref_host.npz was produced by the REFERENCE's own tk_llama_tokenize and llama_sample_top_p_top_k, compiled from
+# /root/reference/th-llama.cpp where it lies (oracle/Makefile target _ref, tools/make_ref_host_golden.py); the fixture is data.
+def _ref_host_fixture():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_host.npz"))
+
+
+def test_tokenizer_matches_reference_fixture(host):
+    g = _ref_host_fixture()
+    blob = g["vocab_blob"].tobytes()
+    lens = np.ascontiguousarray(g["vocab_lens"]); scores = np.ascontiguousarray(g["vocab_scores"])
+    tb, toff, bos = g["text_blob"].tobytes(), g["text_off"], g["text_bos"]
+    ids, ioff = g["ids_blob"], g["ids_off"]
+    assert len(toff) - 1 >= 100
+    for i in range(len(toff) - 1):
+        text = tb[toff[i]:toff[i + 1]]
+        out = np.empty(len(text) + 2, np.int32)
+        n = host.thh_tokenize(blob, P(lens), P(scores), lens.size, text, len(text), int(bos[i]), P(out), out.size)
+        assert out[:n].tolist() == ids[ioff[i]:ioff[i + 1]].tolist(), (i, text)
+
+
+def test_sampler_matches_reference_fixture(host):
+    g = _ref_host_fixture()
+    for c in range(g["smp_par"].shape[0]):
+        k, p, t, pen = g["smp_par"][c]
+        lg = np.ascontiguousarray(g["smp_logits"][c]); last = np.ascontiguousarray(g["smp_last"][c])
+        want = g["smp_draws"][c]
+        out = np.empty(want.size, np.int32)
+        host.thh_sample(C.c_uint32(int(g["smp_seed"][c])), P(lg), lg.size, int(k), C.c_float(float(p)), C.c_float(float(t)), C.c_float(float(pen)),
+                        P(last), last.size, out.size, P(out))
+        assert out.tolist() == want.tolist(), (c, float(k), float(p), float(t))
+
+
+def test_python_restatements_match_reference_fixture():
+    """The independent restatements used elsewhere in this file (py_tokenize, py_sample + MT19937) agree with the reference's
+    own functions too, so the older restatement-based tests are anchored to the same pin."""
+    g = _ref_host_fixture()
+    blob, lens = g["vocab_blob"].tobytes(), g["vocab_lens"]
+    words, off = [], 0
+    for n in lens:
+        words.append(blob[off:off + int(n)]); off += int(n)
+    scores = g["vocab_scores"]
+    tb, toff, bos, ids, ioff = g["text_blob"].tobytes(), g["text_off"], g["text_bos"], g["ids_blob"], g["ids_off"]
+    for i in range(0, len(toff) - 1, 3):
+        text = tb[toff[i]:toff[i + 1]]
+        assert py_tokenize(words, scores, text, bool(bos[i])) == ids[ioff[i]:ioff[i + 1]].tolist(), (i, text)
+    for c in range(g["smp_par"].shape[0]):
+        k, p, t, pen = (float(v) for v in g["smp_par"][c])
+        mt = MT19937(int(g["smp_seed"][c]))
+        last = set(g["smp_last"][c].tolist())
+        got = [py_sample(mt, g["smp_logits"][c], int(k), p, t, pen, last) for _ in range(12)]
+        assert got == g["smp_draws"][c][:12].tolist(), c
