@@ -366,3 +366,12 @@ def test_python_restatements_match_reference_fixture():
         last = set(g["smp_last"][c].tolist())
         got = [py_sample(mt, g["smp_logits"][c], int(k), p, t, pen, last) for _ in range(12)]
         assert got == g["smp_draws"][c][:12].tolist(), c
+
+
+def test_tensor_shape_matches_reference_fixture(host):
+    """A18: TensorShape::get_total_num_elements / canonicalize as the reference's own struct computes them (th.hpp:37-77)."""
+    g = _ref_host_fixture()
+    for sh, want in zip(g["shp_in"], g["shp_out"]):
+        out = (C.c_int64 * 5)()
+        host.thh_tensor_shape_roundtrip(*[C.c_int64(int(v)) for v in sh], out)
+        assert list(out) == want.tolist(), sh

@@ -12,7 +12,8 @@ outputs as plain data:
   sampler     for case c: smp_logits float32[C][N], smp_par float32[C][4] (top_k, top_p, temp, repeat_penalty), smp_seed uint32[C],
               smp_last int32[C][L], smp_draws int32[C][D]                        D consecutive llama_sample_top_p_top_k draws from ONE
                                                                                  std::mt19937(seed), as the reference seeds it
-The fixture is the reference-held pin for A21/A22: tests/test_host_cpu.py checks the host layer's tokenizer and sampler
+  TensorShape shp_in int64[S][4] (l,b,r,c), shp_out int64[S][5] (canonical l,b,r,c; get_total_num_elements of the shape as given), shp_str
+The fixture is the reference-held pin for A21/A22 (and A18's TensorShape): tests/test_host_cpu.py checks the host layer's tokenizer and sampler
 against it.  Needs /root/reference, so it runs in the build container only:  make -C oracle _ref && python tools/make_ref_host_golden.py"""
 import ctypes as C
 import os
@@ -76,9 +77,21 @@ for c, (k, p, t, pen) in enumerate(cases):
     lib.ref_sample(C.c_uint32(int(smp_seed[c])), P(lg), N, int(k), C.c_float(p), C.c_float(t), C.c_float(pen), P(smp_last[c]), L, D, P(out))
     smp_draws[c] = out
 
+# ---- TensorShape (A18, th.hpp:37-77): total elements of the shape as given, canonical form, to_string
+shp_in = np.array([(0, 0, 1, 4096), (1, 1, 0, 7), (0, 512, 32, 128), (0, 0, 0, 0), (1, 0, 0, 5), (2, 1, 1, 1), (0, 1, 4096, 4096), (3, 4, 5, 6),
+                   (0, 0, 32000, 4096), (1, 1, 1, 1), (0, 2, 0, 9), (0, 0, 11008, 4096)], np.int64)
+shp_out = np.empty((len(shp_in), 5), np.int64); shp_str = []
+lib.ref_tensor_shape.argtypes = [C.c_int64] * 4 + [C.c_void_p, C.c_char_p, C.c_int]
+for i, sh in enumerate(shp_in):
+    buf = C.create_string_buffer(128)
+    lib.ref_tensor_shape(*[int(v) for v in sh], P(shp_out[i]), buf, 128)
+    shp_str.append(buf.value)
+shp_str = np.array(shp_str)
+
 dst = os.path.join(ROOT, "tests", "golden", "ref_host.npz")
 np.savez_compressed(dst, vocab_blob=vocab_blob, vocab_lens=vocab_lens, vocab_scores=vocab_scores,
                     text_blob=np.frombuffer(b"".join(texts), np.uint8), text_off=np.array(text_off, np.int32), text_bos=text_bos,
                     ids_blob=np.array(ids, np.int32), ids_off=np.array(ids_off, np.int32),
-                    smp_logits=smp_logits, smp_par=smp_par, smp_seed=smp_seed, smp_last=smp_last, smp_draws=smp_draws)
+                    smp_logits=smp_logits, smp_par=smp_par, smp_seed=smp_seed, smp_last=smp_last, smp_draws=smp_draws,
+                    shp_in=shp_in, shp_out=shp_out, shp_str=shp_str)
 print(f"wrote {dst}: {len(texts)} prompts -> {len(ids)} ids, {len(cases)} sampler cases x {D} draws, {os.path.getsize(dst)} bytes")
