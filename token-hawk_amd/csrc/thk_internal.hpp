@@ -80,6 +80,7 @@ struct thk_model {
     uint16_t* tok_embeddings = nullptr;
     float* norm = nullptr;
     uint16_t* output = nullptr;
+    void* weights_slab = nullptr; size_t weights_slab_bytes = 0;   // one allocation behind every weight pointer above
     std::vector<SeqBuf> seqs;
     // working buffers shared by all sequences (steps run back to back on one stream)
     float *x = nullptr, *q = nullptr, *u = nullptr, *attn_out = nullptr, *part_o = nullptr, *part_ml = nullptr;
