@@ -80,6 +80,7 @@ struct thk_model {
     uint16_t* tok_embeddings = nullptr;
     float* norm = nullptr;
     uint16_t* output = nullptr;
+    std::vector<void*> arena_chunks; size_t arena_off = 0, arena_cap = 0;   // working buffers (thk_model.cpp, arena_alloc)
     void* weights_slab = nullptr; size_t weights_slab_bytes = 0;   // one allocation behind every weight pointer above
     std::vector<SeqBuf> seqs;
     // working buffers shared by all sequences (steps run back to back on one stream)
