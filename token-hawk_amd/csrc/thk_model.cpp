@@ -815,7 +815,8 @@ static int ensure_prefill_pack(thk_model* m) {
     // wq wk wv wo w1 w2 w3: (rows, cols, tile)
     const int R[7] = {E, E, E, E, F, E, F}, C[7] = {E, E, E, E, E, F, E}, T[7] = {tiles[0], tiles[0], tiles[0], tiles[1], tiles[2], tiles[3], tiles[2]};
     size_t per_layer = 0, off[7];
-    for (int k = 0; k < 7; ++k) { off[k] = per_layer; per_layer += (prefill_pack_bytes(R[k], C[k], T[k]) + 255) / 256 * 256; }
+    const size_t kAlign = (size_t)2 << 20;                  // 2 MiB, as the weight slab (a 1 MiB phase costs the decode kernels 2 %)
+    for (int k = 0; k < 7; ++k) { off[k] = per_layer; per_layer += (prefill_pack_bytes(R[k], C[k], T[k]) + kAlign - 1) / kAlign * kAlign; }
     const size_t bytes = per_layer * nl;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (m->prefill_pk_bytes < bytes) {
