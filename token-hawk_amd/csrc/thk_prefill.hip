@@ -51,7 +51,11 @@ static int current_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 &
 //   * weights also arrive by global_load_lds (quad-coalesced, same swizzle), so no VGPR is tied up
 //     by data in flight and hipcc's waitcnt bookkeeping is out of the picture: completion is counted
 //     by hand (s_waitcnt vmcnt(N), loads retire in order);
-//   * kNST LDS stages of 32 KB => (kNST-1) chunks = 96 KB per CU in flight across a raw s_barrier;
+//   * kNST LDS stages of 32 KB => kNST chunks = 128 KB per CU in flight; one raw s_barrier per chunk; the loop is software-
+//     pipelined across chunks (fragments of chunk g+1 are read and the DMA of chunk g+kNST is issued BETWEEN the MFMAs of
+//     chunk g, see the kernel) because one wave per SIMD hides nothing by occupancy;
+//   * the layer matrices are streamed from TILE IMAGES (pack_w_kernel: a second copy of the weights in exactly the LDS stage
+//     layout, made on the first prefill call) with `nt`, or from the row-major matrices when that copy does not fit;
 //   * a wave owns 64 weight rows (two A fragments share every B fragment read), a workgroup 256 rows x 128 tokens
 //     (NF = 1: 32 rows per wave, 128-row tiles -- half the partial-tile bytes for matrices with few row-blocks);
 //   * stream-K: the (row-block, K-chunk) space of up to three matrices that share the operand
@@ -105,36 +109,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // 16 B/clk/CU instead of 55-64 (tools/probes/glds_rate_probe.hip, profiles/r01_glds_rate_probe.txt).
 __device__ __forceinline__ int swz_pos(int row, int piece) { return piece ^ ((row >> 2) & 3); }
 
-// The loads of one K-chunk (LPS = MT + 2 NF per wave) into LDS stage `sb`: this wave's share of the X image (already
-// in the layout above, so a linear copy) and its own 32 NF weight rows (16 rows x 64 B per instruction).
-// A plain function with by-value arguments: as a by-reference lambda the closure (and every captured local)
-// ended up in scratch.
-template <int MT, int NF>
-__device__ __forceinline__ void v3_issue_chunk(char* sb, const char* xs /* image of the chunk + lane*16 */, const _Float16* wcol /* matrix + chunk column + this lane's piece */,
-                                               int row0 /* loader row of instruction 0 */, int R, int C, int wave) {
-    constexpr int XI = MT * 32 * 64 * 2;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) glds16(xs + (wave + 4 * i) * 1024, sb + (wave + 4 * i) * 1024);
-#pragma unroll
-    for (int j = 0; j < 2 * NF; ++j) {
-        int row = row0 + 16 * j; row = row < R ? row : R - 1;      // rows past the matrix repeat the last one (their outputs are never read)
-        glds16(wcol + (size_t)row * C, sb + XI + (wave * 2 * NF + j) * 1024);
-    }
-}
-// The same chunk when the matrix has been repacked into tile images (pack_w_kernel below): the W half of the stage is one
-// contiguous TR x 64-byte block in global memory, so the loader is a linear copy of full 128-byte lines that nobody else
-// reads => `nt`.  (Row-major weights make every instruction touch 16 rows = 16 DRAM pages, 64 bytes each, and the chip
-// keeps 65536 rows in rotation: the stream tops out at ~4.7 TB/s, profiles/r01_glds_rate_probe.txt.)
-template <int MT, int NF>
-__device__ __forceinline__ void v3_issue_chunk_packed(char* sb, const char* xs, const char* wtile /* tile image of (row-block, chunk) + lane*16 */, int wave) {
-    constexpr int XI = MT * 32 * 64 * 2;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) glds16(xs + (wave + 4 * i) * 1024, sb + (wave + 4 * i) * 1024);
-#pragma unroll
-    for (int j = 0; j < 2 * NF; ++j) glds16<2>(wtile + (wave * 2 * NF + j) * 1024, sb + XI + (wave * 2 * NF + j) * 1024);
-}
-
-// load number k (0 .. MT + 2 NF - 1) of a chunk, same destinations as the two functions above.  `real` false (no chunk left to
+// The loads of one K-chunk into LDS stage `sb`, LPS = MT + 2 NF per wave: this wave's share of the X image (pieces wave, wave+4,
+// ...: the image is already in the layout above, so a linear copy) and its own 32 NF weight rows (16 rows x 64 B per
+// instruction).  Row-major weights: lane -> (row lane>>2 of each 16-row group, piece swz_pos(lane>>2, lane&3)), rows past the
+// matrix repeat the last one (their outputs are never read).  Tile images (pack_w_kernel below): the W half of the stage is one
+// contiguous TR x 64-byte block in global memory, a linear copy of full 128-byte lines that nobody else reads => `nt`.
+// (Row-major weights make every instruction touch 16 rows x 64 bytes, and `nt` would fetch each line twice.)
+// A plain function with by-value arguments: as a by-reference lambda the closure (and every captured local) ended up in scratch.
+// Load number k (0 .. MT + 2 NF - 1) of a chunk.  `real` false (no chunk left to
 // fetch): every lane reads the first 16 bytes of the X image into this wave's 1 KiB of scratch behind the stages — one L2 hit,
 // no stage is touched (in the first step the "pending" half-chunk does not exist yet and every stage is live) — so that the
 // number of loads per step, and with it every s_waitcnt vmcnt in the pipeline, is a constant and the step has no branches.
