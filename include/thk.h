@@ -247,6 +247,12 @@ int64_t thk_model_bytes_per_token(const thk_model* m, int32_t T);
 /* Time the last `n` kernels of interest: enables per-kernel hipEvent timing of one
  * decode step outside graph replay; fills names/ms arrays (diagnostics for bench.py). */
 int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_entries, char (*names)[48], float* ms, int32_t* n_out);
+/* Development aid; needs a library built with -DTHK_TRACE (libthk_trace.so), THK_ERR_STATE otherwise.  Runs one eager decode
+ * step in which every wave of every launch stamps the 100 MHz s_memrealtime counter at four points: kernel entry |
+ * activation vector staged | first weight batch consumed | done.  out = [n_kernels][blocks_per_kernel][8 waves][4] u64, 0 = not
+ * stamped; names in thk_model_profile_step order.  No reference counterpart (the reference times whole passes, th-llama.cpp:640-655). */
+int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long long* out, int64_t cap_words, int32_t max_names, char (*names)[48],
+                         int32_t* n_kernels, int32_t* blocks_per_kernel);
 
 /* ---------------------------------------------------------------- pipeline hand-off (config C4)
  * Point-to-point RCCL over xGMI between pipeline stages (one process per GPU).  New functionality:

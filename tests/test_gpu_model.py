@@ -56,12 +56,10 @@ def test_tiny_model_every_token_vs_oracle(thk, orc, ctx, splits, use_graph):
     m.close()
 
 
-@pytest.mark.parametrize("tunables", [{"fuse_attn_wo": 1, "attn_splits": 2}, {"fuse_attn_wo": 1, "attn_splits": 4}, {"fuse_attn_wo": 1, "attn_splits": 8},
-                                      {"attn_combine": 1, "attn_splits": 2}, {"attn_combine": 1, "attn_splits": 4}, {"attn_combine": 1, "attn_splits": 8},
-                                      {"attn_waves": 4}])
+@pytest.mark.parametrize("tunables", [{"attn_waves": 4}, {"attn_waves": 4, "attn_splits": 8}, {"fold_embed": 0}, {"fold_embed": 0, "use_graph": 0}])
 def test_optional_paths_vs_oracle(thk, orc, ctx, tunables):
-    """The off-by-default experiments stay correct: fused attention+wo launch with the
-    in-launch hand-off, last-arriver split combine, 4-wave attention blocks."""
+    """The off-by-default options stay correct: 4-wave attention blocks, the stand-alone embedding launch (default: the row is
+    fetched by layer 0's qkv prologue)."""
     m, om = make_pair(thk, orc, ctx, "TINY", tunables=tunables)
     rng = np.random.default_rng(5)
     toks = [1] + rng.integers(3, 2048, 30).tolist()
@@ -224,13 +222,27 @@ def test_error_paths(thk, ctx):
 
 
 # ------------------------------------------------------------------ 7B / 13B dimensions
+GEMV_KERNELS = ("qkv", "wo", "w13", "w2", "head")
+
+
+@pytest.mark.parametrize("variant", [None, 0, 3, 5, 6, 7])
 @pytest.mark.parametrize("E,H,L,name", [(4096, 32, 2, "7B-dims"), (5120, 40, 1, "13B-dims")])
-def test_full_width_layers_vs_oracle(thk, orc, ctx, E, H, L, name):
-    """Real 7B/13B row geometry (E, F=11008/13824, V=32000, T up to 512) on a 1-2 layer model:
-    exercises every compile-time-specialised kernel against the oracle's fast flavour."""
-    shape = thk.ModelShape(n_embd=E, n_head=H, n_layer=L)
-    oshape = orc.ModelShape(n_embd=E, n_head=H, n_layer=L)
-    m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+def test_full_width_layers_vs_oracle(thk, orc, ctx, E, H, L, name, variant):
+    """Real 7B/13B row geometry (E, F=11008/13824, V=32000, T up to 512) on a 1-2 layer model: exercises every
+    compile-time-specialised kernel against the oracle's fast flavour - with the default launch geometry (None) and with every
+    mat-vec forced to one loop variant (batch loops 0-4, software-pipelined loops 5-7), so each fused prologue/epilogue
+    (norm, embedding fetch, split combine | RoPE + K/V append, residual, SwiGLU, lm-head + arg-max) runs in both loop forms."""
+    tun = {} if variant is None else {f"gemv_variant_{k}": variant for k in GEMV_KERNELS}
+    old = {k: ctx.get_tunable(k) for k in tun}
+    for k, v in tun.items():
+        ctx.set_tunable(k, v)
+    try:
+        shape = thk.ModelShape(n_embd=E, n_head=H, n_layer=L)
+        oshape = orc.ModelShape(n_embd=E, n_head=H, n_layer=L)
+        m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    finally:
+        for k, v in old.items():
+            ctx.set_tunable(k, v)
     om = orc.OracleModel(oshape); om.fill_synthetic()
     rng = np.random.default_rng(E)
     toks = [1] + rng.integers(3, 32000, 5).tolist()

@@ -35,10 +35,12 @@ def test_matvec_f16(ctx, orc, R, C):
     assert np.abs(got - exp).max() < TOL * max(1.0, np.abs(exp).max())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("bpc", [1, 4, 8])
 def test_matvec_variants_and_grids(ctx, orc, variant, bpc):
-    """Every (rows/iteration, slots/batch) variant and grid size gives the same answer."""
+    """Every (rows/iteration, slots/batch) variant - batch loops 0-4, software-pipelined loops 5-7 - and grid size gives the
+    same answer (a wave takes 1, 2 or more row groups depending on the grid, so the pipelined refill and its last-group
+    epilogue are both exercised)."""
     rng = np.random.default_rng(variant * 7 + bpc)
     old = {k: ctx.get_tunable(k) for k in ("gemv_variant_wo", "gemv_variant_w2", "gemv_blocks_per_cu")}
     try:

@@ -319,6 +319,15 @@ class Model:
         self.ctx.check(self.ctx.lib.thk_model_engine_trace(self.h, out.ctypes.data, cap, C.byref(ncu), C.byref(nops)), "thk_model_engine_trace")
         return out[:ncu.value * nops.value * 8].reshape(ncu.value, nops.value, 8)
 
+    def step_trace(self, seq: int = 0):
+        """Development timeline of one eager decode step (libthk_trace.so): (names, uint64 [n_kernels, blocks, 8 waves, 4] of 100 MHz stamps)."""
+        cap = (6 * (self.l1 - self.l0) + 8) * 2048 * 32
+        out = np.zeros(cap, np.uint64)
+        names = ((C.c_char * 48) * 512)()
+        nk, nb = C.c_int32(), C.c_int32()
+        self.ctx.check(self.ctx.lib.thk_model_step_trace(self.h, seq, out.ctypes.data, cap, 512, names, C.byref(nk), C.byref(nb)), "thk_model_step_trace")
+        return [names[i].value.decode() for i in range(nk.value)], out[:nk.value * nb.value * 32].reshape(nk.value, nb.value, 8, 4)
+
     def uses_engine(self) -> bool:
         """True when decode steps run as one persistent loader/consumer launch (thk_engine.hip)."""
         return bool(self.ctx.lib.thk_model_uses_engine(self.h))

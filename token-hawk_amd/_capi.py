@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libthk.so")
+LIB_PATH = os.environ.get("THK_LIB") or os.path.join(_HERE, "libthk.so")   # THK_LIB: development builds (libthk_trace.so)
 
 THK_OK = 0
 THK_F32, THK_F16 = 0, 1
@@ -85,6 +85,7 @@ SIGNATURES = {
     "thk_model_seq_get": (C.c_int, [vp, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]),
     "thk_model_bytes_per_token": (i64, [vp, i32]),
     "thk_model_profile_step": (C.c_int, [vp, i32, i32, vp, vp, C.POINTER(i32)]),
+    "thk_model_step_trace": (C.c_int, [vp, i32, vp, i64, i32, vp, C.POINTER(i32), C.POINTER(i32)]),
     "thk_model_n_embd": (i32, [vp]),
     "thk_pp_get_unique_id": (C.c_int, [vp]),
     "thk_pp_create": (C.c_int, [vp, C.c_int, C.c_int, vp, pp]),

@@ -30,28 +30,28 @@ void default_tunables(thk_ctx* ctx) {
     }
     ctx->tun["attn_splits"] = 4;          // context splits per head (1,2,4,8)
     ctx->tun["attn_waves"] = 8;           // waves per attention block (4 or 8)
-    ctx->tun["attn_combine"] = 0;         // last-arriving split block of a head merges the partials inside the attention launch (measured: slower)
+    ctx->tun["fold_embed"] = 1;           // the embedding row is fetched by layer 0's qkv prologue instead of a launch of its own
     ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
-    ctx->tun["fuse_attn_wo"] = 0;         // attention splits + wo mat-vec in one launch (in-launch hand-off)
     ctx->tun["measure_skip_kernel"] = 0;  // bench.py: marginal cost of one kernel = step time with minus without it (results are garbage then);
                                           // refused unless the process runs with THK_MEASURE_HOOKS=1 (never in a product)
+    ctx->tun["measure_gain_alias"] = 0;   // measurement only (THK_MEASURE_HOOKS=1): the RMS prologues read the activation vector in place of the gain vector
     ctx->tun["kv_f16"] = 0;               // 1 = K/V caches stored as binary16 (half the KV bytes; k, v are rounded RNE at the append); default f32 as the reference
     ctx->tun["engine_park"] = 1;          // engine variant whose waiting consumer waves park one landed ring slot in registers (more loader run-ahead)
     ctx->tun["engine_trace"] = 0;         // development: per-op s_memtime timeline of the engine (thk_model_engine_trace)
     ctx->tun["engine"] = 0;               // 1 = decode step as ONE persistent loader/consumer launch (thk_engine.hip) when the shape allows; default 0 = 5
                                           // launches per layer: measured on MI355X the engine streams at 6.9-7.0 TB/s but every in-launch all-to-all hand-off
                                           // costs ~7 us against ~3.5 us for a kernel boundary (profiles/r02_engine_*.txt), 3.4 vs 2.5 ms per 7B token
-    ctx->tun["fuse_initial_sleeps"] = 0;  // consumer s_sleep(32) repetitions (~0.85 us each) before the first poll
 }
-// Auto launch geometry per (kernel, n_embd): {blocks per CU, variant}.  7B and 13B rows are swept values; other
-// widths take the 7B row.
+// Auto launch geometry per (kernel, n_embd): {blocks per CU, variant}.  7B and 13B rows are swept values (round 3: tools/ab.py on
+// the graph-replayed step, profiles/r03_ab_*.jsonl; the software-pipelined variants 5/6 won every 7B kernel but w2); other widths
+// take the 7B row (their run-time slot count maps the pipelined variants back to variant 0).
 Geo auto_geometry(const char* kernel, int n_embd) {
     const bool w13b = n_embd == 5120;
-    if (!strcmp(kernel, "qkv")) return w13b ? Geo{3, 3} : Geo{3, 0};
-    if (!strcmp(kernel, "wo")) return w13b ? Geo{2, 0} : Geo{2, 3};   // 7B: variant 3 is +0.5 % in graph mode (profiles/r01_sweep_graph_7b.json)
-    if (!strcmp(kernel, "w13")) return w13b ? Geo{8, 1} : Geo{8, 0};
-    if (!strcmp(kernel, "w2")) return Geo{2, 2};
-    if (!strcmp(kernel, "head")) return w13b ? Geo{8, 2} : Geo{8, 1};
+    if (!strcmp(kernel, "qkv")) return w13b ? Geo{3, 3} : Geo{3, 5};
+    if (!strcmp(kernel, "wo")) return Geo{1, 6};
+    if (!strcmp(kernel, "w13")) return w13b ? Geo{8, 5} : Geo{4, 5};
+    if (!strcmp(kernel, "w2")) return w13b ? Geo{1, 5} : Geo{2, 2};
+    if (!strcmp(kernel, "head")) return w13b ? Geo{8, 2} : Geo{8, 6};
     return Geo{4, 0};
 }
 int resolve_variant(thk_ctx* ctx, const char* kernel, int n_embd) {
@@ -168,9 +168,9 @@ extern "C" int thk_set_tunable(thk_ctx* ctx, const char* name, int64_t value) {
     if (!ctx || !name) return THK_ERR_INVALID;
     auto it = ctx->tun.find(name);
     if (it == ctx->tun.end()) return fail(ctx, THK_ERR_NOTFOUND, "unknown tunable '%s'", name);
-    if (!strcmp(name, "measure_skip_kernel") && value != 0) {
+    if ((!strcmp(name, "measure_skip_kernel") || !strcmp(name, "measure_gain_alias")) && value != 0) {
         const char* hook = getenv("THK_MEASURE_HOOKS");
-        if (!hook || strcmp(hook, "1")) return fail(ctx, THK_ERR_INVALID, "measure_skip_kernel makes a model skip work; it is only accepted with THK_MEASURE_HOOKS=1 in the environment");
+        if (!hook || strcmp(hook, "1")) return fail(ctx, THK_ERR_INVALID, "%s makes a model compute garbage; it is only accepted with THK_MEASURE_HOOKS=1 in the environment", name);
     }
     it->second = value;
     return THK_OK;

@@ -67,7 +67,6 @@ struct SeqBuf {
 
 static const int kGenLogCap = 4096;
 static const int kMultiSteps[3] = {2, 4, 8};
-static const size_t kFuseStride = 1024;   // words per layer: counter line + kFuseFlags flag lines, padded
 
 struct thk_model {
     thk_ctx* ctx = nullptr;
@@ -98,18 +97,19 @@ struct thk_model {
     int pk_tiles[4] = {0, 0, 0, 0};      // tile rows (qkv, wo, w13, w2) the images were made with; 0 = none
     bool pk_failed = false;              // the slab did not fit once: stay on row-major weights
     std::vector<std::array<const uint16_t*, 7>> pk_w;
-    // fused attention+wo launch: per-layer arrival counters (zeroed at the start of every step) + error word
-    int fuse_attn_wo = 0, fuse_initial_sleeps = 0, attn_waves = 8, attn_combine = 0;
+    int attn_waves = 8;
+    int gain_alias = 0;    // measurement aid (tunable measure_gain_alias)
     int skip_kernel = 0;   // measurement aid (tunable measure_skip_kernel): 1 qkv, 2 attention, 3 wo, 4 w13, 5 w2, 6 lm-head are NOT launched
-    unsigned* head_ticket = nullptr;   // [H] counters of the in-launch split combine
-    unsigned* fuse_counters = nullptr;   // [n_local_layers] then [1] error
     // persistent loader/consumer engine (thk_engine.hip): one launch per decode step instead of 5 per layer
+    int fold_embed = 1;                  // tunable fold_embed: layer 0's qkv prologue fetches the embedding row (no embed launch)
     int kv_f16 = 0;                      // tunable kv_f16 at finalize: K/V caches stored as binary16 (default 0 = f32, as the reference)
     int engine = 0;                      // resolved at finalize (tunable "engine" and shape eligibility)
     int eng_NS = 0, eng_v0 = 0, eng_v1 = 0, eng_nsplit = 1, eng_tc = 0;
     unsigned long long* eng_gran = nullptr;   // all granule arrays: XG[2][E] | QG[3E] | OG[E] | UG[F] | PG[H*S*(D+2)]
     unsigned* eng_words = nullptr;       // [0] epoch, [32] error word
     unsigned long long* eng_trace = nullptr;   // development timeline (tunable engine_trace), [n_cu][n_ops][8]
+    unsigned long long* trace_buf = nullptr;   // development timeline of the launch path (thk_model_step_trace, THK_TRACE builds)
+    bool trace_on = false;
 };
 
 // ---------------------------------------------------------------- helpers (thk_ctx.cpp)

@@ -19,12 +19,36 @@
 //     serves every token.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include "thk_kernels.hpp"
 
 namespace thk {
 
+// Development timeline (libthk_trace.so only, built with -DTHK_TRACE; tools/step_trace.py): every wave stamps the 100 MHz
+// s_memrealtime counter at up to four points of its kernel into [workgroup][wave (8)][4].  Scalar instructions only (the stamp
+// is written with s_store_dwordx2, flushed by s_dcache_wb at the last one): no VGPR, no exec-mask branch, so the register
+// allocation and occupancy of the traced build stay those of the product build.  In the product build the macro is empty.
+#ifdef THK_TRACE
+__device__ __forceinline__ void thk_stamp(unsigned long long* tr, int bid, int slot) {
+    if (tr) {                                                            // kernel argument: a scalar branch
+        unsigned long long t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+        const unsigned off = __builtin_amdgcn_readfirstlane(((unsigned)bid * 8u + (threadIdx.x >> 6)) * 32u + (unsigned)slot * 8u);
+        asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(t), "s"(tr), "s"(off));
+        if (slot == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
+    }
+}
+// THK_TRACE=1 stamps kernel entry and exit only (register allocation identical to the product build, checked with
+// -Rpass-analysis=kernel-resource-usage); THK_TRACE=2 adds the two inner stamps, which cost the mat-vec kernels 20+ VGPRs.
+#define THK_STAMP(tr, bid, slot) do { if (THK_TRACE >= 2 || (slot) == 0 || (slot) == 3) thk_stamp((tr), (bid), (slot)); } while (0)
+#else
+#define THK_STAMP(tr, bid, slot) do { } while (0)
+#endif
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------- wave reductions
 // DPP butterfly inside each row of 16 lanes (quad_perm, row_half_mirror,
@@ -68,13 +92,17 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float block_sum(float v, float* red /* >= 4 floats of LDS */) {
+template <int WPB = kWaves>
+__device__ __forceinline__ float block_sum(float v, float* red /* >= WPB floats of LDS */) {
     v = wave_sum(v);
     const int w = threadIdx.x >> 6;
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[w] = v;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    float t = 0.f;
+    if (WPB == 4) t = (red[0] + red[1]) + (red[2] + red[3]);
+    else { t = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])); }
+    return t;
 }
 
 // ---------------------------------------------------------------- LDS x-vector layout
@@ -93,51 +121,8 @@ __device__ __forceinline__ int xs_index(int e, int ns) {   // float index in LDS
 // Store index for float4 #i of the padded vector; threads past the end (only possible when the
 // slot count is odd) are steered to a dummy 16-byte slot behind the vector instead of branching.
 __device__ __forceinline__ int xs_store_index(int i, int ns) {
-    return (i < (ns << 7)) ? xs_index(i << 2, ns) : (ns << 9) + 12;
+    return (i < (ns << 7)) ? xs_index(i << 2, ns) : (ns << 9) + 8;
 }
-
-// In-launch producer -> consumer hand-off (guide recipe R1): producers publish with write-through
-// (sc1) stores, drain, and bump a device-scope counter; consumers issue their weight loads, poll
-// the counter relaxed (one thread, s_sleep, bounded), then read the payload with sc1 loads.
-// The last-arriving producer (ticket == target-1) raises kFuseFlags replicated flag words, one
-// per 128-byte line, so the consumers' polls are spread over several L2 channels instead of
-// hammering the arrival counter (guide: fan-in / polling-cost rows).
-__device__ __forceinline__ void fuse_signal(const FuseSync& fs) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave drains its sc1 stores
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        unsigned ticket = 0;
-        if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(fs.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ticket = __builtin_amdgcn_readfirstlane(ticket);
-        if (ticket == fs.target - 1 && threadIdx.x < kFuseFlags)
-            __hip_atomic_store(fs.flags + threadIdx.x * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-__device__ __forceinline__ void fuse_wait(const FuseSync& fs, int bid) {
-    if (threadIdx.x == 0) {
-        const unsigned* flag = fs.flags + (bid % kFuseFlags) * 32;
-        for (unsigned k = 0; k < fs.initial_sleeps; ++k) __builtin_amdgcn_s_sleep(32);   // producers need a few us anyway
-        unsigned spins = 0;
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > fs.spin_limit) { __hip_atomic_store(fs.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-        }
-    }
-    __syncthreads();
-}
-__device__ __forceinline__ f4 load_f4_sc1(const float* p) {   // two 8-byte agent-scope (sc1) loads
-    const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    f4 r;
-    r.x = __builtin_bit_cast(float, (unsigned)a); r.y = __builtin_bit_cast(float, (unsigned)(a >> 32));
-    r.z = __builtin_bit_cast(float, (unsigned)b); r.w = __builtin_bit_cast(float, (unsigned)(b >> 32));
-    return r;
-}
-__device__ __forceinline__ float2 load_f2_sc1(const float* p) {
-    const unsigned long long a = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return float2{__builtin_bit_cast(float, (unsigned)a), __builtin_bit_cast(float, (unsigned)(a >> 32))};
-}
-
 
 // ---------------------------------------------------------------- GEMV prologues
 // All run with the whole block; on return xs[] holds the activation vector and a
@@ -151,33 +136,30 @@ __device__ __forceinline__ float2 load_f2_sc1(const float* p) {
 //              issued first), reduce / combine, write LDS, __syncthreads()
 // => the prologue's latency and math hide under the HBM latency of the first weight batch.
 // With a run-time slot count (NS == 0) issue() is empty and finish() loops.
-template <int NS> struct PrologueK { static constexpr int value = NS ? (NS * 128 + kBlock - 1) / kBlock : 1; };
+template <int NS, int WPB> struct PrologueK { static constexpr int value = NS ? (NS * 128 + WPB * 64 - 1) / (WPB * 64) : 1; };
 
 // plain copy (th.cpp K1 with no fused producer)
-template <int NS>
+template <int NS, int WPB>
 struct ProCopy {
-    static constexpr int KP = PrologueK<NS>::value;
+    static constexpr int KP = PrologueK<NS, WPB>::value;
+    static constexpr int BT = WPB * 64;
     f4 v[KP];
-    template <bool SC1>
     __device__ __forceinline__ void issue(const GemvArgs& a) {
         if (NS == 0) return;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const float* p = a.x + min((int)(threadIdx.x + k * kBlock) << 2, a.C - 4);
-            v[k] = SC1 ? load_f4_sc1(p) : *reinterpret_cast<const f4*>(p);
-        }
+        for (int k = 0; k < KP; ++k) v[k] = *reinterpret_cast<const f4*>(a.x + min((int)(threadIdx.x + k * BT) << 2, a.C - 4));
     }
-    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns) {
+    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns, int) {
         const int C = a.C;
         if (NS != 0) {
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                const int i = threadIdx.x + k * kBlock;
+                const int i = threadIdx.x + k * BT;
                 const f4 o = ((i << 2) < C) ? v[k] : f4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = o;
             }
         } else {
-            for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
+            for (int i = threadIdx.x; i < (ns << 7); i += BT) {
                 f4 o = {0.f, 0.f, 0.f, 0.f};
                 if ((i << 2) < C) o = *reinterpret_cast<const f4*>(a.x + (i << 2));
                 *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = o;
@@ -188,50 +170,66 @@ struct ProCopy {
 };
 
 // RMSNorm + gain (K4 th.cpp:1169-1198, K5 :1311-1313): xs = (x * inv) * g
-template <int NS>
+// EMB: the input vector is the embedding row of the sequence's current token (loader :185-195, th-llama.cpp:577-584: x =
+// f32(table[token,:])), fetched here instead of by a launch of its own; block 0 also writes the f32 row to a.x_out, which
+// the layer's residual add reads two launches later.
+template <int NS, bool EMB, int WPB>
 struct ProRms {
-    static constexpr int KP = PrologueK<NS>::value;
+    static constexpr int KP = PrologueK<NS, WPB>::value;
+    static constexpr int BT = WPB * 64;
     f4 v[KP], g[KP];
-    template <bool SC1>
+    __device__ __forceinline__ f4 ldx(const GemvArgs& a, const _Float16* row, int ic) {
+        if (EMB) {
+            const h4 h = *reinterpret_cast<const h4*>(row + ic);
+            return f4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        }
+        return *reinterpret_cast<const f4*>(a.x + ic);
+    }
     __device__ __forceinline__ void issue(const GemvArgs& a) {
         if (NS == 0) return;
+        const _Float16* row = EMB ? reinterpret_cast<const _Float16*>(a.embed) + (size_t)(*a.tok_ptr) * a.C : nullptr;
 #pragma unroll
         for (int k = 0; k < KP; ++k) {
-            const int ic = min((int)(threadIdx.x + k * kBlock) << 2, a.C - 4);     // branch-free: clamp, select later
-            v[k] = SC1 ? load_f4_sc1(a.x + ic) : *reinterpret_cast<const f4*>(a.x + ic);
+            const int ic = min((int)(threadIdx.x + k * BT) << 2, a.C - 4);     // branch-free: clamp, select later
+            v[k] = ldx(a, row, ic);
             g[k] = *reinterpret_cast<const f4*>(a.gain + ic);
         }
     }
-    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float* red, int ns) {
+    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float* red, int ns, int bid) {
         const int C = a.C;
         if (NS != 0) {
             float ss = 0.f;
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                const int i = threadIdx.x + k * kBlock;
+                const int i = threadIdx.x + k * BT;
                 if ((i << 2) >= C) v[k] = f4{0.f, 0.f, 0.f, 0.f};
+                else if (EMB && bid == 0) *reinterpret_cast<f4*>(a.x_out + (i << 2)) = v[k];
                 ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
             }
-            ss = block_sum(ss, red);
+            ss = block_sum<WPB>(ss, red);
             const float inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                const int i = threadIdx.x + k * kBlock;
+                const int i = threadIdx.x + k * BT;
                 f4 o;
                 o.x = (v[k].x * inv) * g[k].x; o.y = (v[k].y * inv) * g[k].y; o.z = (v[k].z * inv) * g[k].z; o.w = (v[k].w * inv) * g[k].w;
                 *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = o;
             }
         } else {
+            const _Float16* row = EMB ? reinterpret_cast<const _Float16*>(a.embed) + (size_t)(*a.tok_ptr) * C : nullptr;
             float ss = 0.f;
-            for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
+            for (int i = threadIdx.x; i < (ns << 7); i += BT) {
                 f4 t = {0.f, 0.f, 0.f, 0.f};
-                if ((i << 2) < C) t = *reinterpret_cast<const f4*>(a.x + (i << 2));
+                if ((i << 2) < C) {
+                    t = ldx(a, row, i << 2);
+                    if (EMB && bid == 0) *reinterpret_cast<f4*>(a.x_out + (i << 2)) = t;
+                }
                 ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
                 *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = t;   // raw copy, normalised below
             }
-            ss = block_sum(ss, red);
+            ss = block_sum<WPB>(ss, red);
             const float inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
-            for (int i = threadIdx.x; i < (C >> 2); i += kBlock) {
+            for (int i = threadIdx.x; i < (C >> 2); i += BT) {
                 const f4 gg = *reinterpret_cast<const f4*>(a.gain + (i << 2));
                 f4* p = reinterpret_cast<f4*>(xs + xs_index(i << 2, ns));
                 f4 t = *p;   // same thread wrote it
@@ -258,54 +256,54 @@ __device__ __forceinline__ f4 attn_merge(const float2 (&ml)[NSP], const f4 (&ov)
     }
     return o * (1.0f / L);
 }
-template <int NS, int NSP>
+template <int NS, int NSP, int WPB>
 struct ProAttn {
-    static constexpr int KP = PrologueK<NS>::value;
+    static constexpr int KP = PrologueK<NS, WPB>::value;
+    static constexpr int BT = WPB * 64;
     float2 ml[KP][NSP];
     f4 ov[KP][NSP];
-    template <bool SC1>
     __device__ __forceinline__ void load1(const GemvArgs& a, int e, float2 (&m)[NSP], f4 (&o)[NSP]) {
         const int h = e / a.D, d = e - h * a.D;
 #pragma unroll
         for (int s = 0; s < NSP; ++s) {
             const float* pm = a.part_ml + (h * NSP + s) * 2;
             const float* po = a.part_o + (size_t)(h * NSP + s) * a.D + d;
-            m[s] = SC1 ? load_f2_sc1(pm) : *reinterpret_cast<const float2*>(pm);
-            o[s] = SC1 ? load_f4_sc1(po) : *reinterpret_cast<const f4*>(po);
+            m[s] = *reinterpret_cast<const float2*>(pm);
+            o[s] = *reinterpret_cast<const f4*>(po);
         }
     }
-    template <bool SC1>
     __device__ __forceinline__ void issue(const GemvArgs& a) {
         if (NS == 0) return;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) load1<SC1>(a, min((int)(threadIdx.x + k * kBlock) << 2, a.C - 4), ml[k], ov[k]);
+        for (int k = 0; k < KP; ++k) load1(a, min((int)(threadIdx.x + k * BT) << 2, a.C - 4), ml[k], ov[k]);
     }
-    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns) {
+    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns, int) {
         const int C = a.C;
         if (NS != 0) {
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                const int i = threadIdx.x + k * kBlock;
+                const int i = threadIdx.x + k * BT;
                 f4 res = attn_merge<NSP>(ml[k], ov[k]);
                 if ((i << 2) >= C) res = f4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = res;
             }
         } else {
-            for (int i = threadIdx.x; i < (ns << 7); i += kBlock) {
+            for (int i = threadIdx.x; i < (ns << 7); i += BT) {
                 f4 res = {0.f, 0.f, 0.f, 0.f};
-                if ((i << 2) < C) { float2 m[NSP]; f4 o[NSP]; load1<false>(a, i << 2, m, o); res = attn_merge<NSP>(m, o); }
+                if ((i << 2) < C) { float2 m[NSP]; f4 o[NSP]; load1(a, i << 2, m, o); res = attn_merge<NSP>(m, o); }
                 *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = res;
             }
         }
         __syncthreads();
     }
 };
-template <int NS, int PRO, int NSP> struct ProSelect { typedef ProCopy<NS> type; };
-template <int NS, int NSP> struct ProSelect<NS, GEMV_PRO_RMS, NSP> { typedef ProRms<NS> type; };
-template <int NS, int NSP> struct ProSelect<NS, GEMV_PRO_ATTN, NSP> { typedef ProAttn<NS, (NSP > 0 ? NSP : 1)> type; };
+template <int NS, int PRO, int NSP, int WPB> struct ProSelect { typedef ProCopy<NS, WPB> type; };
+template <int NS, int NSP, int WPB> struct ProSelect<NS, GEMV_PRO_RMS, NSP, WPB> { typedef ProRms<NS, false, WPB> type; };
+template <int NS, int NSP, int WPB> struct ProSelect<NS, GEMV_PRO_RMS_EMBED, NSP, WPB> { typedef ProRms<NS, true, WPB> type; };
+template <int NS, int NSP, int WPB> struct ProSelect<NS, GEMV_PRO_ATTN, NSP, WPB> { typedef ProAttn<NS, (NSP > 0 ? NSP : 1), WPB> type; };
 
 // ---------------------------------------------------------------- GEMV core
-enum { PRO_COPY = GEMV_PRO_COPY, PRO_RMS = GEMV_PRO_RMS, PRO_ATTN = GEMV_PRO_ATTN };
+enum { PRO_COPY = GEMV_PRO_COPY, PRO_RMS = GEMV_PRO_RMS, PRO_ATTN = GEMV_PRO_ATTN, PRO_RMS_EMBED = GEMV_PRO_RMS_EMBED };
 enum { EPI_STORE = GEMV_EPI_STORE, EPI_RESID = GEMV_EPI_RESID, EPI_ROPE_KV = GEMV_EPI_ROPE_KV, EPI_SWIGLU = GEMV_EPI_SWIGLU,
        EPI_HEAD = GEMV_EPI_HEAD };
 
@@ -337,20 +335,21 @@ __device__ __forceinline__ unsigned long long argmax_key(float v, unsigned idx) 
 // NS = compile-time slot count (C = NS*512 or NS*512-256), 0 = run-time (any C % 256 == 0).
 // U = slots per load batch (NS % U == 0 when NS != 0): NR*U 16-byte loads per lane are issued
 // back to back with no intervening branch or wait.
-// bid / nblk: this block's index and the number of blocks working on the op (== blockIdx.x /
-// gridDim.x for a stand-alone launch; a sub-range of the grid inside a fused launch).
-// SYNC: the activation vector is produced by other blocks of the SAME launch (a.fs).
-template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool SYNC>
+// bid / nblk: this block's index and the number of blocks working on the op (== blockIdx.x / gridDim.x).
+template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool PIPE, int WPB = kWaves>
 __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, const int nblk) {
+    static_assert(!PIPE || (NS != 0 && U == NS), "the pipelined loop keeps one whole row group in flight");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int C = a.C;
     const int nvec = C >> 3;                                  // 16-byte vectors per row
     const int ns = NS ? NS : ((nvec + 63) >> 6);
     float* xs = smem;                 // ns*512 floats
-    float* red = smem + (ns << 9);    // floats 0-3: reduction, 4-11: EPI_HEAD scratch, 12-15: dummy store slot
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wave_global = bid * kWaves + wave;
-    const int total_waves = nblk * kWaves;
+    float* red = smem + (ns << 9);    // floats 0-7: reduction, 8-11: dummy store slot, 12-27: EPI_HEAD scratch (one u64 per wave)
+    // the wave index is read into an SGPR: row numbers and row pointers become scalar, so every weight load is
+    // `global_load_dwordx4 v, v_lane_offset, s[row]` instead of carrying a 64-bit address per lane
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_global = bid * WPB + wave;
+    const int total_waves = nblk * WPB;
     const f4* xlo = reinterpret_cast<const f4*>(xs);
     const f4* xhi = reinterpret_cast<const f4*>(xs + (ns << 8));
     const int half_c = C >> 1;
@@ -406,7 +405,22 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
 
     unsigned long long best = 0ull;   // EPI_HEAD running arg-max of this wave (valid in lane 0)
 
-    auto finish_group = [&](int g, float (&acc)[NR], float (&acc_hi)[NR]) {
+    // Epilogue operands of a group (residuals / RoPE cos,sin).  The pipelined loop fetches them BEFORE it refills the ring with
+    // the next group's weights: vmcnt retires in order, so a load issued behind the refill could only be waited for by draining
+    // the whole prefetch.
+    struct EpiOps { float resid[NR]; float cs, sn; };
+    const int pos_pipe = (PIPE && EPI == EPI_ROPE_KV) ? (a.pos_ptr ? *a.pos_ptr : a.pos_val) : 0;
+    auto epi_fetch = [&](int g, EpiOps& eo) {
+        if (EPI == EPI_RESID) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) eo.resid[r] = a.resid[min(NR * g + r, a.R - 1)];      // wave-uniform address: one request
+        } else if (EPI == EPI_ROPE_KV) {
+            const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E, j = rr % a.D;
+            const float2 t = *reinterpret_cast<const float2*>(a.rope_tab + ((size_t)pos_pipe * (a.D >> 1) + (j >> 1)) * 2);
+            eo.cs = t.x; eo.sn = t.y;
+        }
+    };
+    auto finish_group = [&](int g, float (&acc)[NR], float (&acc_hi)[NR], const EpiOps* eo = nullptr) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) { acc[r] = wave_sum(acc[r]); if (EPI == EPI_HEAD) acc_hi[r] = wave_sum(acc_hi[r]); }
         if (EPI == EPI_STORE) {
@@ -417,17 +431,17 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         } else if (EPI == EPI_RESID) {       // K11 th.cpp:2136-2147: c = a + b
             if (lane == 0) {
 #pragma unroll
-                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) a.y[NR * g + r] = a.resid[NR * g + r] + acc[r];
+                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) a.y[NR * g + r] = (eo ? eo->resid[r] : a.resid[NR * g + r]) + acc[r];
             }
         } else if (EPI == EPI_ROPE_KV) {     // K6 th.cpp:1476-1490 + K/V append th-llama.cpp:332-339
             if (lane == 0) {
-                const int pos = a.pos_ptr ? *a.pos_ptr : a.pos_val;
+                const int pos = PIPE ? pos_pipe : (a.pos_ptr ? *a.pos_ptr : a.pos_val);
                 const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E;
                 float y0 = acc[0], y1 = acc[1 % NR];
                 if (which < 2) {
                     const int j = rr % a.D;    // even
-                    const float cs = a.rope_tab[((size_t)pos * (a.D >> 1) + (j >> 1)) * 2];
-                    const float sn = a.rope_tab[((size_t)pos * (a.D >> 1) + (j >> 1)) * 2 + 1];
+                    const float cs = eo ? eo->cs : a.rope_tab[((size_t)pos * (a.D >> 1) + (j >> 1)) * 2];
+                    const float sn = eo ? eo->sn : a.rope_tab[((size_t)pos * (a.D >> 1) + (j >> 1)) * 2 + 1];
                     const float t0 = y0 * cs - y1 * sn, t1 = y0 * sn + y1 * cs;
                     y0 = t0; y1 = t1;
                 }
@@ -458,6 +472,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         }
     };
 
+    THK_STAMP(a.trace, bid, 0);
     // --- memory traffic is ordered: activation loads, then the wave's first weight batch (weights
     // do not depend on the activations), then the prologue math while the weights are in flight.
     int g = wave_global;
@@ -465,92 +480,145 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     const h8* rp0[NR];
     h8 w0[NR][U];
     row_ptrs(has_first ? g : a.n_groups - 1, rp0);   // idle waves (more waves than groups) load a valid row:
-    typename ProSelect<NS, PRO, NSP>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
-    if (SYNC) {
-        load_batch(rp0, 0, w0);                      // weights stream in while the producers are still running
-        __builtin_amdgcn_sched_barrier(0);
-        fuse_wait(a.fs, bid);
-        pro.template issue<true>(a);
-    } else {
-        pro.template issue<false>(a);
-        __builtin_amdgcn_sched_barrier(0);
-        load_batch(rp0, 0, w0);
-    }
+    typename ProSelect<NS, PRO, NSP, WPB>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
+    pro.issue(a);
     __builtin_amdgcn_sched_barrier(0);
-    pro.finish(a, xs, red, ns);
+    load_batch(rp0, 0, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    pro.finish(a, xs, red, ns, bid);
+    THK_STAMP(a.trace, bid, 1);
 
+    if constexpr (PIPE) {
+        // Software-pipelined stream: the ring w0 holds one whole row group (NR*NS 16-byte loads per lane).  Slot c of the NEXT
+        // group is requested as soon as slot c of the current one has been consumed, so the wave keeps a constant NR*NS KiB in
+        // flight from its first load to its last - no drain between batches or groups even at one wave per SIMD.
+        auto slot_loads = [&](const h8* const (&rp)[NR], int c, h8 (&w)[NR][U]) {
+            const int v = c * 64 + lane;
+            const int vc = (c == NS - 1) ? min(v, vlast) : v;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) w[r][c] = ldw<NT>(rp[r] + vc);
+        };
+        auto slot_fma = [&](int c, const h8 (&w)[NR][U], float (&acc)[NR], float (&acc_hi)[NR]) {
+            const int v = c * 64 + lane;
+            const f4 xl = xlo[v], xh = xhi[v];
+            if (EPI == EPI_HEAD) {
+                const bool hi = (v << 3) >= half_c;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const float p = dot8(w[r][c], xl, xh, 0.f);
+                    acc[r] += hi ? 0.f : p; acc_hi[r] += hi ? p : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[r] = dot8(w[r][c], xl, xh, acc[r]);
+            }
+        };
+        if (has_first) {
+            for (int gn = g + total_waves; gn < a.n_groups; g = gn, gn += total_waves) {     // steady state: every consume is followed by a refill
+                const h8* rpn[NR];
+                row_ptrs(gn, rpn);
+                EpiOps eo;
+                epi_fetch(g, eo);
+                float acc[NR], acc_hi[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
+                __builtin_amdgcn_sched_barrier(0);                                            // the operand loads stay ahead of the refills
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    slot_fma(c, w0, acc, acc_hi);
+                    __builtin_amdgcn_sched_barrier(0);                                        // keep refill c right behind consume c
+                    slot_loads(rpn, c, w0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                finish_group(g, acc, acc_hi, &eo);
+            }
+            EpiOps eo;                                                                        // last group: nothing left to request
+            epi_fetch(g, eo);
+            __builtin_amdgcn_sched_barrier(0);
+            float acc[NR], acc_hi[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < NS; ++c) slot_fma(c, w0, acc, acc_hi);
+            THK_STAMP(a.trace, bid, 2);
+            finish_group(g, acc, acc_hi, &eo);
+        }
+    } else {
     if (has_first) {
-        float acc[NR], acc_hi[NR];
+            float acc[NR], acc_hi[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
-        compute_batch(0, w0, acc, acc_hi);
-        if (NS != 0) {
+            for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
+            compute_batch(0, w0, acc, acc_hi);
+            THK_STAMP(a.trace, bid, 2);
+            if (NS != 0) {
 #pragma unroll
-            for (int c0 = U; c0 < NS; c0 += U) {
-                h8 w[NR][U];
-                load_batch(rp0, c0, w);
-                __builtin_amdgcn_sched_barrier(0);   // keep all NR*U loads ahead of the first use
-                compute_batch(c0, w, acc, acc_hi);
+                for (int c0 = U; c0 < NS; c0 += U) {
+                    h8 w[NR][U];
+                    load_batch(rp0, c0, w);
+                    __builtin_amdgcn_sched_barrier(0);   // keep all NR*U loads ahead of the first use
+                    compute_batch(c0, w, acc, acc_hi);
+                }
+            } else {
+                for (int c0 = U; c0 < ns; c0 += U) {
+                    h8 w[NR][U];
+                    load_batch(rp0, c0, w);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_batch(c0, w, acc, acc_hi);
+                }
             }
-        } else {
-            for (int c0 = U; c0 < ns; c0 += U) {
-                h8 w[NR][U];
-                load_batch(rp0, c0, w);
-                __builtin_amdgcn_sched_barrier(0);
-                compute_batch(c0, w, acc, acc_hi);
-            }
+            finish_group(g, acc, acc_hi);
+            g += total_waves;
         }
-        finish_group(g, acc, acc_hi);
-        g += total_waves;
-    }
-    for (; g < a.n_groups; g += total_waves) {
-        const h8* rp[NR];
-        row_ptrs(g, rp);
-        float acc[NR], acc_hi[NR];
+        for (; g < a.n_groups; g += total_waves) {
+            const h8* rp[NR];
+            row_ptrs(g, rp);
+            float acc[NR], acc_hi[NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
-        if (NS != 0) {
+            for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
+            if (NS != 0) {
 #pragma unroll
-            for (int c0 = 0; c0 < NS; c0 += U) {
-                h8 w[NR][U];
-                load_batch(rp, c0, w);
-                __builtin_amdgcn_sched_barrier(0);
-                compute_batch(c0, w, acc, acc_hi);
+                for (int c0 = 0; c0 < NS; c0 += U) {
+                    h8 w[NR][U];
+                    load_batch(rp, c0, w);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_batch(c0, w, acc, acc_hi);
+                }
+            } else {
+                for (int c0 = 0; c0 < ns; c0 += U) {
+                    h8 w[NR][U];
+                    load_batch(rp, c0, w);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_batch(c0, w, acc, acc_hi);
+                }
             }
-        } else {
-            for (int c0 = 0; c0 < ns; c0 += U) {
-                h8 w[NR][U];
-                load_batch(rp, c0, w);
-                __builtin_amdgcn_sched_barrier(0);
-                compute_batch(c0, w, acc, acc_hi);
-            }
+            finish_group(g, acc, acc_hi);
         }
-        finish_group(g, acc, acc_hi);
     }
+    THK_STAMP(a.trace, bid, 3);
     if (EPI == EPI_HEAD) {
-        unsigned long long* wb = reinterpret_cast<unsigned long long*>(red + 4);   // 16-byte aligned
+        unsigned long long* wb = reinterpret_cast<unsigned long long*>(red + 12);   // 16-byte aligned
         __syncthreads();
         if (lane == 0) wb[wave] = best;
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned long long b = wb[0];
-            for (int w = 1; w < kWaves; ++w) b = wb[w] > b ? wb[w] : b;
+            for (int w = 1; w < WPB; ++w) b = wb[w] > b ? wb[w] : b;
             a.block_best[bid] = b;
         }
     }
 }
 
-template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP>
-__global__ __launch_bounds__(kBlock) void gemv_kernel(const GemvArgs a) {
-    gemv_body<NR, U, NS, PRO, EPI, NT, NSP, false>(a, blockIdx.x, gridDim.x);
+template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool PIPE, int WPB>
+__global__ __launch_bounds__(WPB * 64) void gemv_kernel(const GemvArgs a) {
+    gemv_body<NR, U, NS, PRO, EPI, NT, NSP, PIPE, WPB>(a, blockIdx.x, gridDim.x);
 }
 
-template <int NR, int U, int NS, int PRO, int EPI, int NSP>
+template <int NR, int U, int NS, int PRO, int EPI, int NSP, bool PIPE, int WPB>
 static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_t st) {
     const int ns = NS ? NS : (((a.C >> 3) + 63) >> 6);
     const size_t smem = (size_t)ns * 512 * 4 + 128;
     (void)nt;   // weights always stream with non-temporal loads (default-policy loads measured 8 % slower)
-    auto kn = gemv_kernel<NR, U, NS, PRO, EPI, true, NSP>;
+    auto kn = gemv_kernel<NR, U, NS, PRO, EPI, true, NSP, PIPE, WPB>;
     static size_t attr_set[kMaxDevices] = {};   // per instantiation AND per device; first call happens outside graph capture
     if (smem > 48 * 1024) {
         int dev = 0;
@@ -563,21 +631,31 @@ static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_
             attr_set[dev] = smem;
         }
     }
-    hipLaunchKernelGGL(kn, dim3(grid), dim3(kBlock), smem, st, a);
+    static const bool dbg = getenv("THK_DEBUG_OCC") != nullptr;      // development: what the runtime says about residency
+    if (dbg) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kn), WPB * 64, smem);
+        fprintf(stderr, "[thk] gemv<NR=%d,U=%d,NS=%d,PRO=%d,EPI=%d,PIPE=%d,WPB=%d> grid=%d smem=%zu: %d blocks/CU (occupancy API)\n", NR, U, NS, PRO, EPI, (int)PIPE, WPB, grid, smem, nb);
+    }
+    hipLaunchKernelGGL(kn, dim3(grid), dim3(WPB * 64), smem, st, a);
     return hipGetLastError();
 }
-template <int NR, int U, int NS, int PRO, int EPI>
-static hipError_t launch_gemv_t(const GemvArgs& a, int grid, bool nt, hipStream_t st) {
+template <int NR, int U, int NS, int PRO, int EPI, bool PIPE, int WPB>
+static hipError_t launch_gemv_w(const GemvArgs& a, int grid, bool nt, hipStream_t st) {
     if constexpr (PRO == PRO_ATTN) {
         switch (a.nsplit) {
-            case 2: return launch_gemv_k<NR, U, NS, PRO, EPI, 2>(a, grid, nt, st);
-            case 4: return launch_gemv_k<NR, U, NS, PRO, EPI, 4>(a, grid, nt, st);
-            case 8: return launch_gemv_k<NR, U, NS, PRO, EPI, 8>(a, grid, nt, st);
+            case 2: return launch_gemv_k<NR, U, NS, PRO, EPI, 2, PIPE, WPB>(a, grid, nt, st);
+            case 4: return launch_gemv_k<NR, U, NS, PRO, EPI, 4, PIPE, WPB>(a, grid, nt, st);
+            case 8: return launch_gemv_k<NR, U, NS, PRO, EPI, 8, PIPE, WPB>(a, grid, nt, st);
             default: return hipErrorInvalidValue;   // nsplit == 1 uses PRO_COPY on the finished output
         }
     } else {
-        return launch_gemv_k<NR, U, NS, PRO, EPI, 0>(a, grid, nt, st);
+        return launch_gemv_k<NR, U, NS, PRO, EPI, 0, PIPE, WPB>(a, grid, nt, st);
     }
+}
+template <int NR, int U, int NS, int PRO, int EPI, bool PIPE>
+static hipError_t launch_gemv_t(const GemvArgs& a, int grid, bool nt, hipStream_t st) {
+    return launch_gemv_w<NR, U, NS, PRO, EPI, PIPE, kWaves>(a, grid, nt, st);
 }
 
 // Slot-count class of a column count: compile-time NS for the LLaMA-7B/13B shapes,
@@ -585,56 +663,66 @@ static hipError_t launch_gemv_t(const GemvArgs& a, int grid, bool nt, hipStream_
 static int ns_class(int C) {
     switch (C) { case 4096: return 8; case 5120: return 10; case 11008: return 22; case 13824: return 27; default: return 0; }
 }
-// (NR rows per wave iteration, U slots per load batch) variants per class, selectable at run
+// (NR rows per wave iteration, U slots per load batch, pipelined loop) variants per class, selectable at run
 // time (tunable "gemv_variant_*") so launch geometry can be swept on the GPU without rebuilding.
-void gemv_variant(int C, int epi, int nru, int* NR, int* U) {
+//   0-3  batch loop: NR*U loads, then their FMAs, per batch
+//   4    batch loop with four whole rows per wave in ONE batch (4096/5120 columns)
+//   5-7  software-pipelined loop (gemv_body PIPE): one whole row group in flight, slot c of the next group requested as soon as
+//        slot c of the current one is consumed.  5 = row pair (one row for 11008/13824 columns), 6 = one row, 7 = four rows
+void gemv_variant(int C, int epi, int nru, int* NR, int* U, int* pipe) {
     const bool pair = (epi == EPI_ROPE_KV || epi == EPI_SWIGLU);
-    static const int t8[4][2] = {{2, 8}, {1, 8}, {2, 4}, {4, 4}};
-    static const int t10[4][2] = {{2, 10}, {1, 10}, {2, 5}, {4, 5}};
-    static const int t22[4][2] = {{2, 11}, {1, 11}, {1, 22}, {2, 11}};
-    static const int t27[4][2] = {{2, 9}, {1, 9}, {1, 27}, {2, 9}};
-    const int (*t)[2] = t8;
-    switch (ns_class(C)) { case 10: t = t10; break; case 22: t = t22; break; case 27: t = t27; break; default: break; }
-    if (nru < 0 || nru > 3) nru = 0;
+    static const int t8[8][3] = {{2, 8, 0}, {1, 8, 0}, {2, 4, 0}, {4, 4, 0}, {4, 8, 0}, {2, 8, 1}, {1, 8, 1}, {4, 8, 1}};
+    static const int t10[8][3] = {{2, 10, 0}, {1, 10, 0}, {2, 5, 0}, {4, 5, 0}, {4, 10, 0}, {2, 10, 1}, {1, 10, 1}, {4, 10, 1}};
+    static const int t22[8][3] = {{2, 11, 0}, {1, 11, 0}, {1, 22, 0}, {2, 11, 0}, {2, 11, 0}, {1, 22, 1}, {1, 22, 1}, {1, 22, 1}};
+    static const int t27[8][3] = {{2, 9, 0}, {1, 9, 0}, {1, 27, 0}, {2, 9, 0}, {2, 9, 0}, {1, 27, 1}, {1, 27, 1}, {1, 27, 1}};
+    const int (*t)[3] = t8;
+    const int cls = ns_class(C);
+    switch (cls) { case 10: t = t10; break; case 22: t = t22; break; case 27: t = t27; break; default: break; }
+    if (nru < 0 || nru > 7) nru = 0;
+    if (cls == 0 && nru > 4) nru = 0;                  // the pipelined loop needs a compile-time slot count
+    if (cls == 0 && nru == 4) nru = 3;
+    if (pair && t[nru][0] != 2) nru = t[nru][2] ? 5 : 0;
     *NR = t[nru][0]; *U = t[nru][1];
-    if (pair && *NR != 2) { *NR = t[0][0]; *U = t[0][1]; }
+    if (pipe) *pipe = t[nru][2];
 }
 
 template <int PRO, int EPI, int NS>
-static hipError_t launch_gemv_ns(int NR, int U, const GemvArgs& a, int grid, bool nt, hipStream_t st) {
+static hipError_t launch_gemv_ns(int NR, int U, int pipe, const GemvArgs& a, int grid, bool nt, hipStream_t st) {
     constexpr bool pair = (EPI == EPI_ROPE_KV || EPI == EPI_SWIGLU);
-#define THK_TRY(nr, u)                                                                      \
-    if constexpr ((NS == 0 || NS % (u) == 0) && (!pair || (nr) == 2)) {                       \
-        if (NR == (nr) && U == (u)) return launch_gemv_t<nr, u, NS, PRO, EPI>(a, grid, nt, st); \
+#define THK_TRY(nr, u, pp)                                                                                  \
+    if constexpr ((NS == 0 || NS % (u) == 0) && (!pair || (nr) == 2) && (!(pp) || (NS != 0 && (u) == NS))) {   \
+        if (NR == (nr) && U == (u) && pipe == (pp)) return launch_gemv_t<nr, u, NS, PRO, EPI, (pp) != 0>(a, grid, nt, st); \
     }
-    if constexpr (NS == 8 || NS == 0) { THK_TRY(2, 8) THK_TRY(1, 8) THK_TRY(2, 4) THK_TRY(4, 4) }
-    if constexpr (NS == 10) { THK_TRY(2, 10) THK_TRY(1, 10) THK_TRY(2, 5) THK_TRY(4, 5) }
-    if constexpr (NS == 22) { THK_TRY(2, 11) THK_TRY(1, 11) THK_TRY(1, 22) }
-    if constexpr (NS == 27) { THK_TRY(2, 9) THK_TRY(1, 9) THK_TRY(1, 27) }
+    if constexpr (NS == 8 || NS == 0) { THK_TRY(2, 8, 0) THK_TRY(1, 8, 0) THK_TRY(2, 4, 0) THK_TRY(4, 4, 0) }
+    if constexpr (NS == 8) { THK_TRY(4, 8, 0) THK_TRY(2, 8, 1) THK_TRY(1, 8, 1) THK_TRY(4, 8, 1) }
+    if constexpr (NS == 10) { THK_TRY(2, 10, 0) THK_TRY(1, 10, 0) THK_TRY(2, 5, 0) THK_TRY(4, 5, 0) THK_TRY(4, 10, 0) THK_TRY(2, 10, 1) THK_TRY(1, 10, 1) THK_TRY(4, 10, 1) }
+    if constexpr (NS == 22) { THK_TRY(2, 11, 0) THK_TRY(1, 11, 0) THK_TRY(1, 22, 0) THK_TRY(1, 22, 1) }
+    if constexpr (NS == 27) { THK_TRY(2, 9, 0) THK_TRY(1, 9, 0) THK_TRY(1, 27, 0) THK_TRY(1, 27, 1) }
 #undef THK_TRY
     return hipErrorInvalidValue;
 }
 
 template <int PRO, int EPI>
 static hipError_t launch_gemv_pe(int nru, const GemvArgs& a, int grid, bool nt, hipStream_t st) {
-    int NR, U; gemv_variant(a.C, EPI, nru, &NR, &U);
+    int NR, U, pipe; gemv_variant(a.C, EPI, nru, &NR, &U, &pipe);
     switch (ns_class(a.C)) {
-        case 8: return launch_gemv_ns<PRO, EPI, 8>(NR, U, a, grid, nt, st);
-        case 10: return launch_gemv_ns<PRO, EPI, 10>(NR, U, a, grid, nt, st);
-        case 22: return launch_gemv_ns<PRO, EPI, 22>(NR, U, a, grid, nt, st);
-        case 27: return launch_gemv_ns<PRO, EPI, 27>(NR, U, a, grid, nt, st);
-        default: return launch_gemv_ns<PRO, EPI, 0>(NR, U, a, grid, nt, st);
+        case 8: return launch_gemv_ns<PRO, EPI, 8>(NR, U, pipe, a, grid, nt, st);
+        case 10: return launch_gemv_ns<PRO, EPI, 10>(NR, U, pipe, a, grid, nt, st);
+        case 22: return launch_gemv_ns<PRO, EPI, 22>(NR, U, pipe, a, grid, nt, st);
+        case 27: return launch_gemv_ns<PRO, EPI, 27>(NR, U, pipe, a, grid, nt, st);
+        default: return launch_gemv_ns<PRO, EPI, 0>(NR, U, pipe, a, grid, nt, st);
     }
 }
 
 int gemv_rows_per_group(int C, int epi, int nru) {
-    int NR, U; gemv_variant(C, epi, nru, &NR, &U);
+    int NR, U; gemv_variant(C, epi, nru, &NR, &U, nullptr);
     return NR;
 }
 
 hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, bool nt, hipStream_t st) {
     if (a.C < 256 || a.C % 256 != 0) return hipErrorInvalidValue;
     if (epi == EPI_ROPE_KV && pro == PRO_RMS) return launch_gemv_pe<PRO_RMS, EPI_ROPE_KV>(nru, a, grid, nt, st);
+    if (epi == EPI_ROPE_KV && pro == PRO_RMS_EMBED) return (a.embed && a.tok_ptr && a.x_out) ? launch_gemv_pe<PRO_RMS_EMBED, EPI_ROPE_KV>(nru, a, grid, nt, st) : hipErrorInvalidValue;
     if (epi == EPI_SWIGLU && pro == PRO_RMS) return launch_gemv_pe<PRO_RMS, EPI_SWIGLU>(nru, a, grid, nt, st);
     if (epi == EPI_HEAD && pro == PRO_RMS) return launch_gemv_pe<PRO_RMS, EPI_HEAD>(nru, a, grid, nt, st);
     if (epi == EPI_HEAD && pro == PRO_COPY) return launch_gemv_pe<PRO_COPY, EPI_HEAD>(nru, a, grid, nt, st);
@@ -654,7 +742,6 @@ hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, b
 // softmax K10 th.cpp:1901-1957.
 // WAVES waves per block share one (head, split): more waves = fewer positions per wave, so every
 // wave needs a single load batch (one HBM round trip) at T = 512 with 4 splits.
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 // one position's 4-element slice for this lane: f32 cache (16 bytes) or f16 cache (8 bytes, widened by v_cvt_f32_f16)
 template <bool KVH>
 __device__ __forceinline__ f4 ld_kv4(const float* base, size_t elem_off) {
@@ -664,7 +751,7 @@ __device__ __forceinline__ f4 ld_kv4(const float* base, size_t elem_off) {
     }
     return __builtin_nontemporal_load(reinterpret_cast<const f4*>(base + elem_off));
 }
-template <int D, int WAVES, bool PUBLISH, bool KVH = false>
+template <int D, int WAVES, bool KVH>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     constexpr int LPP = D / 4;          // lanes per position
     constexpr int PPW = 64 / LPP;       // positions per wave-instruction
@@ -679,6 +766,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     const int h = hb / a.nsplit, s = hb - h * a.nsplit;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPP, li = lane - grp * LPP;
+    THK_STAMP(a.trace, bid, 0);
     const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + qi + 1;
     const int E = a.H * D;
     const int t0 = s * a.tc, t1 = min(t0 + a.tc, T);
@@ -688,8 +776,10 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
 
     float m = -INFINITY, l = 0.f;
     f4 o = {0.f, 0.f, 0.f, 0.f};
-    // wave w takes positions t0 + (it*kWaves + w)*PPW*UB + u*PPW + grp.  Loads are branch-free:
+    // wave w takes positions t0 + (it*WAVES + w)*PPW*UB + u*PPW + grp.  Loads are branch-free:
     // positions past the end are clamped to a valid row and masked out of the softmax.
+    // (Round 3 tried fetching the first batch BEFORE the device-resident position is known - every row below n_ctx is
+    // allocated - to take the position's round trip off the critical path: 0.6 us per launch SLOWER on MI355X, removed.)
     for (int tb = t0 + wave * (PPW * UB); tb < t1; tb += WAVES * PPW * UB) {
         f4 kv[UB], vv[UB];
 #pragma unroll
@@ -723,6 +813,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
             l += p; o += vv[u] * p;
         }
         m = mn;
+        THK_STAMP(a.trace, bid, 1);
     }
     // merge the PPW lane groups of the wave (same m): sum l and o across groups
     if (PPW >= 2) { l += __shfl_xor(l, LPP); o.x += __shfl_xor(o.x, LPP); o.y += __shfl_xor(o.y, LPP); o.z += __shfl_xor(o.z, LPP); o.w += __shfl_xor(o.w, LPP); }
@@ -730,6 +821,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     if (lane < LPP) *reinterpret_cast<f4*>(&sm_o[wave][lane * 4]) = o;
     if (lane == 0) { sm_ml[wave][0] = m; sm_ml[wave][1] = l; }
     __syncthreads();
+    THK_STAMP(a.trace, bid, 2);
     if (threadIdx.x < D) {
         const int d = threadIdx.x;
         float M = -INFINITY;
@@ -740,83 +832,19 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
             const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
             L += sm_ml[w][1] * f; od += sm_o[w][d] * f;
         }
-        if (a.out && !a.head_ticket) {   // nsplit == 1: finished output, [H*D]
+        if (a.out) {   // nsplit == 1: finished output, [H*D]
             a.out[(size_t)qi * E + h * D + d] = od / L;
-        } else if (PUBLISH || a.head_ticket) {   // consumed by other blocks of this launch: write-through stores
-            __hip_atomic_store(a.part_o + (size_t)(h * a.nsplit + s) * D + d, od, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == 0) {
-                __hip_atomic_store(a.part_ml + (h * a.nsplit + s) * 2, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(a.part_ml + (h * a.nsplit + s) * 2 + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
+        } else {       // split partial: combined by the consumer's prologue (ProAttn) or by attn_combine_kernel
             a.part_o[(size_t)(h * a.nsplit + s) * D + d] = od;
             if (d == 0) { a.part_ml[(h * a.nsplit + s) * 2] = M; a.part_ml[(h * a.nsplit + s) * 2 + 1] = L; }
         }
     }
-}
-
-// Split combine inside the attention launch: every (head, split) block publishes its partial with
-// write-through stores and takes a ticket on a per-head counter; the LAST arriver of a head merges
-// the nsplit partials and writes the finished [D] slice, so the wo mat-vec that follows needs no
-// combine prologue.  Counters reset themselves (next use is in a later launch).  No block ever
-// waits, so this cannot dead-lock; summation order is by split index => deterministic.
-template <int D>
-__device__ __forceinline__ void attn_last_arriver_combine(const AttnArgs& a, const int bid) {
-    __shared__ unsigned sm_last;
-    const int per_q = a.H * a.nsplit;
-    const int hb = bid % per_q, h = hb / a.nsplit;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its sc1 stores
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(a.head_ticket + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sm_last = (t == (unsigned)a.nsplit - 1u) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!sm_last) return;
-    if (threadIdx.x < D) {
-        const int d = threadIdx.x;
-        float M = -INFINITY;
-        float ms[kMaxSplit], ls[kMaxSplit], os[kMaxSplit];
-#pragma unroll
-        for (int s = 0; s < kMaxSplit; ++s) {
-            ms[s] = -INFINITY; ls[s] = 0.f; os[s] = 0.f;
-            if (s < a.nsplit) {
-                const float2 ml = load_f2_sc1(a.part_ml + (h * a.nsplit + s) * 2);
-                ms[s] = ml.x; ls[s] = ml.y;
-                os[s] = __hip_atomic_load(a.part_o + (size_t)(h * a.nsplit + s) * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            M = fmaxf(M, ms[s]);
-        }
-        float L = 0.f, o = 0.f;
-#pragma unroll
-        for (int s = 0; s < kMaxSplit; ++s) {
-            const float f = (ms[s] == -INFINITY) ? 0.f : expf(ms[s] - M);
-            L += ls[s] * f; o += os[s] * f;
-        }
-        a.out[h * D + d] = o / L;
-    }
-    if (threadIdx.x == 0) __hip_atomic_store(a.head_ticket + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    THK_STAMP(a.trace, bid, 3);
 }
 
 template <int D, int WAVES, bool KVH>
 __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(const AttnArgs a) {
-    attn_body<D, WAVES, false, KVH>(a, blockIdx.x);
-    if (a.head_ticket) attn_last_arriver_combine<D>(a, blockIdx.x);
-}
-
-// Fused launch: blocks [0, H*nsplit) run the attention splits and publish their partials; the
-// remaining blocks are the wo mat-vec (split combine prologue, + residual epilogue) whose first
-// weight batch is already in flight while the attention runs.  Producers have the LOWER block
-// ids and never wait, so the launch cannot dead-lock even when the grid is not fully resident.
-template <int D, int NR, int U, int NS, int NSP, bool NT>
-__global__ __launch_bounds__(kBlock) void attn_wo_kernel(const AttnArgs t, const GemvArgs g) {
-    const int na = t.H * t.nsplit;
-    if ((int)blockIdx.x < na) {
-        attn_body<D, kWaves, true>(t, blockIdx.x);
-        fuse_signal(g.fs);
-    } else {
-        gemv_body<NR, U, NS, GEMV_PRO_ATTN, GEMV_EPI_RESID, NT, NSP, true>(g, blockIdx.x - na, gridDim.x - na);
-    }
+    attn_body<D, WAVES, KVH>(a, blockIdx.x);
 }
 
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
@@ -836,62 +864,6 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     }
 #undef THK_ATTN
     return hipGetLastError();
-}
-
-template <int D, int NR, int U, int NS, int NSP>
-static hipError_t launch_attn_wo_k(const AttnArgs& t, const GemvArgs& g, int grid_wo, bool nt, hipStream_t st) {
-    const int ns = NS ? NS : (((g.C >> 3) + 63) >> 6);
-    const size_t smem = (size_t)ns * 512 * 4 + 128;
-    (void)nt;
-    auto kn = attn_wo_kernel<D, NR, U, NS, NSP, true>;
-    static size_t attr_set[kMaxDevices] = {};
-    if (smem > 48 * 1024) {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
-        if (smem > attr_set[dev]) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            if (e != hipSuccess) return e;
-            attr_set[dev] = smem;
-        }
-    }
-    hipLaunchKernelGGL(kn, dim3(t.H * t.nsplit + grid_wo), dim3(kBlock), smem, st, t, g);
-    return hipGetLastError();
-}
-template <int D, int NS, int NSP>
-static hipError_t launch_attn_wo_v(int NR, int U, const AttnArgs& t, const GemvArgs& g, int grid_wo, bool nt, hipStream_t st) {
-    // experiment path: only the default (rows, slots) variant of each column class is instantiated
-    if constexpr (NS == 8 || NS == 0) { if (NR == 2 && U == 8) return launch_attn_wo_k<D, 2, 8, NS, NSP>(t, g, grid_wo, nt, st); }
-    if constexpr (NS == 10) { if (NR == 2 && U == 10) return launch_attn_wo_k<D, 2, 10, NS, NSP>(t, g, grid_wo, nt, st); }
-    return hipErrorInvalidValue;
-}
-template <int D, int NS>
-static hipError_t launch_attn_wo_s(int NR, int U, const AttnArgs& t, const GemvArgs& g, int grid_wo, bool nt, hipStream_t st) {
-    switch (t.nsplit) {
-        case 2: return launch_attn_wo_v<D, NS, 2>(NR, U, t, g, grid_wo, nt, st);
-        case 4: return launch_attn_wo_v<D, NS, 4>(NR, U, t, g, grid_wo, nt, st);
-        case 8: return launch_attn_wo_v<D, NS, 8>(NR, U, t, g, grid_wo, nt, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-template <int D>
-static hipError_t launch_attn_wo_d(int NR, int U, const AttnArgs& t, const GemvArgs& g, int grid_wo, bool nt, hipStream_t st) {
-    switch (ns_class(g.C)) {
-        case 8: return launch_attn_wo_s<D, 8>(NR, U, t, g, grid_wo, nt, st);
-        case 10: return launch_attn_wo_s<D, 10>(NR, U, t, g, grid_wo, nt, st);
-        case 0: return launch_attn_wo_s<D, 0>(NR, U, t, g, grid_wo, nt, st);
-        default: return hipErrorInvalidValue;
-    }
-}
-hipError_t launch_attn_wo(const AttnArgs& t, const GemvArgs& g, int nru, int grid_wo, bool nt, hipStream_t st) {
-    if (g.C != t.H * t.D || g.C < 256 || g.C % 256 != 0 || t.out != nullptr || t.kv_f16) return hipErrorInvalidValue;
-    int NR, U; gemv_variant(g.C, GEMV_EPI_RESID, nru, &NR, &U);
-    switch (t.D) {
-        case 64: return launch_attn_wo_d<64>(NR, U, t, g, grid_wo, nt, st);
-        case 128: return launch_attn_wo_d<128>(NR, U, t, g, grid_wo, nt, st);
-        default: return hipErrorInvalidValue;
-    }
 }
 
 // Stand-alone combine of split partials -> out[H*D] (used by thk_attn_decode when nsplit > 1).
@@ -1012,10 +984,12 @@ hipError_t launch_kv_append(float* kc, float* vc, const float* k, const float* v
 // ---------------------------------------------------------------- token plumbing
 // Embedding fetch: x = f32(table[token,:]) (loader :185-195, th-llama.cpp:577-584).
 __global__ __launch_bounds__(kBlock) void embed_kernel(const uint16_t* __restrict__ table, const SeqState* st, int token_val,
-                                                       int E, float* x) {
+                                                       int E, float* x, unsigned long long* trace) {
+    THK_STAMP(trace, 0, 0);
     const int token = st ? st->token : token_val;
     const _Float16* row = reinterpret_cast<const _Float16*>(table) + (size_t)token * E;
     for (int i = threadIdx.x; i < E; i += kBlock) x[i] = (float)row[i];
+    THK_STAMP(trace, 0, 3);
 }
 __global__ __launch_bounds__(kBlock) void embed_rows_kernel(const uint16_t* __restrict__ table, const int32_t* __restrict__ tokens, int E, float* x) {
     const _Float16* row = reinterpret_cast<const _Float16*>(table) + (size_t)tokens[blockIdx.x] * E;
@@ -1025,8 +999,8 @@ hipError_t launch_embed_rows(const uint16_t* table, const int32_t* tokens_dev, i
     hipLaunchKernelGGL(embed_rows_kernel, dim3(n), dim3(kBlock), 0, st, table, tokens_dev, E, x);
     return hipGetLastError();
 }
-hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token_val, int E, float* x, hipStream_t st) {
-    hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(kBlock), 0, st, table, st_dev, token_val, E, x);
+hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token_val, int E, float* x, hipStream_t st, unsigned long long* trace) {
+    hipLaunchKernelGGL(embed_kernel, dim3(1), dim3(kBlock), 0, st, table, st_dev, token_val, E, x, trace);
     return hipGetLastError();
 }
 
@@ -1038,8 +1012,10 @@ hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token
 // epoch != NULL: the engine's tag epoch is bumped here, i.e. after the engine launch of this step and before the next.
 __global__ __launch_bounds__(kBlock) void finish_token_kernel(const unsigned long long* __restrict__ block_best, int nblocks,
                                                               SeqState* st, int32_t* gen_log, int log_cap,
-                                                              const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch) {
+                                                              const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch,
+                                                              unsigned long long* trace) {
     __shared__ unsigned long long sm[kBlock];
+    THK_STAMP(trace, 0, 0);
     unsigned long long b = 0ull;
     for (int i = threadIdx.x; i < nblocks; i += kBlock) { const unsigned long long k = block_best[i]; b = k > b ? k : b; }
     sm[threadIdx.x] = b;
@@ -1059,10 +1035,11 @@ __global__ __launch_bounds__(kBlock) void finish_token_kernel(const unsigned lon
         }
         if (epoch) *epoch += 1u;
     }
+    THK_STAMP(trace, 0, 3);
 }
 hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
-                               const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st) {
-    hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(kBlock), 0, st, block_best, nblocks, st_dev, gen_log, log_cap, advance_ptr, id_out, n_ctx, epoch);
+                               const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st, unsigned long long* trace) {
+    hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(kBlock), 0, st, block_best, nblocks, st_dev, gen_log, log_cap, advance_ptr, id_out, n_ctx, epoch, trace);
     return hipGetLastError();
 }
 // Non-head stages only advance the position (same clamp, same epoch bump).
@@ -1095,6 +1072,14 @@ __global__ __launch_bounds__(kBlock) void argmax_kernel(const float* __restrict_
 hipError_t launch_argmax(const float* logits, int V, unsigned long long* block_best, int nblocks, hipStream_t st) {
     hipLaunchKernelGGL(argmax_kernel, dim3(nblocks), dim3(kBlock), 0, st, logits, V, block_best);
     return hipGetLastError();
+}
+
+bool trace_compiled() {
+#ifdef THK_TRACE
+    return true;
+#else
+    return false;
+#endif
 }
 
 // ---------------------------------------------------------------- synthetic tensors

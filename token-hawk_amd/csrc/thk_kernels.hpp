@@ -20,19 +20,8 @@ struct SeqState {
 };
 
 // prologue / epilogue selectors of the fused mat-vec
-enum { GEMV_PRO_COPY = 0, GEMV_PRO_RMS = 1, GEMV_PRO_ATTN = 2 };
+enum { GEMV_PRO_COPY = 0, GEMV_PRO_RMS = 1, GEMV_PRO_ATTN = 2, GEMV_PRO_RMS_EMBED = 3 };
 enum { GEMV_EPI_STORE = 0, GEMV_EPI_RESID = 1, GEMV_EPI_ROPE_KV = 2, GEMV_EPI_SWIGLU = 3, GEMV_EPI_HEAD = 4 };
-
-// In-launch producer/consumer synchronisation of a fused launch (see fuse_wait / fuse_signal).
-constexpr int kFuseFlags = 16;   // replicated "producers done" flags, 128 bytes apart
-struct FuseSync {
-    unsigned* counter;        // arrival counter, zeroed at the start of every step; producers add 1 each
-    unsigned* flags;          // kFuseFlags words at a 32-word stride, zeroed with the counter; set by the last producer
-    unsigned target;          // number of producer blocks
-    unsigned spin_limit;      // bounded polling: give up (and raise *error) after this many polls
-    unsigned initial_sleeps;  // s_sleep(32) repetitions before the first poll
-    unsigned* error;
-};
 
 struct GemvArgs {
     const uint16_t* W[3];   // f16 row-major [R,C] matrices (see gemv_kernel for their meaning per epilogue)
@@ -41,6 +30,8 @@ struct GemvArgs {
     int n_groups;           // row groups to process
     const float* x;         // PRO_COPY / PRO_RMS input vector f32[C]
     const float* gain;      // PRO_RMS gain f32[C]
+    // PRO_RMS_EMBED: x = f32(embed[*tok_ptr, :]) (f16 table [n_vocab, C]); block 0 also stores it to x_out
+    const uint16_t* embed; const int32_t* tok_ptr; float* x_out;
     float* y;               // output (q for ROPE_KV, u for SWIGLU, logits for HEAD)
     const float* resid;     // EPI_RESID
     // EPI_ROPE_KV
@@ -50,8 +41,7 @@ struct GemvArgs {
     const float* part_o; const float* part_ml; int H; int nsplit;
     // EPI_HEAD
     int lm_faithful; int q1_split; int q1_cov; unsigned long long* block_best;
-    // fused launches only
-    FuseSync fs;
+    unsigned long long* trace;   // development timeline, [blocks][8 waves][4] (only read by a THK_TRACE build; NULL otherwise)
 };
 
 struct AttnArgs {
@@ -64,20 +54,18 @@ struct AttnArgs {
     int nq;                    // causal queries in this launch (prefill); 0/1 = single decode query
     int kv_f16;                // the caches hold binary16 (kcache / vcache then point to _Float16 data)
     float scale;               // 1/sqrtf(D)
-    float* out;                // finished output [H*D]: nsplit == 1, or the last-arriver combine (head_ticket != NULL)
-    unsigned* head_ticket;     // [H] arrival counters for the in-launch split combine (NULL = partials only)
+    float* out;                // finished output [H*D] (nsplit == 1); NULL = write split partials
     float* part_o;             // [H, nsplit, D]
     float* part_ml;            // [H, nsplit, 2]
+    unsigned long long* trace; // development timeline, [blocks][8 waves][4] (only read by a THK_TRACE build; NULL otherwise)
 };
 
-// nru (0..3) selects the (rows per wave iteration, slots per load batch) variant for the column class of C;
+// nru (0..7) selects the (rows per wave iteration, slots per load batch) variant for the column class of C;
 // see gemv_variant() in thk_kernels.hip.  Row groups = ceil(rows / gemv_rows_per_group).
 int gemv_rows_per_group(int C, int epi, int nru);
-void gemv_variant(int C, int epi, int nru, int* NR, int* U);
+void gemv_variant(int C, int epi, int nru, int* NR, int* U, int* pipe);
 hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, bool nt, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
-// attention splits + (combine -> wo -> +residual) in ONE launch; grid_wo = number of mat-vec blocks
-hipError_t launch_attn_wo(const AttnArgs& t, const GemvArgs& g, int nru, int grid_wo, bool nt, hipStream_t st);
 hipError_t launch_attn_combine(const float* part_o, const float* part_ml, float* out, int H, int D, int nsplit, hipStream_t st);
 hipError_t launch_rms_norm(float* x, int rows, int N, hipStream_t st);
 hipError_t launch_row_mul(float* x, const float* g, int rows, int N, hipStream_t st);
@@ -88,9 +76,12 @@ hipError_t launch_silu(float* a, size_t n, hipStream_t st);
 hipError_t launch_mul(float* a, const float* b, size_t n, hipStream_t st);
 hipError_t launch_kv_append(float* kc, float* vc, const float* k, const float* v, int pos, int E, hipStream_t st);
 hipError_t launch_embed_rows(const uint16_t* table, const int32_t* tokens_dev, int n, int E, float* x, hipStream_t st);
-hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token_val, int E, float* x, hipStream_t st);
+hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token_val, int E, float* x, hipStream_t st, unsigned long long* trace = nullptr);
 hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
-                               const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st);
+                               const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st, unsigned long long* trace = nullptr);
+constexpr int kTraceBlocks = 2048;   // workgroups recorded per launch of the development timeline
+constexpr int kTraceWords = 8 * 4;    // u64 per workgroup: [wave (8)][stamp (4)]
+bool trace_compiled();               // true in a -DTHK_TRACE build (libthk_trace.so)
 hipError_t launch_advance_pos(SeqState* st_dev, const int* advance_ptr, int n_ctx, unsigned* epoch, hipStream_t st);
 hipError_t launch_argmax(const float* logits, int V, unsigned long long* block_best, int nblocks, hipStream_t st);
 hipError_t launch_synth_f16(uint64_t key, float scale, size_t n, void* out, hipStream_t st);

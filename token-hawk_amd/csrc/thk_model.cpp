@@ -87,7 +87,6 @@ static void free_working(thk_model* m) {
     for (void* c : m->arena_chunks) hipFree(c);     // x, q, u, attn_out, part_*, block_best, rope_tab, counters, engine words, per-sequence state
     m->arena_chunks.clear(); m->arena_off = m->arena_cap = 0;
     hipFree(m->prefill_ws); hipFree(m->prefill_pk); m->prefill_pk = nullptr; m->prefill_pk_bytes = 0; m->pk_w.clear(); m->pk_tiles[0] = 0; m->pk_failed = false;
-    m->fuse_counters = nullptr; m->head_ticket = nullptr;
     m->eng_trace = nullptr;
     m->eng_gran = nullptr; m->eng_words = nullptr; m->engine = 0;
     m->x = m->q = m->u = m->attn_out = m->part_o = m->part_ml = nullptr; m->block_best = nullptr; m->rope_tab = nullptr;
@@ -99,6 +98,7 @@ extern "C" int thk_model_destroy(thk_model* m) {
     hipSetDevice(m->ctx->device);
     hipStreamSynchronize(m->ctx->stream);
     free_working(m);
+    hipFree(m->trace_buf);
     hipFree(m->weights_slab);     // every weight pointer of the stage points into it
     delete m;
     return THK_OK;
@@ -225,9 +225,11 @@ static inline float* vcache_of(const thk_model* m, const SeqBuf& sb, int i) {
 struct StepProf {
     std::vector<std::string> names;
     std::vector<hipEvent_t> events;   // events[i] recorded before kernel i; one extra at the end
+    bool names_only = false;          // collect the launch names without recording events (the step trace must not perturb the stream)
 };
 static int prof_mark(thk_ctx* ctx, StepProf* p, const char* name) {
     if (!p) return THK_OK;
+    if (p->names_only) { if (name) p->names.push_back(name); return THK_OK; }
     hipEvent_t ev;
     HIPCHK(ctx, hipEventCreate(&ev));
     HIPCHK(ctx, hipEventRecord(ev, ctx->stream));
@@ -245,13 +247,14 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
     const bool nt = m->nt != 0;
     const int nl = m->l1 - m->l0;
     const float* xin = sb.hidden_in;
-    if (m->fuse_attn_wo) {
-        MARK("zero_counters");
-        HIPCHK(ctx, hipMemsetAsync(m->fuse_counters, 0, (size_t)nl * kFuseStride * 4, st));   // arrival counters + flags of this step's fused launches
-    }
+    int trace_k = 0;                                     // development timeline (thk_model_step_trace): one [kTraceBlocks][8][4] slab per launch
+    auto trace_slab = [&]() -> unsigned long long* { return m->trace_on ? m->trace_buf + (size_t)(trace_k++) * kTraceBlocks * kTraceWords : nullptr; };
+    const bool fold_embed = (m->flags & THK_STAGE_EMBED) && m->fold_embed && !m->engine && nl > 0 && m->skip_kernel != 1;
     if (m->flags & THK_STAGE_EMBED) {
-        MARK("embed");
-        HIPCHK(ctx, launch_embed(m->tok_embeddings, sb.st, 0, E, m->x, st));
+        if (!fold_embed) {      // with fold_embed the first layer's qkv prologue fetches the row itself (ProRms<.., EMB>)
+            MARK("embed");
+            HIPCHK(ctx, launch_embed(m->tok_embeddings, sb.st, 0, E, m->x, st, trace_slab()));
+        }
         xin = m->x;
     }
     if (m->engine) {   // every layer (+ lm-head) of this stage in ONE persistent launch; the program was built at finalize
@@ -282,41 +285,38 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.W[0] = L.wq; a.W[1] = L.wk; a.W[2] = L.wv; a.R = E; a.C = E; a.n_groups = 3 * E / 2;
             a.x = xr_in; a.gain = L.attention_norm; a.y = m->q;
             a.kcache = kc; a.vcache = vc; a.rope_tab = m->rope_tab; a.pos_ptr = &sb.st->pos; a.E = E; a.D = D; a.kv_f16 = m->kv_f16;
+            const bool emb = fold_embed && i == 0;
+            if (emb) { a.embed = m->tok_embeddings; a.tok_ptr = &sb.st->token; a.x_out = m->x; }
+            if (m->gain_alias && !emb) a.gain = a.x;
+            a.trace = trace_slab();
             MARK("norm_qkv_rope_kv");
-            if (m->skip_kernel != 1) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_ROPE_KV, m->var_qkv, a, m->grid_qkv, nt, st));
+            if (m->skip_kernel != 1) HIPCHK(ctx, launch_gemv(emb ? GEMV_PRO_RMS_EMBED : GEMV_PRO_RMS, GEMV_EPI_ROPE_KV, m->var_qkv, a, m->grid_qkv, nt, st));
         }
         {   // attention over the cache in place (steps 5-9, th-llama.cpp:341-397), then
             // split combine -> wo -> + residual (steps 10-11, th-llama.cpp:401-413)
             AttnArgs t{};
             t.q = m->q; t.kcache = kc; t.vcache = vc; t.pos_ptr = &sb.st->pos; t.H = H; t.D = D; t.nsplit = m->nsplit; t.tc = m->tc;
             t.scale = 1.0f / sqrtf((float)D); t.waves = m->attn_waves; t.kv_f16 = m->kv_f16;
-            const bool combined = m->attn_combine && !m->fuse_attn_wo;      // attention writes the finished vector itself
-            t.out = (m->nsplit == 1 || combined) ? m->attn_out : nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml;
-            t.head_ticket = combined ? m->head_ticket : nullptr;
+            t.out = m->nsplit == 1 ? m->attn_out : nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml;
             GemvArgs a{};
             a.W[0] = L.wo; a.R = E; a.C = E;
-            const int wo_var = m->fuse_attn_wo ? 0 : m->var_wo;             // the fused experiment only has the default variant
-            const int NR = gemv_rows_per_group(E, GEMV_EPI_RESID, wo_var);
+            const int NR = gemv_rows_per_group(E, GEMV_EPI_RESID, m->var_wo);
             a.n_groups = (E + NR - 1) / NR;
             a.x = m->attn_out; a.part_o = m->part_o; a.part_ml = m->part_ml; a.H = H; a.D = D; a.nsplit = m->nsplit;
             a.resid = xr_in; a.y = m->x;
-            if (m->fuse_attn_wo) {
-                a.fs.counter = m->fuse_counters + (size_t)i * kFuseStride; a.fs.flags = a.fs.counter + 32;
-                a.fs.target = (unsigned)(H * m->nsplit); a.fs.spin_limit = 1u << 20;
-                a.fs.initial_sleeps = (unsigned)m->fuse_initial_sleeps; a.fs.error = m->fuse_counters + (size_t)nl * kFuseStride;
-                MARK("attn_wo_fused");
-                HIPCHK(ctx, launch_attn_wo(t, a, 0 /* default variant */, m->grid_wo, nt, st));
-            } else {
-                MARK("attn_decode");
-                if (m->skip_kernel != 2) HIPCHK(ctx, launch_attn_decode(t, st));
-                MARK("attn_wo_resid");
-                if (m->skip_kernel != 3) HIPCHK(ctx, launch_gemv((m->nsplit == 1 || combined) ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, wo_var, a, m->grid_wo, nt, st));
-            }
+            t.trace = trace_slab();
+            MARK("attn_decode");
+            if (m->skip_kernel != 2) HIPCHK(ctx, launch_attn_decode(t, st));
+            a.trace = trace_slab();
+            MARK("attn_wo_resid");
+            if (m->skip_kernel != 3) HIPCHK(ctx, launch_gemv(m->nsplit == 1 ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, m->var_wo, a, m->grid_wo, nt, st));
         }
         {   // rms_norm*gain -> w1,w3 -> silu*gate   (steps 12-14, th-llama.cpp:415-438)
             GemvArgs a{};
             a.W[0] = L.w1; a.W[1] = L.w3; a.R = F; a.C = E; a.n_groups = F;
             a.x = m->x; a.gain = L.ffn_norm; a.y = m->u;
+            if (m->gain_alias) a.gain = a.x;
+            a.trace = trace_slab();
             MARK("norm_w13_swiglu");
             if (m->skip_kernel != 4) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_SWIGLU, m->var_w13, a, m->grid_w13, nt, st));
         }
@@ -327,6 +327,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.n_groups = (E + NR - 1) / NR;
             a.x = m->u; a.resid = m->x;
             a.y = (i == nl - 1 && !(m->flags & THK_STAGE_HEAD)) ? sb.hidden_out : m->x;
+            a.trace = trace_slab();
             MARK("w2_resid");
             if (m->skip_kernel != 5) HIPCHK(ctx, launch_gemv(GEMV_PRO_COPY, GEMV_EPI_RESID, m->var_w2, a, m->grid_w2, nt, st));
         }
@@ -339,10 +340,11 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         a.x = m->x; a.gain = m->norm; a.y = sb.logits;
         a.lm_faithful = m->lm_mode == THK_LMHEAD_FAITHFUL; q1_constants(V, &a.q1_split, &a.q1_cov);
         a.block_best = m->block_best;
+        a.trace = trace_slab();
         MARK("norm_lmhead");
         if (m->skip_kernel != 6) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, nt, st));
         MARK("finish_token");
-        if (m->skip_kernel != 6) HIPCHK(ctx, launch_finish_token(m->block_best, m->grid_head, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, T, nullptr, st));
+        if (m->skip_kernel != 6) HIPCHK(ctx, launch_finish_token(m->block_best, m->grid_head, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, T, nullptr, st, trace_slab()));
         else HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, T, nullptr, st));       // no arg-max keys were written: keep the token
     } else {
         MARK("advance_pos");
@@ -386,7 +388,7 @@ static bool engine_plan(thk_model* m) {
     if (D != 64 && D != 128) return false;
     if (E % 512 != 0 || F % 256 != 0 || E > 6144 || (V & 1)) return false;            // row pairs, one-sweep norm gather, whole pieces
     if ((m->flags & THK_STAGE_HEAD) && m->lm_mode != THK_LMHEAD_CORRECT) return false;  // the Q1-faithful combine stays on the launch path
-    if (m->skip_kernel || m->fuse_attn_wo || m->kv_f16 || H > ctx->n_cu) return false;   // the engine reads the reference's f32 cache
+    if (m->skip_kernel || m->kv_f16 || H > ctx->n_cu) return false;   // the engine reads the reference's f32 cache
     int S = 1;
     while (S * 2 <= kMaxSplit && S * 2 * H <= ctx->n_cu) S *= 2;
     const int v1 = ((E + 511) / 512) * 2048, v0 = ((std::max(E, F) + 511) / 512) * 2048;
@@ -468,12 +470,11 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->tc = (int)((T + m->nsplit - 1) / m->nsplit);
     m->nt = true;
     m->use_graph = tun(ctx, "use_graph") != 0;
-    m->fuse_initial_sleeps = (int)tun(ctx, "fuse_initial_sleeps");
     m->skip_kernel = (int)tun(ctx, "measure_skip_kernel");
     m->attn_waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
-    m->attn_combine = tun(ctx, "attn_combine") != 0 && m->nsplit > 1;
     m->kv_f16 = tun(ctx, "kv_f16") != 0;
-    m->fuse_attn_wo = tun(ctx, "fuse_attn_wo") != 0 && m->nsplit > 1 && (D == 64 || D == 128) && !m->kv_f16;
+    m->fold_embed = tun(ctx, "fold_embed") != 0;
+    m->gain_alias = tun(ctx, "measure_gain_alias") != 0;
     m->var_qkv = resolve_variant(ctx, "qkv", (int)E); m->var_wo = resolve_variant(ctx, "wo", (int)E);
     m->var_w13 = resolve_variant(ctx, "w13", (int)E); m->var_w2 = resolve_variant(ctx, "w2", (int)E); m->var_head = resolve_variant(ctx, "head", (int)E);
     m->grid_qkv = grid_for(ctx, "gemv_bpc_qkv", (int)(3 * E / 2), (int)E);
@@ -494,8 +495,6 @@ extern "C" int thk_model_finalize(thk_model* m) {
     ALLOCZ(m->part_o, H * kMaxSplit * D * 4); ALLOCZ(m->part_ml, H * kMaxSplit * 2 * 4);
     ALLOCZ(m->block_best, (size_t)std::max(m->grid_head > 0 ? m->grid_head : 1, ctx->n_cu) * 8 + 4096);
     ALLOCZ(m->rope_tab, T * (D / 2) * 2 * 4);
-    ALLOCZ(m->fuse_counters, ((size_t)nl * kFuseStride + 32) * 4);
-    ALLOCZ(m->head_ticket, (size_t)H * 4);
     {
         std::vector<float> tab;
         build_rope_table(tab, (int)D, 0, (int)T);
@@ -546,7 +545,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
 }
 
 // Bounded in-launch waits raise a device-side error word instead of hanging; surface it.
-static int check_fuse_error(thk_model* m) {
+static int check_engine_error(thk_model* m) {
     if (m->engine && m->eng_words) {
         unsigned e = 0;
         HIPCHK(m->ctx, hipMemcpyAsync(&e, m->eng_words + 32, 4, hipMemcpyDeviceToHost, m->ctx->stream));
@@ -556,12 +555,6 @@ static int check_fuse_error(thk_model* m) {
             return fail(m->ctx, THK_ERR_STATE, "decode engine: bounded wait timed out (code %u, op %u, workgroup %u)", (e >> 24) & 0x7f, (e >> 12) & 0xfff, e & 0xfff);
         }
     }
-    if (!m->fuse_counters || !m->fuse_attn_wo) return THK_OK;   // only the fused experiment has in-launch waits
-    unsigned e = 0;
-    const int nl = m->l1 - m->l0;
-    HIPCHK(m->ctx, hipMemcpyAsync(&e, m->fuse_counters + (size_t)nl * kFuseStride, 4, hipMemcpyDeviceToHost, m->ctx->stream));
-    HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
-    if (e) return fail(m->ctx, THK_ERR_STATE, "in-launch attention->wo hand-off timed out (device error word %u)", e);
     return THK_OK;
 }
 
@@ -604,7 +597,7 @@ extern "C" int thk_model_eval(thk_model* m, int32_t seq, const int32_t* tokens, 
     if (logits_out) HIPCHK(ctx, hipMemcpyAsync(logits_out, sb.logits, V * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (hidden_inout) HIPCHK(ctx, hipMemcpyAsync(hidden_inout, head ? m->x : sb.hidden_out, E * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return check_fuse_error(m);
+    return check_engine_error(m);
 }
 
 extern "C" int thk_model_seq_set(thk_model* m, int32_t seq, int32_t token, int32_t pos) {
@@ -707,7 +700,7 @@ extern "C" int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out,
     }
     if (n_out) *n_out = h.n_gen;
     if (pos_out) *pos_out = h.pos;
-    return check_fuse_error(m);
+    return check_engine_error(m);
 }
 
 extern "C" int64_t thk_model_bytes_per_token(const thk_model* m, int32_t T) {
@@ -741,6 +734,36 @@ extern "C" int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_ent
     for (auto ev : p.events) hipEventDestroy(ev);
     *n_out = n;
     return rc;
+}
+
+// Development aid (libthk_trace.so, tools/step_trace.py): one eager decode step with every wave of every launch stamping
+// the 100 MHz s_memrealtime counter at four points (kernel entry | activation vector staged | first weight batch consumed |
+// done); returns [n_kernels][kTraceBlocks][8 waves][4] u64 (0 = not stamped) and the launch names in thk_model_profile_step order.
+extern "C" int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long long* out, int64_t cap_words, int32_t max_names, char (*names)[48],
+                                    int32_t* n_kernels, int32_t* blocks_per_kernel) {
+    if (!m || !out || !n_kernels || !blocks_per_kernel) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
+    if (!trace_compiled()) return fail(ctx, THK_ERR_STATE, "this libthk was built without -DTHK_TRACE (build libthk_trace.so: __graft_entry__.build_libthk(trace=True))");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t max_k = 6 * (size_t)(m->l1 - m->l0) + 8;
+    const size_t words = max_k * kTraceBlocks * kTraceWords;
+    if (!m->trace_buf) HIPCHK(ctx, hipMalloc((void**)&m->trace_buf, words * 8));
+    HIPCHK(ctx, hipMemsetAsync(m->trace_buf, 0, words * 8, ctx->stream));
+    StepProf p;
+    p.names_only = true;
+    m->trace_on = true;
+    int rc = enqueue_step(m, seq, &p);
+    m->trace_on = false;
+    if (rc == THK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "sync failed while tracing");
+    for (auto ev : p.events) hipEventDestroy(ev);
+    if (rc != THK_OK) return rc;
+    const size_t nk = p.names.size();
+    REQUIRE(ctx, nk <= max_k && (int64_t)(nk * kTraceBlocks * kTraceWords) <= cap_words, "step trace needs %zu words", nk * kTraceBlocks * kTraceWords);
+    HIPCHK(ctx, hipMemcpy(out, m->trace_buf, nk * kTraceBlocks * kTraceWords * 8, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nk && (int)i < max_names && names; ++i) { strncpy(names[i], p.names[i].c_str(), 47); names[i][47] = 0; }
+    *n_kernels = (int)nk; *blocks_per_kernel = kTraceBlocks;
+    return THK_OK;
 }
 
 // Batched prompt prefill (config C3): the M prompt tokens go through the layers together so every
