@@ -45,6 +45,9 @@ def parse():
                    help="prompt: run the 511-token synthetic prompt through the decode path; seeded: (N>1 default off)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-profile", action="store_true")
+    p.add_argument("--no-extras", action="store_true",
+                   help="skip the time-boxed extra measurements taken after the timed region at N=1 (per-step distribution over 200 steps, "
+                        "128-token prefill = config C3, 13B decode = config C5); `value`/`config` never depend on them")
     p.add_argument("--tunable", action="append", default=[], help="name=value (libthk launch-geometry knob)")
     p.add_argument("--lmhead", default="correct", choices=["correct", "faithful"])
     p.add_argument("--force-pipeline", action="store_true",
@@ -55,6 +58,9 @@ def parse():
                    help="KV-cache storage: f32 as the reference (default, the headline configuration) or the optional binary16 cache (s_kv = 2 in bytes/token)")
     p.add_argument("--cpu-baseline-layers", type=int, default=0,
                    help="layers of the CPU baseline model (0 = the full model when host RAM allows, else a 4-layer sample scaled up and labelled so)")
+    p.add_argument("--stub-stage", action="store_true",
+                   help="PLUMBING CHECK, no GPU: run the N>1 flow (self-launch, process group, ring driver, timing protocol, JSON line) over gloo "
+                        "with a trivial CPU stage in place of libthk; the line is marked \"stub\": true and its value means nothing")
     p.add_argument("--master-port", type=int, default=29533, help="rendezvous port when bench.py launches its own ranks (--gpus N without torchrun)")
     return p.parse_args()
 
@@ -65,7 +71,7 @@ def self_launch(args):
     import subprocess
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if have < args.gpus:
+    if have < args.gpus and not args.stub_stage:
         log(f"[bench] ERROR: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to run on fewer ranks")
         return 2
     cmd = launch_command(args.gpus, args.master_port, sys.argv[1:])
@@ -157,6 +163,70 @@ def kernel_profile(model, shape, T, n_steps=6):
     return out
 
 
+def step_distribution(model, stream, torch, n=200):
+    """median / p5 / p95 over >= 200 steps.  Single-step graph replays with a HIP event between steps on the
+    libthk stream (the headline `value` replays multi-step graphs - 20 steps = ONE graph - with no events in between; consecutive graph launches sit ~50 us apart on the GPU, so these run that much slower per step)."""
+    model.prepare_steps(1)
+    model.decode_steps(8, 0, advance=False)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    evs[0].record(stream)
+    for i in range(n):
+        model.decode_steps(1, 0, advance=False)
+        evs[i + 1].record(stream)
+    torch.cuda.synchronize()
+    ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(n)])
+    return {"n": n, "p5": round(float(np.percentile(ms, 5)), 4), "p50": round(float(np.percentile(ms, 50)), 4),
+            "p95": round(float(np.percentile(ms, 95)), 4), "mean": round(float(ms.mean()), 4), "max": round(float(ms.max()), 4),
+            "method": "single-step graph replays, one HIP event between steps on the libthk stream"}
+
+
+def extra_prefill_128(thk, model, shape, ctx):
+    """Config C3 on the model that was just timed: 128 synthetic ids, n_past = 0, one batched forward on the MFMA GEMM path."""
+    M = 128
+    toks = np.concatenate([[1], np.random.default_rng(128).integers(3, shape.n_vocab, M - 1)]).astype(np.int32)
+    t_first = time.perf_counter()
+    model.reset_kv(0)
+    model.prefill(toks, 0)                       # first call: builds the tile images of the layer matrices and the workspace
+    t_first = time.perf_counter() - t_first
+    ts = []
+    for _ in range(5):
+        model.reset_kv(0); ctx.sync()
+        t0 = time.perf_counter(); model.prefill(toks, 0); ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    flops = 2.0 * (shape.weight_bytes(head=False) / 2) * M + 2.0 * shape.n_vocab * shape.n_embd
+    return {"workload": f"LLaMA-7B f16, {M}-token prompt prefill (n_past=0), 1 GPU, logits of the last token read back", "ms": round(t * 1e3, 3),
+            "ms_min": round(min(ts) * 1e3, 3), "tok_s": round(M / t, 1), "tflops": round(flops / t / 1e12, 2), "mfma_peak_tflops_f16_dense": 2500,
+            "frac_of_mfma_peak": round(flops / t / 2.5e15, 4), "weight_pass_hbm_ms": round(shape.weight_bytes() / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
+            "first_call_ms": round(t_first * 1e3, 1), "timing": "host wall time around thk_model_prefill (host-to-device token copy and 128 KB logits read-back included), median of 5"}
+
+
+def extra_decode_13b(thk, ctx, T, stream, torch, steps=100, warmup=20):
+    """Config C5: LLaMA-13B f16 on the same GPU, same protocol as the headline (KV filled by the 511-token prompt, hold position)."""
+    shape = thk.LLAMA_13B
+    m = thk.Model(ctx, shape, n_seq=1)
+    try:
+        m.fill_synthetic(); m.finalize()
+        prompt = synthetic_prompt(shape, T, 0)
+        m.eval(prompt[:T - 1], 0, want_logits=False)
+        m.seq_set(0, int(prompt[T - 1]), T - 1)
+        m.prepare_steps(warmup); m.prepare_steps(steps)
+        m.decode_steps(warmup, 0, advance=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); e0.record(stream)
+        m.decode_steps(steps, 0, advance=False)
+        e1.record(stream); torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        b_tok = shape.bytes_per_token(T)
+        tok_s = steps / wall
+        return {"workload": f"LLaMA-13B f16, {T}-ctx single-token greedy decode (n_past={T - 1}), 1 sequence", "tok_s": round(tok_s, 2),
+                "ms_per_step": round(wall / steps * 1e3, 4), "event_ms_per_step": round(e0.elapsed_time(e1) / steps, 4), "steps": steps, "warmup": warmup,
+                "bytes_per_token": b_tok,
+                "step_roofline": {"achieved": round(b_tok * tok_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_tok * tok_s / 1e9 / HBM_PEAK_GBS, 4)}}
+    finally:
+        m.close()
+
+
 SKIP_IDS = {"norm_qkv_rope_kv": 1, "attn_decode": 2, "attn_wo_resid": 3, "norm_w13_swiglu": 4, "w2_resid": 5, "norm_lmhead": 6}
 
 
@@ -186,6 +256,82 @@ def marginal_kernel_us(thk, ctx, shape, T, skip_id, launches_per_step, full_ms_p
     return (full_ms_per_step - skip_ms_per_step) * 1e3 / launches_per_step
 
 
+class StubStage:
+    """CPU stand-in for HipStage (--stub-stage): same duck type, trivial arithmetic, no libthk.  Exists so that the N>1 control
+    flow of this file can run where there is no GPU (tests/test_bench_launcher.py); it computes nothing of the model."""
+
+    def __init__(self, torch, rank, world, n_seq, n_embd=64, n_vocab=1000):
+        self.is_first, self.is_last, self.V = rank == 0, rank == world - 1, n_vocab
+        self.hidden_in = [torch.zeros(n_embd) for _ in range(n_seq)]
+        self.hidden_out = [torch.zeros(n_embd) for _ in range(n_seq)]
+        self.token = [torch.zeros(1, dtype=torch.int32) for _ in range(n_seq)]
+        self.steps = 0
+
+    def set_seq(self, s, token, pos):
+        self.token[s][0] = int(token)
+
+    def set_token(self, s, token):
+        self.token[s][0] = int(token)
+
+    def step(self, s, advance):
+        src = self.token[s].float().expand(self.hidden_out[s].shape) if self.is_first else self.hidden_in[s]
+        if self.is_last:
+            self.token[s][0] = int(src.sum().item() * 31 + 7) % self.V
+        else:
+            self.hidden_out[s].copy_(src + 1.0)
+        self.steps += 1
+
+
+def main_stub(args, json_fd):
+    """The N>1 protocol of main() over gloo with StubStage: rendezvous, ring driver (prime / steady / drain), barriers, MAX over
+    ranks, one JSON line from rank 0.  No GPU, no libthk, no model arithmetic."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    thk_pkg_dir = os.path.join(ROOT, "token-hawk_amd")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("thk_pipeline_only", os.path.join(thk_pkg_dir, "pipeline.py"))
+    pipe = importlib.util.module_from_spec(spec)
+    sys.modules["thk_pipeline_only"] = pipe          # dataclasses look the module up while the class body runs
+    spec.loader.exec_module(pipe)                    # pipeline.py alone: importing the package would dlopen libthk
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_PORT", str(args.master_port)); os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    N = S = world
+    stage = StubStage(torch, rank, N, S)
+    drv = pipe.PipelineDriver(stage, rank, N, S, force_ring=(N == 1))
+    T = max(2, min(args.ctx, 16))
+    prompts = np.stack([synthetic_prompt(type("Sh", (), {"n_vocab": stage.V})(), T, s) for s in range(S)], axis=1)
+    for s in range(S):
+        stage.set_seq(s, int(prompts[0, s]), 0)
+    drv.run(T - 1, advance=True, forced_tokens=prompts[:T - 1])
+    drv.prime(advance=False)
+    drv.steady(args.warmup, advance=False)
+    dist.barrier()
+    before = stage.steps
+    t0 = time.perf_counter()
+    drv.steady(args.steps, advance=False)
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    timed_items = stage.steps - before
+    drv.drain(advance=False)
+    tmax = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    one = torch.ones(1, dtype=torch.int32); dist.all_reduce(one)
+    items = torch.tensor([timed_items], dtype=torch.int64); dist.all_reduce(items, op=dist.ReduceOp.MIN)
+    elapsed = float(tmax.item())
+    if rank == 0:
+        result = {"metric": "decode tokens/sec, LLaMA-7B f16, 512-ctx, 1/2/4/8 MI355X; % HBM roofline", "stub": True,
+                  "value": round(args.steps * S / elapsed, 2), "unit": "tokens/s", "n_gpus": N, "ranks_joined": int(one.item()), "steps": args.steps,
+                  "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                  "vs_baseline": None, "dtype": "none", "data": "STUB STAGE (CPU plumbing check of the N>1 flow: no GPU, no model arithmetic)",
+                  "config": {"workload": "stub", "sequences": S, "parallelism": f"pp{N}", "transport": "gloo"},
+                  "items_per_rank_in_timed_region": int(items.item()),
+                  "single_stream": {"latency_ms_per_token": round(elapsed / args.steps * 1e3, 4)},
+                  "timed_region": "steady ring: prime() before the warm-up, steps * S micro-steps timed, drain() after (no fill/drain inside)"}
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     # stdout must carry exactly ONE line (the JSON).  Native libraries print there too (RCCL writes a version banner
@@ -200,6 +346,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.stub_stage and world == args.gpus:
+        return main_stub(args, json_fd)
     if world != args.gpus:
         log(f"[bench] ERROR: WORLD_SIZE={world} but --gpus {args.gpus}: launch exactly --gpus ranks (or run `python bench.py --gpus N` and let it launch them)")
         sys.exit(2)
@@ -307,9 +455,12 @@ def main():
 
         def run_steps(k):
             if not PIPE:
-                model.decode_steps(k, 0, advance=False)       # replays of captured 8/4/2/1-step graphs (20 = 8 + 8 + 4)
+                model.decode_steps(k, 0, advance=False)       # replays of captured multi-step graphs (20 steps = ONE 20-step graph; 200 = 6 x 32 + 8)
             else:
-                drv.run(k, advance=False)
+                drv.steady(k, advance=False)                  # ring kept full: k * S micro-steps, one item per rank in each
+
+        if PIPE:
+            drv.prime(advance=False)                          # N - 1 fill micro-steps, outside the warm-up and the timed region
 
         if not PIPE:                                         # capture every multi-step graph the two calls below replay, outside the timed region
             model.prepare_steps(args.warmup); model.prepare_steps(args.steps)
@@ -332,6 +483,9 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
 
+        if PIPE:
+            drv.drain(advance=False)                          # the items still inside the ring leave it after the timed region
+            torch.cuda.synchronize(dev)
         tokens = args.steps * S
         value = tokens / elapsed
         ms_per_step = elapsed / args.steps * 1e3
@@ -364,8 +518,8 @@ def main():
                                    f"{'1 sequence' if N == 1 else f'{S} sequences in flight, layers pipelined over {N} GPUs (RCCL p2p)'}",
                        "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single", "transport": args.transport if PIPE else None,
                        "lmhead_mode": args.lmhead, "numerics": "f16 GGML weights x f32 activations, f32 accumulate, " + ("f32 KV cache (as the reference)" if kv_bytes == 4 else "binary16 KV cache (OPTION, not the reference's: s_kv = 2 in bytes/token)"),
-                       "decode_path": "persistent engine (1 launch/step)" if model.uses_engine() else "5 fused launches per layer, hipGraph replay (8/4/2/1-step graphs)",
-                       "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "attn_waves", "use_graph", "engine")}},
+                       "decode_path": "persistent engine (1 launch/step)" if model.uses_engine() else "5 fused launches per layer, hipGraph replay (n-step graphs, n <= 32: 20 steps = one graph)",
+                       "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "attn_waves", "use_graph", "engine", "fold_embed")}},
             "bytes_per_token": b_tok,
             "step_roofline": {"achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                               "frac_of_copy_rate": round(step_gbs / COPY_RATE_GBS, 4), "event_ms_per_step": round(ev_ms / args.steps, 4)},
@@ -379,6 +533,10 @@ def main():
                 result["stage_ms_no_handoff"] = stage_ms
                 result["ideal_pipeline_tokens_per_s"] = round(1e3 / max(stage_ms), 2)          # every stage busy, zero hand-off cost
                 result["pure_replica_upper_bound_tokens_per_s"] = round(N * 1e3 / sum(stage_ms), 2)   # N independent full models, no communication
+                # what a zero-cost hand-off could reach relative to N perfectly balanced stages: the slowest stage (the last one carries
+                # the lm-head, rank 0 the embedding fetch) bounds the ring
+                result["ideal_efficiency_bound"] = round(sum(stage_ms) / (N * max(stage_ms)), 4)
+            result["timed_region"] = "steady ring: prime() before the warm-up, steps * S micro-steps timed, drain() after (no fill/drain inside)"
         if rank == 0:
             gen, ngen, pos = (model.seq_get(0) if not PIPE else ([], 0, 0))
             if not PIPE:
@@ -424,6 +582,29 @@ def main():
                     log(f"[bench] marginal-cost measurement failed ({e}); keeping the eager figure")
             result["kernels"] = kp
         result["roofline"] = roof
+
+        if rank == 0 and N == 1 and not PIPE and not args.no_extras:
+            # Measured live AFTER the timed region and the roofline pass; never feeds `value` / `config`.  Each item is time-boxed by
+            # construction (200 steps; 6 prefill calls; 13B: ~3 s of fill + 511 + 120 steps) and failure-tolerant.
+            extras = {}
+            t_x = time.time()
+            try:
+                dist_ms = step_distribution(model, stream, torch)
+                result["ms_per_step_p5"], result["ms_per_step_p50"], result["ms_per_step_p95"] = dist_ms["p5"], dist_ms["p50"], dist_ms["p95"]
+                result["step_distribution"] = dist_ms
+            except Exception as e:
+                result["step_distribution"] = {"error": str(e)}
+            if args.model == "7b":
+                try:
+                    extras["prefill_128"] = extra_prefill_128(thk, model, shape, ctx)
+                except Exception as e:
+                    extras["prefill_128"] = {"error": str(e)}
+                try:
+                    extras["decode_13b"] = extra_decode_13b(thk, ctx, T, stream, torch)
+                except Exception as e:
+                    extras["decode_13b"] = {"error": str(e)}
+            extras["wall_s"] = round(time.time() - t_x, 1)
+            result["extras"] = extras
 
         if rank == 0 and N == 1 and not args.no_cpu_baseline:
             try:

@@ -219,8 +219,9 @@ int thk_model_seq_set_token(thk_model* m, int32_t seq, int32_t token);
  *   advance != 0: pos[seq] += 1 afterwards (0 = keep re-evaluating the same slot,
  *                 the fixed-T=512 benchmark protocol of BASELINE.md) */
 int thk_model_decode_step(thk_model* m, int32_t seq, int advance);
-/* n_steps back-to-back decode steps; replays captured 8-, 4- and 2-step graphs (20 = 8 + 8 + 4), which
- * amortises the inter-graph launch latency (~8 us) of the single-step form.
+/* n_steps back-to-back decode steps; replays captured multi-step graphs - one graph of exactly n_steps steps up to 32
+ * (20 steps = ONE graph launch), 32-step graphs plus one remainder graph beyond - because consecutive graph launches sit
+ * ~50 us apart on the GPU (measured on MI355X: single-step replays run 58 us per step slower than multi-step graphs).
  * Position contract (both calls): a step at position p needs p < n_ctx; an advancing step leaves p + 1.
  * A call that would evaluate a position >= n_ctx returns THK_ERR_INVALID and enqueues nothing (the device
  * side additionally never advances past n_ctx - 1). */

@@ -35,3 +35,18 @@ def test_too_few_gpus_is_an_error_not_a_one_gpu_run():
     """On a box with fewer than N GPUs (this container has none) `bench.py --gpus 2` exits 2 and prints no JSON line."""
     r = run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
     assert r.returncode == 2 and "refusing" in r.stderr and r.stdout.strip() == ""
+
+
+def test_self_launch_world_2_runs_the_ring_protocol_on_cpu():
+    """`bench.py --gpus 2` without torchrun starts its own two ranks; with --stub-stage (gloo, trivial CPU stage, no libthk) the
+    whole N>1 flow runs here: rendezvous on 127.0.0.1, prime / steady / drain of the ring driver, barriers, MAX over ranks, ONE
+    JSON line from rank 0 - so the first multi-GPU run is not the first time this code executes with N > 1."""
+    import json
+    r = run_bench(["--gpus", "2", "--stub-stage", "--steps", "4", "--warmup", "1", "--ctx", "8", "--master-port", str(29700 + os.getpid() % 200)], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["stub"] is True and d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["steps"] == 4 and d["scaling"] == "weak"
+    assert d["items_per_rank_in_timed_region"] == 4 * 2          # every rank processed exactly steps * S items: no fill/drain inside
+    assert "single_stream" in d and "steady ring" in d["timed_region"]

@@ -136,3 +136,31 @@ def test_driver_with_native_transport_single_rank_ring(thk, orc):
     assert got[2:] == exp
     ctx.lib.thk_pp_destroy(stage.pp)
     stage.model.close(); ctx.close()
+
+
+@pytest.mark.parametrize("transport", ["native", "torch"])
+def test_bench_pipeline_path_end_to_end_on_one_gpu(transport):
+    """`bench.py --force-pipeline --model tiny`: the N>1 code path of the benchmark itself (process group on RCCL, HipStage, ring
+    kept full across prime / steady / drain, stage timing, JSON line) runs end to end with one rank and a self send/recv, and the
+    line carries the keys the N>1 runs report."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env["MASTER_PORT"] = str(29800 + os.getpid() % 150 + (0 if transport == "native" else 1))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-pipeline", "--model", "tiny", "--steps", "6", "--warmup", "2",
+                        "--transport", transport, "--no-cpu-baseline", "--no-kernel-profile"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["ranks_joined"] == 1 and d["steps"] == 6 and d["value"] > 0
+    assert d["config"]["transport"] in (transport, "torch")           # native falls back to torch only if librccl cannot be bound
+    for key in ("single_stream", "stage_ms_no_handoff", "ideal_pipeline_tokens_per_s", "pure_replica_upper_bound_tokens_per_s",
+                "ideal_efficiency_bound", "timed_region"):
+        assert key in d, key
+    assert len(d["stage_ms_no_handoff"]) == 1 and 0 < d["ideal_efficiency_bound"] <= 1.0
+    assert "extras" not in d and "cpu_baseline" not in d              # N>1 protocol: no single-GPU extras on the pipeline path

@@ -48,7 +48,7 @@ class OracleStage:
             self.pos[s] += 1
 
 
-def _worker(rank, world, port, n_prompt, n_gen):
+def _worker(rank, world, port, n_prompt, n_gen, steady=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -66,8 +66,25 @@ def _worker(rank, world, port, n_prompt, n_gen):
         for s in range(S):
             stage.set_seq(s, int(prompts[0, s]), 0)
         r1 = drv.run(n_prompt, advance=True, forced_tokens=prompts)       # prompt through the pipeline
-        r2 = drv.run(n_gen, advance=True)                                  # greedy continuation (token ring)
-        assert r1.items == n_prompt * S and r2.items == n_gen * S
+        assert r1.items == n_prompt * S
+        extra = [0] * S
+        if not steady:
+            r2 = drv.run(n_gen, advance=True)                              # greedy continuation (token ring)
+            assert r2.items == n_gen * S
+        else:
+            # the ring kept full across calls (what bench.py times): prime, two steady() calls, drain.  Every rank processes exactly
+            # steps * S items per steady() call; after the drain all N - 1 + n_gen * S issued items have left the last stage, so the
+            # first N - 1 sequences are one token ahead of the others.
+            p = drv.prime(advance=True)
+            a = drv.steady(1, advance=True)
+            b = drv.steady(n_gen - 1, advance=True)
+            d = drv.drain(advance=True)
+            assert a.items == S and a.micro_steps == S and b.items == (n_gen - 1) * S and b.micro_steps == (n_gen - 1) * S
+            assert p.items + d.items == world - 1 and p.micro_steps == d.micro_steps == world - 1
+            extra = [1 if s < world - 1 else 0 for s in range(S)]
+            r3 = drv.run(1, advance=True)                                  # an empty ring takes a self-contained run again
+            assert r3.items == S
+            extra = [e + 1 for e in extra]
         if rank == world - 1:
             full = orc.OracleModel(shape, S); full.fill_synthetic()
             for s in range(S):
@@ -76,7 +93,7 @@ def _worker(rank, world, port, n_prompt, n_gen):
                 exp, tok = [], orc.greedy(lg)
                 exp.append(tok)
                 assert (stage.logits[s][n_prompt - 1] == lg).all()
-                for i in range(n_gen):
+                for i in range(n_gen + extra[s]):
                     lg, _ = full.eval(tok, n_prompt + i, seq=s); tok = orc.greedy(lg); exp.append(tok)
                     assert (stage.logits[s][n_prompt + i] == lg).all(), (s, i)
                 got = stage.gen[s]
@@ -91,6 +108,13 @@ def _worker(rank, world, port, n_prompt, n_gen):
 def test_pipeline_ring_matches_single_process(world):
     port = 29500 + world + (os.getpid() % 1000)
     mp.spawn(_worker, args=(world, port, 3, 4), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipeline_ring_kept_full_matches_single_process(world):
+    """prime / steady / steady / drain (no fill or drain inside a steady() call) produces the same tokens and logits."""
+    port = 29600 + world + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(world, port, 3, 4, True), nprocs=world, join=True)
 
 
 def test_layer_range_partition():

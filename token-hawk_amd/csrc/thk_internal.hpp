@@ -58,15 +58,14 @@ struct SeqBuf {
     int advance_host = -1;           // last value written
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    hipGraph_t graph_multi[3] = {nullptr, nullptr, nullptr};        // 2, 4 and 8 decode steps in one graph (thk_model_prepare_steps / first use)
-    hipGraphExec_t exec_multi[3] = {nullptr, nullptr, nullptr};
+    std::map<int, std::pair<hipGraph_t, hipGraphExec_t>> multi;     // n decode steps (2 <= n <= kMaxGraphSteps) in ONE graph (thk_model_prepare_steps / first use)
     int pos_host = 0;                // position the NEXT step evaluates (every change goes through this API, so the host knows it exactly)
     EngOp* eng_ops = nullptr;        // device: this sequence's engine program (cache / hidden-state pointers differ per sequence)
     int eng_n_ops = 0;
 };
 
 static const int kGenLogCap = 4096;
-static const int kMultiSteps[3] = {2, 4, 8};
+static const int kMaxGraphSteps = 32;     // longest multi-step graph; a request of n steps replays floor(n / 32) of these and ONE graph of the remainder
 
 struct thk_model {
     thk_ctx* ctx = nullptr;

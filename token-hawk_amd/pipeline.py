@@ -91,36 +91,53 @@ class PipelineResult:
 
 
 class PipelineDriver:
+    """Synchronous ring over an endless stream of work items: item i = (step i // S, sequence i % S); at global micro-step j rank
+    r processes item j - r and then exchanges (one send, one receive, grouped).  Two ways to drive it:
+
+    * run(steps)                     self-contained: fills the ring, processes steps * S items on every rank, drains it
+                                     (steps * S + N - 1 micro-steps).  Used for the prompt and by the tests.
+    * prime() / steady(steps) / drain()   the ring stays full between calls: steady(steps) is exactly steps * S micro-steps in
+                                     which EVERY rank processes one item, so a timed region around it holds no fill or drain
+                                     (round 2 timed run(): 7 of 167 micro-steps at N = 8, steps = 20 were fill/drain).
+    """
+
     def __init__(self, stage, rank: int, world: int, n_seq: int, force_ring: bool = False):
         assert n_seq == world or (world == 1 and not force_ring), "the synchronous ring schedule needs one sequence per stage"
         self.stage, self.rank, self.world, self.S = stage, rank, world, n_seq
         self.force_ring = force_ring      # world == 1 only: still post the (self) send/recv pair, to exercise the P2P plumbing
         self.prev, self.next = (rank - 1) % world, (rank + 1) % world
+        self.base = 0                     # items [0, base) have left the last stage
+        self.j = 0                        # next global micro-step
+        self.primed = False
 
-    def _exchange(self, j: int, total: int):
-        """Grouped P2P after micro-step j: send item (j - rank)'s output, receive the input of item (j + 1 - rank)."""
+    @property
+    def ring(self) -> bool:
+        return self.world > 1 or self.force_ring
+
+    def _exchange(self, j: int, lo: int, hi):
+        """Grouped P2P after micro-step j: send item (j - rank)'s output, receive the input of item (j + 1 - rank).
+        Only items in [lo, hi) exist (hi = None: no upper bound, the ring is kept full)."""
         st, r, N, S = self.stage, self.rank, self.world, self.S
+        live = (lambda i: lo <= i and (hi is None or i < hi))
+        i_done = j - r                                   # item this rank just finished
+        i_prev = j - ((r - 1) % N)                       # item the previous rank just finished
         if getattr(st, "pp", None) is not None:          # native RCCL transport (thk_pp_*), same schedule
             sends, recvs = [], []
-            i_done = j - r
-            if 0 <= i_done < total:
+            if live(i_done):
                 sends.append(("token" if st.is_last else "hidden", i_done % S, self.next))
-            i_prev = j - ((r - 1) % N)
-            if 0 <= i_prev < total:
+            if live(i_prev):
                 recvs.append(("token" if st.is_first else "hidden", i_prev % S, self.prev))
             if sends or recvs:
                 st.native_exchange(sends, recvs)
             return
         ops = []
-        i_done = j - r                                   # item this rank just finished
-        if 0 <= i_done < total:
+        if live(i_done):
             s = i_done % S
             if not st.is_last:
                 ops.append(dist.P2POp(dist.isend, st.hidden_out[s], self.next))
-            else:                                        # the token feeds item i_done + S on rank 0 (the ring
-                ops.append(dist.P2POp(dist.isend, st.token[s], self.next))   # stays primed across run() calls)
-        i_prev = j - ((r - 1) % N)                       # item the previous rank just finished
-        if 0 <= i_prev < total:
+            else:                                        # the token feeds item i_done + S on rank 0
+                ops.append(dist.P2POp(dist.isend, st.token[s], self.next))
+        if live(i_prev):
             if not st.is_first:
                 ops.append(dist.P2POp(dist.irecv, st.hidden_in[i_prev % S], self.prev))
             else:
@@ -129,27 +146,72 @@ class PipelineDriver:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()                                 # stream-ordered for NCCL; blocking for gloo
 
+    def _micro(self, n_micro: int, lo: int, hi, advance: bool, forced_tokens=None) -> int:
+        """n_micro global micro-steps from self.j on; returns the number of items this rank processed."""
+        st, r, S = self.stage, self.rank, self.S
+        done = 0
+        for j in range(self.j, self.j + n_micro):
+            i = j - r
+            if lo <= i and (hi is None or i < hi):
+                if st.is_first and forced_tokens is not None:
+                    k, s = divmod(i - lo, S)             # lo is a multiple of S here (checked by run())
+                    st.set_token(s, forced_tokens[k][s])
+                st.step(i % S, advance)
+                done += 1
+            self._exchange(j, lo, hi)
+        self.j += n_micro
+        return done
+
     def run(self, steps: int, advance: bool, forced_tokens=None) -> PipelineResult:
-        """Advance every sequence by `steps` tokens.  forced_tokens[k][s] (rank 0 only) overrides
+        """Advance every sequence by `steps` tokens, ring empty before and after.  forced_tokens[k][s] (rank 0 only) overrides
         the fed-back token with a prompt token (prefill through the same path)."""
-        st, r, N, S = self.stage, self.rank, self.world, self.S
+        st, S = self.stage, self.S
+        assert not self.primed, "run() needs an empty ring: drain() first"
         total = steps * S
-        if N == 1 and not self.force_ring:
+        if not self.ring:
             for i in range(total):
                 k, s = divmod(i, S)
                 if forced_tokens is not None:
                     st.set_token(s, forced_tokens[k][s])
                 st.step(s, advance)
             return PipelineResult(total, total)
-        done = 0
-        n_micro = total + N - 1
-        for j in range(n_micro):
-            i = j - r
-            if 0 <= i < total:
-                k, s = divmod(i, S)
-                if st.is_first and forced_tokens is not None:
-                    st.set_token(s, forced_tokens[k][s])
-                st.step(s, advance)
-                done += 1
-            self._exchange(j, total)
+        assert forced_tokens is None or self.base % S == 0, "forced tokens need the ring at a step boundary"
+        lo = self.base
+        n_micro = total + self.world - 1
+        done = self._micro(n_micro, lo, lo + total, advance, forced_tokens)
+        self.base = lo + total
+        self.j = self.base                                # an empty ring restarts at micro-step == first item
         return PipelineResult(done, n_micro)
+
+    def prime(self, advance: bool) -> PipelineResult:
+        """Fill the ring: N - 1 micro-steps, after which rank r has item base + N - 2 - r behind it and every later
+        micro-step finds work on every rank."""
+        assert not self.primed
+        self.primed = True
+        if not self.ring:
+            return PipelineResult(0, 0)
+        n = self.world - 1
+        return PipelineResult(self._micro(n, self.base, None, advance), n)
+
+    def steady(self, steps: int, advance: bool) -> PipelineResult:
+        """steps * S micro-steps with the ring full: every rank processes exactly steps * S items."""
+        assert self.primed, "prime() first"
+        total = steps * self.S
+        if not self.ring:
+            for i in range(total):
+                self.stage.step(i % self.S, advance)
+            return PipelineResult(total, total)
+        return PipelineResult(self._micro(total, self.base, None, advance), total)
+
+    def drain(self, advance: bool) -> PipelineResult:
+        """Let the items already issued by rank 0 leave the last stage (N - 1 micro-steps); the ring is empty afterwards."""
+        assert self.primed
+        self.primed = False
+        if not self.ring:
+            return PipelineResult(0, 0)
+        n = self.world - 1
+        hi = self.j                                       # rank 0 has issued items [base, j)
+        done = self._micro(n, self.base, hi, advance)
+        self.base = hi
+        self.j = hi
+        return PipelineResult(done, n)
