@@ -140,6 +140,10 @@ int thk_lmhead_f16(thk_ctx* ctx, const void* W, int64_t V, int64_t E, const floa
 /* Greedy pick, llama_sample_top_p_top_k temp<=0 branch (th-llama.cpp:826-838):
  * smallest index attaining the max.  id_out is a dev int32. */
 int thk_argmax(thk_ctx* ctx, const float* logits, int64_t V, int32_t* id_out);
+/* The k largest of V device-resident f32 logits, value descending and ties by ascending index (a total order, so the result is
+ * unique), selected and sorted on the GPU; only k (value, index) pairs are copied to the host.  V <= 32768, k <= 1024.
+ * Replaces the 4 * n_vocab-byte map-read + CPU partial_sort of the stochastic sampler (th-llama.cpp:686-724, :814-857). */
+int thk_topk_f32(thk_ctx* ctx, const float* logits, int64_t V, int32_t k, float* values_out, int32_t* ids_out);
 
 /* Embedding row fetch (th-llama.cpp:577-584 + loader :185-195): x = f32(table[token,:]),
  * table f16 [V,E] on device (the reference keeps an f32 copy on the host). */
@@ -241,6 +245,12 @@ void* thk_model_token_dev(thk_model* m, int32_t seq);   /* dev int32: current/ne
 void* thk_model_logits_dev(thk_model* m, int32_t seq);  /* dev f32[V] (head stage) */
 /* Blocking: copy the generated-token log (up to cap ids) and position of `seq`. */
 int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out, int32_t cap, int32_t* n_out, int32_t* pos_out);
+/* Logits of the sequence's last evaluated token (head stages): the k largest via thk_topk_f32's kernel, or all n_vocab of them. */
+int thk_model_logits_topk(thk_model* m, int32_t seq, int32_t k, float* values_out, int32_t* ids_out);
+int thk_model_read_logits(thk_model* m, int32_t seq, float* logits_out);
+/* The sequence's current token: the greedy pick of its last step (or what thk_model_seq_set / _set_token put there).  One
+ * 4-byte read-back after a stream sync; unlike the log of thk_model_seq_get it does not depend on how many steps ran. */
+int thk_model_seq_last_token(thk_model* m, int32_t seq, int32_t* token_out);
 
 /* Bytes of HBM this stage streams per decode step at context length T
  * (weights + KV read + KV write + gains; SURVEY.md §8d formula) — used by bench.py. */

@@ -8,9 +8,9 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-3
 
 
-def engine_model(thk, ctx, shape, *args, park=1, graph=1, **kw):
-    old = {k: ctx.get_tunable(k) for k in ("engine", "engine_park", "use_graph")}
-    ctx.set_tunable("engine", 1); ctx.set_tunable("engine_park", park); ctx.set_tunable("use_graph", graph)
+def engine_model(thk, ctx, shape, *args, graph=1, **kw):
+    old = {k: ctx.get_tunable(k) for k in ("engine", "use_graph")}
+    ctx.set_tunable("engine", 1); ctx.set_tunable("use_graph", graph)
     try:
         m = thk.Model(ctx, shape, *args, **kw)
         m.fill_synthetic()
@@ -22,12 +22,11 @@ def engine_model(thk, ctx, shape, *args, park=1, graph=1, **kw):
     return m
 
 
-@pytest.mark.parametrize("park", [0, 1])
 @pytest.mark.parametrize("graph", [0, 1])
-def test_engine_tiny_every_token_vs_oracle(thk, orc, ctx, park, graph):
-    m = engine_model(thk, ctx, thk.TINY, park=park, graph=graph)
+def test_engine_tiny_every_token_vs_oracle(thk, orc, ctx, graph):
+    m = engine_model(thk, ctx, thk.TINY, graph=graph)
     om = orc.OracleModel(orc.TINY); om.fill_synthetic()
-    rng = np.random.default_rng(park * 2 + graph)
+    rng = np.random.default_rng(2 + graph)
     toks = [1] + rng.integers(3, 2048, 40).tolist()
     for i, t in enumerate(toks):
         lg, hid = m.eval([t], i, want_hidden=True)

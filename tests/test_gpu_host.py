@@ -36,6 +36,7 @@ def host(thk):
     lib.thh_do_inference.argtypes = [C.c_int64, C.c_char_p, C.c_void_p, C.c_char_p, C.c_int]
     lib.thh_set_sampler.argtypes = [C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float]
     lib.thh_set_prefill.argtypes = [C.c_int64, C.c_int]
+    lib.thh_set_device_topk.argtypes = [C.c_int64, C.c_int]
     lib.thh_free.argtypes = [C.c_int64]; lib.thh_reset.argtypes = [C.c_int64]; lib.thh_hparams.argtypes = [C.c_int64, C.c_void_p]
     lib.capi_model_begin_load.argtypes = []
     lib.capi_load_model_header.argtypes = [C.c_char_p, C.c_double]
@@ -244,6 +245,40 @@ def test_prompt_prefill_generates_the_same_text(host, ctx, model_file, temp):
         host.thh_free(h)
     assert out[0][0] > 0
     assert out[0] == out[1]
+
+
+@pytest.mark.parametrize("params", [(40, 0.95, 0.8, 1.1), (5, 1.0, 1.5, 1.3), (100, 0.6, 0.4, 1.0)])
+def test_device_topk_sampler_generates_the_same_text(host, ctx, model_file, params):
+    """Stochastic do_inference with the sampler's candidates selected on the device (thk_model_logits_topk: k x 8 bytes per token)
+    == the reference-style path that reads all n_vocab logits back per token (th-llama.cpp:686-724): same seed, same text, same
+    final position, across two messages (the second one runs with a filled repetition-penalty window)."""
+    path, _, words, scores = model_file
+    k, p, t, pen = params
+    out = []
+    for dev_topk in (0, 1):
+        h = host.thh_load_file(ctx.h, path.encode(), 0)       # fresh model => fresh mt19937(780658349)
+        assert h > 0, host.thh_last_error()
+        host.thh_set_sampler(h, k, p, t, pen)
+        host.thh_set_device_topk(h, dev_topk)
+        n_past = C.c_int32(); text = C.create_string_buffer(1 << 16)
+        n1 = host.thh_do_inference(h, b"the quick brown fox", C.byref(n_past), text, len(text))
+        t1 = text.value
+        n2 = host.thh_do_inference(h, b"jumps over", C.byref(n_past), text, len(text))
+        out.append((n1, n2, n_past.value, t1, text.value))
+        host.thh_free(h)
+    assert out[0][0] > 0
+    assert out[0] == out[1]
+
+
+def test_model_logits_topk_and_read_logits(thk, ctx):
+    m = thk.Model(ctx, thk.TINY_Q1); m.fill_synthetic(); m.finalize()
+    lg, _ = m.eval([1, 5, 9], 0)
+    full = m.read_logits()
+    assert (full.view(np.uint32) == lg.view(np.uint32)).all()
+    vals, ids = m.logits_topk(64)
+    order = np.lexsort((np.arange(lg.size), -lg.astype(np.float64)))[:64]
+    assert ids.tolist() == order.tolist() and (vals == lg[order]).all()
+    m.close()
 
 
 def test_cli_matches_library(host, ctx, model_file):

@@ -212,6 +212,31 @@ def test_argmax_first_max_wins(ctx):
     assert int(did.download(np.int32, 1)[0]) == 42
 
 
+@pytest.mark.parametrize("V,k", [(32000, 41), (32000, 1), (32000, 1024), (2048, 40), (777, 777), (5, 3)])
+def test_topk_f32(ctx, V, k):
+    """Device top-k (radix select + bitonic sort in one workgroup) == numpy: the k largest values, descending, ties by ascending
+    index - with heavy ties (quantised logits), negative values, signed zeros and infinities in the input."""
+    rng = np.random.default_rng(V * 31 + k)
+    lg = (rng.standard_normal(V) * 4).astype(np.float32)
+    lg[::3] = np.round(lg[::3])                             # many exact ties
+    if V > 100:
+        lg[7] = np.inf; lg[11] = -np.inf; lg[13] = 0.0; lg[17] = -0.0; lg[19] = lg[23] = lg.max()
+    d = ctx.from_numpy(lg)
+    vals, ids = ctx.topk_f32(d, V, k)
+    # reference order: value descending, then index ascending; -0.0 sorts below +0.0 in the kernel's bit-order map
+    key = np.where(np.signbit(lg), ~lg.view(np.uint32), lg.view(np.uint32) | np.uint32(0x80000000)).astype(np.uint64)
+    order = np.lexsort((np.arange(V), -key.astype(np.int64)))[:k]
+    assert ids.tolist() == order.tolist()
+    assert vals.view(np.uint32).tolist() == lg[order].view(np.uint32).tolist()
+
+
+def test_topk_rejects_out_of_range(ctx, thk):
+    d = ctx.alloc(40000 * 4)
+    for V, k in [(40000, 10), (1000, 1025), (10, 11), (0, 1)]:
+        with pytest.raises(thk.ThkError):
+            ctx.topk_f32(d, V, k)
+
+
 def test_embed(ctx, orc):
     rng = np.random.default_rng(2)
     V, E = 100, 512

@@ -347,6 +347,46 @@ def test_sampler_matches_reference_fixture(host):
         assert out.tolist() == want.tolist(), (c, float(k), float(p), float(t))
 
 
+def test_sampler_from_device_topk_candidates_matches_reference_fixture(host):
+    """The stochastic sampler fed with the K largest raw logits only (what thk_model_logits_topk returns: value descending, ties
+    by ascending id; K = top_k + distinct penalised ids + 1) instead of all n_vocab reproduces every draw of the REFERENCE's own
+    llama_sample_top_p_top_k - including the parameter sets with tied logits, where the candidate path refuses (the order of equal
+    values is std::partial_sort's business) and the full vector is used, exactly as th_eval does on the GPU path."""
+    g = _ref_host_fixture()
+    fast_total = draws_total = 0
+    for c in range(g["smp_par"].shape[0]):
+        k, p, t, pen = g["smp_par"][c]
+        lg = np.ascontiguousarray(g["smp_logits"][c]); last = np.ascontiguousarray(g["smp_last"][c])
+        want = g["smp_draws"][c]
+        out = np.empty(want.size, np.int32); n_fast = C.c_int32()
+        host.thh_sample_topk(C.c_uint32(int(g["smp_seed"][c])), P(lg), lg.size, int(k), C.c_float(float(p)), C.c_float(float(t)), C.c_float(float(pen)),
+                             P(last), last.size, out.size, P(out), C.byref(n_fast))
+        assert out.tolist() == want.tolist(), (c, float(k), float(p), float(t))
+        if t > 0 and 0 < k < lg.size:
+            fast_total += n_fast.value; draws_total += want.size
+    assert draws_total > 0 and fast_total >= draws_total // 2, (fast_total, draws_total)   # the candidate path really carried most draws
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sampler_from_topk_candidates_random_logits_and_penalties(host, seed):
+    """Seeded logits with many penalised ids (both signs) and an engineered tie exactly at the top_k boundary: candidate path ==
+    full path draw for draw."""
+    rng = np.random.default_rng(seed)
+    V = 5000
+    lg = (rng.standard_normal(V) * 3).astype(np.float32)
+    last = rng.integers(0, V, 300).astype(np.int32)
+    order = np.argsort(-lg, kind="stable")
+    if seed == 3:
+        lg[order[40]] = lg[order[39]]                     # tie between the 40th and the 41st largest: refusal + full path
+    for (k, p, t, pen) in [(40, 0.95, 0.8, 1.1), (10, 1.0, 1.3, 1.3), (100, 0.5, 0.5, 1.0)]:
+        a = np.empty(64, np.int32); b = np.empty(64, np.int32); n_fast = C.c_int32()
+        host.thh_sample(C.c_uint32(77 + seed), P(lg), V, k, C.c_float(p), C.c_float(t), C.c_float(pen), P(last), last.size, a.size, P(a))
+        host.thh_sample_topk(C.c_uint32(77 + seed), P(lg), V, k, C.c_float(p), C.c_float(t), C.c_float(pen), P(last), last.size, b.size, P(b), C.byref(n_fast))
+        assert a.tolist() == b.tolist(), (k, p, t, pen)
+        if seed != 3:
+            assert n_fast.value == 64
+
+
 def test_python_restatements_match_reference_fixture():
     """The independent restatements used elsewhere in this file (py_tokenize, py_sample + MT19937) agree with the reference's
     own functions too, so the older restatement-based tests are anchored to the same pin."""

@@ -178,6 +178,12 @@ class Context:
     def argmax(self, logits, V, id_out):
         self.check(self.lib.thk_argmax(self.h, _ptr(logits), V, _ptr(id_out)), "thk_argmax")
 
+    def topk_f32(self, logits, V, k):
+        """The k largest of V device logits as (values f32[k], ids int32[k]); value descending, ties by ascending id."""
+        vals, ids = np.empty(k, np.float32), np.empty(k, np.int32)
+        self.check(self.lib.thk_topk_f32(self.h, _ptr(logits), V, k, vals.ctypes.data, ids.ctypes.data), "thk_topk_f32")
+        return vals, ids
+
     def embed_f16(self, table, E, token, x):
         self.check(self.lib.thk_embed_f16(self.h, _ptr(table), E, token, _ptr(x)), "thk_embed_f16")
 
@@ -294,6 +300,16 @@ class Model:
         self.ctx.check(self.ctx.lib.thk_model_prefill(self.h, seq, toks.ctypes.data, toks.size, n_past,
                                                       None if logits is None else logits.ctypes.data), "thk_model_prefill")
         return logits
+
+    def logits_topk(self, k: int, seq: int = 0):
+        vals, ids = np.empty(k, np.float32), np.empty(k, np.int32)
+        self.ctx.check(self.ctx.lib.thk_model_logits_topk(self.h, seq, k, vals.ctypes.data, ids.ctypes.data), "thk_model_logits_topk")
+        return vals, ids
+
+    def read_logits(self, seq: int = 0):
+        out = np.empty(self.shape.n_vocab, np.float32)
+        self.ctx.check(self.ctx.lib.thk_model_read_logits(self.h, seq, out.ctypes.data), "thk_model_read_logits")
+        return out
 
     def seq_set(self, seq: int, token: int, pos: int):
         self.ctx.check(self.ctx.lib.thk_model_seq_set(self.h, seq, token, pos), "thk_model_seq_set")

@@ -56,6 +56,7 @@ SIGNATURES = {
     "thk_mul_inplace": (C.c_int, [vp, vp, vp, i64]),
     "thk_lmhead_f16": (C.c_int, [vp, vp, i64, i64, vp, vp, C.c_int]),
     "thk_argmax": (C.c_int, [vp, vp, i64, vp]),
+    "thk_topk_f32": (C.c_int, [vp, vp, i64, i32, vp, vp]),
     "thk_embed_f16": (C.c_int, [vp, vp, i64, i32, vp]),
     "thk_gemm_f16_prefill": (C.c_int, [vp, vp, i64, i64, vp, i64, vp]),
     "thk_synth_f16": (C.c_int, [vp, C.c_char_p, u64, C.c_float, i64, vp]),
@@ -83,6 +84,9 @@ SIGNATURES = {
     "thk_model_token_dev": (vp, [vp, i32]),
     "thk_model_logits_dev": (vp, [vp, i32]),
     "thk_model_seq_get": (C.c_int, [vp, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]),
+    "thk_model_seq_last_token": (C.c_int, [vp, i32, C.POINTER(i32)]),
+    "thk_model_logits_topk": (C.c_int, [vp, i32, i32, vp, vp]),
+    "thk_model_read_logits": (C.c_int, [vp, i32, vp]),
     "thk_model_bytes_per_token": (i64, [vp, i32]),
     "thk_model_profile_step": (C.c_int, [vp, i32, i32, vp, vp, C.POINTER(i32)]),
     "thk_model_step_trace": (C.c_int, [vp, i32, vp, i64, i32, vp, C.POINTER(i32), C.POINTER(i32)]),

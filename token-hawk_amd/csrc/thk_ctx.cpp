@@ -36,7 +36,6 @@ void default_tunables(thk_ctx* ctx) {
                                           // refused unless the process runs with THK_MEASURE_HOOKS=1 (never in a product)
     ctx->tun["measure_gain_alias"] = 0;   // measurement only (THK_MEASURE_HOOKS=1): the RMS prologues read the activation vector in place of the gain vector
     ctx->tun["kv_f16"] = 0;               // 1 = K/V caches stored as binary16 (half the KV bytes; k, v are rounded RNE at the append); default f32 as the reference
-    ctx->tun["engine_park"] = 1;          // engine variant whose waiting consumer waves park one landed ring slot in registers (more loader run-ahead)
     ctx->tun["engine_trace"] = 0;         // development: per-op s_memtime timeline of the engine (thk_model_engine_trace)
     ctx->tun["engine"] = 0;               // 1 = decode step as ONE persistent loader/consumer launch (thk_engine.hip) when the shape allows; default 0 = 5
                                           // launches per layer: measured on MI355X the engine streams at 6.9-7.0 TB/s but every in-launch all-to-all hand-off

@@ -24,37 +24,30 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "thk_kernels.hpp"
+#include "thk_device.hpp"
 
 namespace thk {
 
-// Two builds of the same kernel: without and with register parking (see Park in the body).  Parking extends the
-// loader's run-ahead by one slot per consumer wave; two slots per wave exceed the 256-ArchVGPR budget and spill.
-#define THK_ENG_NS eng_p0
-#define THK_ENG_PARK 0
+// One build (round 3): waiting consumer waves park one landed ring slot each in registers, which extends the loader's run-ahead
+// by three slots.  (Round 2 also shipped the variant without parking; it was never faster and is gone.)
+namespace eng {
 #include "thk_engine_body.inc"
-#undef THK_ENG_NS
-#undef THK_ENG_PARK
-#define THK_ENG_NS eng_p1
-#define THK_ENG_PARK 1
-#include "thk_engine_body.inc"
-#undef THK_ENG_NS
-#undef THK_ENG_PARK
+}
 
-size_t engine_lds_bytes(int NS, int v0_bytes, int v1_bytes) { return (size_t)NS * kEngSlotBytes + (size_t)v0_bytes + (size_t)v1_bytes + eng_p0::SC_BYTES + eng_p0::CT_BYTES; }
+size_t engine_lds_bytes(int NS, int v0_bytes, int v1_bytes) { return (size_t)NS * kEngSlotBytes + (size_t)v0_bytes + (size_t)v1_bytes + eng::SC_BYTES + eng::CT_BYTES; }
 
 hipError_t launch_engine(const EngArgs& a, int n_cu, hipStream_t st) {
     const size_t lds = engine_lds_bytes(a.NS, a.v0_bytes, a.v1_bytes);
-    static size_t attr_set[2][kMaxDevices] = {};
-    const int v = a.park ? 1 : 0;
-    auto kn = v ? eng_p1::engine_kernel : eng_p0::engine_kernel;
+    static size_t attr_set[kMaxDevices] = {};
+    auto kn = eng::engine_kernel;
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
-    if (lds > attr_set[v][dev]) {
+    if (lds > attr_set[dev]) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        attr_set[v][dev] = lds;
+        attr_set[dev] = lds;
     }
     hipLaunchKernelGGL(kn, dim3(n_cu), dim3(256), lds, st, a, a.ops, a.st, a.epoch);
     return hipGetLastError();

@@ -111,6 +111,22 @@ struct thk_model {
     bool trace_on = false;
 };
 
+// ---------------------------------------------------------------- model internals shared by thk_model*.cpp
+// K / V cache of local layer i (rows of E elements, f32 or binary16): byte arithmetic, typed as float* for the kernel args
+static inline float* kcache_of(const thk_model* m, const SeqBuf& sb, int i) {
+    const size_t row = (size_t)m->hp.n_ctx * m->hp.n_embd * (m->kv_f16 ? 2 : 4);
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(sb.kv) + (size_t)i * 2 * row);
+}
+static inline float* vcache_of(const thk_model* m, const SeqBuf& sb, int i) {
+    const size_t row = (size_t)m->hp.n_ctx * m->hp.n_embd * (m->kv_f16 ? 2 : 4);
+    return reinterpret_cast<float*>(reinterpret_cast<char*>(sb.kv) + ((size_t)i * 2 + 1) * row);
+}
+
+int set_seq_state(thk_model* m, int seq, int token, int pos, bool reset_gen);   // thk_model.cpp
+bool engine_plan(thk_model* m);                                                 // thk_model_engine.cpp
+int engine_build_program(thk_model* m, SeqBuf& sb);
+int check_engine_error(thk_model* m);
+
 // ---------------------------------------------------------------- helpers (thk_ctx.cpp)
 int fail(thk_ctx* ctx, int code, const char* fmt, ...);
 #define HIPCHK(ctx, call)                                                                                  \
@@ -133,4 +149,5 @@ float synth_scale(float sigma);
 int valid_head_dim(int64_t D);
 int valid_splits(int64_t s);
 void q1_constants(int V, int* split, int* cov);
+int topk_to_host(thk_ctx* ctx, const float* logits_dev, int64_t V, int32_t k, float* values_out, int32_t* ids_out);
 hipError_t attn_prefill_dispatch(thk_ctx* ctx, const float* q, const float* kc, const float* vc, int n_past, int M, int H, int D, float* out, bool kv_f16 = false);

@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "thk_kernels.hpp"
+#include "thk_device.hpp"
 
 namespace thk {
 
@@ -45,52 +46,6 @@ __device__ __forceinline__ void thk_stamp(unsigned long long* tr, int bid, int s
 #else
 #define THK_STAMP(tr, bid, slot) do { } while (0)
 #endif
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-
-// ---------------------------------------------------------------- wave reductions
-// DPP butterfly inside each row of 16 lanes (quad_perm, row_half_mirror,
-// row_mirror), then the four row totals are combined through readlane.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row16_sum(float v) {
-    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);  // row_half_mirror
-    v += dpp_f<0x140>(v);  // row_mirror
-    return v;
-}
-__device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, dpp_f<0xB1>(v));
-    v = fmaxf(v, dpp_f<0x4E>(v));
-    v = fmaxf(v, dpp_f<0x141>(v));
-    v = fmaxf(v, dpp_f<0x140>(v));
-    return v;
-}
-__device__ __forceinline__ float rdlane(float v, int l) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
-// Full-wave sum; result is wave-uniform.
-__device__ __forceinline__ float wave_sum(float v) {
-    v = row16_sum(v);
-    return (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
-}
-__device__ __forceinline__ float wave_max(float v) {
-    v = row16_max(v);
-    return fmaxf(fmaxf(rdlane(v, 0), rdlane(v, 16)), fmaxf(rdlane(v, 32), rdlane(v, 48)));
-}
-// Sum over aligned groups of G lanes (G = 16, 32 or 64); every lane of a group gets its group's sum.
-template <int G>
-__device__ __forceinline__ float group_sum(float v) {
-    v = row16_sum(v);
-    if (G >= 32) v += __shfl_xor(v, 16);
-    if (G >= 64) v += __shfl_xor(v, 32);
-    return v;
-}
 
 template <int WPB = kWaves>
 __device__ __forceinline__ float block_sum(float v, float* red /* >= WPB floats of LDS */) {
@@ -311,20 +266,6 @@ template <bool NT>
 __device__ __forceinline__ h8 ldw(const h8* p) {
     if (NT) return __builtin_nontemporal_load(p);
     return *p;
-}
-
-__device__ __forceinline__ float dot8(h8 w, f4 xl, f4 xh, float acc) {
-    acc = fmaf((float)w[0], xl.x, acc); acc = fmaf((float)w[1], xl.y, acc);
-    acc = fmaf((float)w[2], xl.z, acc); acc = fmaf((float)w[3], xl.w, acc);
-    acc = fmaf((float)w[4], xh.x, acc); acc = fmaf((float)w[5], xh.y, acc);
-    acc = fmaf((float)w[6], xh.z, acc); acc = fmaf((float)w[7], xh.w, acc);
-    return acc;
-}
-
-__device__ __forceinline__ unsigned long long argmax_key(float v, unsigned idx) {
-    unsigned b = __builtin_bit_cast(unsigned, v);
-    b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);          // order-preserving map
-    return ((unsigned long long)b << 32) | (unsigned long long)(0xFFFFFFFFu - idx);   // ties: smaller idx wins
 }
 
 // One launch = one fused op.  Work unit = "row group": NR weight rows streamed
@@ -1071,6 +1012,77 @@ __global__ __launch_bounds__(kBlock) void argmax_kernel(const float* __restrict_
 }
 hipError_t launch_argmax(const float* logits, int V, unsigned long long* block_best, int nblocks, hipStream_t st) {
     hipLaunchKernelGGL(argmax_kernel, dim3(nblocks), dim3(kBlock), 0, st, logits, V, block_best);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- top-k of a logits vector (stochastic sampler, th-llama.cpp:814-907)
+// keys[j] = (order-preserving map of logits[i]) << 32 | ~i  for the k largest, sorted descending: value descending, ties by
+// ascending index - a total order, so the selection and its order are unique.  ONE workgroup of 1024 threads: every thread holds
+// up to kTopkPer keys in registers; the k-th largest key is found by an 8-pass radix select on the 64-bit keys (256-bin LDS
+// histogram of the next byte among the keys that match the prefix so far), the keys >= it are compacted into LDS (exactly k: keys
+// are unique) and sorted with a bitonic network.  V <= 1024 * kTopkPer = 32768, k <= 1024.
+constexpr int kTopkThreads = 1024, kTopkPer = 32, kTopkMax = 1024;     // 32 keys = 64 VGPRs per thread (16 waves per workgroup leave 128)
+__global__ __launch_bounds__(kTopkThreads) void topk_kernel(const float* __restrict__ logits, int V, int k, unsigned long long* __restrict__ keys_out) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long sel[kTopkMax];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned s_need, s_count;
+    const int tid = threadIdx.x;
+    unsigned long long key[kTopkPer];
+#pragma unroll
+    for (int j = 0; j < kTopkPer; ++j) {
+        const int i = tid + j * kTopkThreads;
+        key[j] = i < V ? argmax_key(logits[i], (unsigned)i) : 0ull;      // 0 is below every real key (a real key has ~idx != 0 in its low word or a non-zero value word)
+    }
+    if (tid == 0) { s_prefix = 0ull; s_need = (unsigned)k; s_count = 0u; }
+    __syncthreads();
+    for (int pass = 7; pass >= 0; --pass) {                                  // most significant byte first
+        if (tid < 256) hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        const unsigned long long hi_mask = pass == 7 ? 0ull : (~0ull << ((pass + 1) * 8));
+#pragma unroll
+        for (int j = 0; j < kTopkPer; ++j) {
+            const int i = tid + j * kTopkThreads;
+            if (i < V && (key[j] & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(key[j] >> (pass * 8)) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {                                                      // walk the bins from the top until the k-th largest falls into one
+            unsigned need = s_need, b = 255;
+            for (;; --b) { if (hist[b] >= need || b == 0) break; need -= hist[b]; }
+            s_need = need;
+            s_prefix = prefix | ((unsigned long long)b << (pass * 8));
+        }
+        __syncthreads();
+    }
+    const unsigned long long kth = s_prefix;                                 // the k-th largest key itself
+#pragma unroll
+    for (int j = 0; j < kTopkPer; ++j) {
+        const int i = tid + j * kTopkThreads;
+        if (i < V && key[j] >= kth) { const unsigned at = atomicAdd(&s_count, 1u); if (at < (unsigned)kTopkMax) sel[at] = key[j]; }
+    }
+    __syncthreads();
+    int n = 1;
+    while (n < k) n <<= 1;                                                   // bitonic sort of n >= k slots, descending; empty slots are 0
+    for (int i = tid; i < n; i += kTopkThreads) if (i >= k) sel[i] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= n; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < n; i += kTopkThreads) {
+                const int p = i ^ stride;
+                if (p > i) {
+                    const bool desc = (i & size) == 0;
+                    const unsigned long long a = sel[i], b = sel[p];
+                    if ((a < b) == desc) { sel[i] = b; sel[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = tid; i < k; i += kTopkThreads) keys_out[i] = sel[i];
+}
+hipError_t launch_topk(const float* logits, int V, int k, unsigned long long* keys_out, hipStream_t st) {
+    if (V < 1 || V > kTopkThreads * kTopkPer || k < 1 || k > kTopkMax || k > V) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(kTopkThreads), 0, st, logits, V, k, keys_out);
     return hipGetLastError();
 }
 

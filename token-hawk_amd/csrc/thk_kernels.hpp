@@ -84,6 +84,8 @@ constexpr int kTraceWords = 8 * 4;    // u64 per workgroup: [wave (8)][stamp (4)
 bool trace_compiled();               // true in a -DTHK_TRACE build (libthk_trace.so)
 hipError_t launch_advance_pos(SeqState* st_dev, const int* advance_ptr, int n_ctx, unsigned* epoch, hipStream_t st);
 hipError_t launch_argmax(const float* logits, int V, unsigned long long* block_best, int nblocks, hipStream_t st);
+// the k largest logits as sorted keys ((ordered value << 32) | ~index, descending); V <= 32768, k <= 1024
+hipError_t launch_topk(const float* logits, int V, int k, unsigned long long* keys_out, hipStream_t st);
 hipError_t launch_synth_f16(uint64_t key, float scale, size_t n, void* out, hipStream_t st);
 hipError_t launch_synth_gain(uint64_t key, float scale, size_t n, float* out, hipStream_t st);
 
@@ -125,7 +127,6 @@ struct EngArgs {
     const float* rope_tab; float scale;
     unsigned long long* block_best;               // HEAD: one arg-max key per workgroup
     unsigned long long* trace;                    // development timeline (NULL in production), see thk_engine.hip
-    int park;                                     // kernel variant: consumer waves park one landed slot in registers while they wait
 };
 size_t engine_lds_bytes(int NS, int v0_bytes, int v1_bytes);
 hipError_t launch_engine(const EngArgs& a, int n_cu, hipStream_t st);

@@ -1,6 +1,7 @@
 // thk_model.cpp — the model level of the C-ABI: th_eval_gpu (th-llama.cpp:464-660) as ONE hipGraph replay per decode step
-// (embed, 5 fused kernels per layer, lm-head + greedy pick; reference: 773 dispatches, 129 copies and a blocking map-read
-// per token) or as one persistent engine launch (thk_engine.hip), the MFMA prompt prefill, layer-range pipeline stages.
+// (5 fused kernels per layer, lm-head + greedy pick; reference: 773 dispatches, 129 copies and a blocking map-read per token),
+// layer-range pipeline stages, per-sequence state.  The optional one-launch engine's program builder lives in
+// thk_model_engine.cpp, the MFMA prompt prefill in thk_model_prefill.cpp.
 #include "thk_internal.hpp"
 
 // ---------------------------------------------------------------- model
@@ -103,19 +104,6 @@ extern "C" int thk_model_destroy(thk_model* m) {
     delete m;
     return THK_OK;
 }
-// Development aid: copies the engine timeline of the last step ([n_cu][n_ops][8] u64, see thk_engine.hip) to the host.
-extern "C" int thk_model_engine_trace(thk_model* m, unsigned long long* out, int64_t cap_words, int32_t* n_cu, int32_t* n_ops) {
-    if (!m || !out) return THK_ERR_INVALID;
-    thk_ctx* ctx = m->ctx;
-    REQUIRE(ctx, m->finalized && m->engine && m->eng_trace, "no engine timeline (set the tunable engine_trace=1 before finalize)");
-    const int64_t words = (int64_t)ctx->n_cu * m->seqs[0].eng_n_ops * 8;
-    REQUIRE(ctx, cap_words >= words, "engine timeline needs %lld words", (long long)words);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(out, m->eng_trace, (size_t)words * 8, hipMemcpyDeviceToHost));
-    if (n_cu) *n_cu = ctx->n_cu;
-    if (n_ops) *n_ops = m->seqs[0].eng_n_ops;
-    return THK_OK;
-}
 extern "C" int thk_model_uses_engine(const thk_model* m) { return (m && m->finalized && m->engine) ? 1 : 0; }
 extern "C" int32_t thk_model_n_ff(const thk_model* m) { return m ? m->n_ff : 0; }
 extern "C" int32_t thk_model_n_embd(const thk_model* m) { return m ? m->hp.n_embd : 0; }
@@ -211,16 +199,6 @@ extern "C" int thk_model_set_lmhead_mode(thk_model* m, int mode) {
     return THK_OK;
 }
 
-// K / V cache of local layer i (rows of E elements, f32 or binary16): byte arithmetic, typed as float* for the kernel args
-static inline float* kcache_of(const thk_model* m, const SeqBuf& sb, int i) {
-    const size_t row = (size_t)m->hp.n_ctx * m->hp.n_embd * (m->kv_f16 ? 2 : 4);
-    return reinterpret_cast<float*>(reinterpret_cast<char*>(sb.kv) + (size_t)i * 2 * row);
-}
-static inline float* vcache_of(const thk_model* m, const SeqBuf& sb, int i) {
-    const size_t row = (size_t)m->hp.n_ctx * m->hp.n_embd * (m->kv_f16 ? 2 : 4);
-    return reinterpret_cast<float*>(reinterpret_cast<char*>(sb.kv) + ((size_t)i * 2 + 1) * row);
-}
-
 // ----- one decode step of this stage, enqueued on the ctx stream (eager or under capture)
 struct StepProf {
     std::vector<std::string> names;
@@ -262,7 +240,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         a.ops = sb.eng_ops; a.n_ops = sb.eng_n_ops; a.st = sb.st; a.epoch = m->eng_words; a.err = m->eng_words + 32;
         a.E = E; a.H = H; a.D = D; a.nsplit = m->eng_nsplit; a.tc = m->eng_tc;
         a.NS = m->eng_NS; a.v0_bytes = m->eng_v0; a.v1_bytes = m->eng_v1;
-        a.rope_tab = m->rope_tab; a.scale = 1.0f / sqrtf((float)D); a.block_best = m->block_best; a.trace = m->eng_trace; a.park = (int)tun(ctx, "engine_park");
+        a.rope_tab = m->rope_tab; a.scale = 1.0f / sqrtf((float)D); a.block_best = m->block_best; a.trace = m->eng_trace;
         MARK("engine");
         HIPCHK(ctx, launch_engine(a, ctx->n_cu, st));
         if (m->flags & THK_STAGE_HEAD) {
@@ -360,7 +338,7 @@ __global__ void set_seq_state_kernel(SeqState* st, int token, int pos, int reset
 __global__ void set_seq_token_kernel(SeqState* st, int token) {
     if (threadIdx.x == 0 && blockIdx.x == 0) st->token = token;
 }
-static int set_seq_state(thk_model* m, int seq, int token, int pos, bool reset_gen) {
+int set_seq_state(thk_model* m, int seq, int token, int pos, bool reset_gen) {
     m->seqs[seq].pos_host = pos;
     hipLaunchKernelGGL(set_seq_state_kernel, dim3(1), dim3(64), 0, m->ctx->stream, m->seqs[seq].st, token, pos, reset_gen ? 1 : 0);
     HIPCHK(m->ctx, hipGetLastError());
@@ -378,82 +356,6 @@ static int set_advance(thk_model* m, int seq, int advance) {
 static int run_step(thk_model* m, int seq) {
     if (m->use_graph && m->seqs[seq].exec) { HIPCHK(m->ctx, hipGraphLaunch(m->seqs[seq].exec, m->ctx->stream)); return THK_OK; }
     return enqueue_step(m, seq, nullptr);
-}
-
-// ----- persistent engine (thk_engine.hip): eligibility, LDS plan and the per-sequence op program
-static bool engine_plan(thk_model* m) {
-    thk_ctx* ctx = m->ctx;
-    const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, V = m->hp.n_vocab, T = m->hp.n_ctx;
-    if (tun(ctx, "engine") == 0) return false;
-    if (D != 64 && D != 128) return false;
-    if (E % 512 != 0 || F % 256 != 0 || E > 6144 || (V & 1)) return false;            // row pairs, one-sweep norm gather, whole pieces
-    if ((m->flags & THK_STAGE_HEAD) && m->lm_mode != THK_LMHEAD_CORRECT) return false;  // the Q1-faithful combine stays on the launch path
-    if (m->skip_kernel || m->kv_f16 || H > ctx->n_cu) return false;   // the engine reads the reference's f32 cache
-    int S = 1;
-    while (S * 2 <= kMaxSplit && S * 2 * H <= ctx->n_cu) S *= 2;
-    const int v1 = ((E + 511) / 512) * 2048, v0 = ((std::max(E, F) + 511) / 512) * 2048;
-    const long budget = 160 * 1024 - (long)engine_lds_bytes(0, v0, v1);
-    const int NS = (int)(budget / kEngSlotBytes);
-    if (NS < 3) return false;
-    m->eng_NS = NS > 8 ? 8 : NS; m->eng_v0 = v0; m->eng_v1 = v1; m->eng_nsplit = S; m->eng_tc = (T + S - 1) / S;
-    return true;
-}
-static void eng_unit_geometry(EngOp& o) {       // a unit = two rows of C f16 = 4C bytes = C/256 pieces of 1 KiB
-    o.row_bytes = o.C * 2;
-    const int pieces = o.C / 256;
-    o.fpu = (pieces + 15) / 16;
-    o.pieces_last = pieces - 16 * (o.fpu - 1);
-}
-static int engine_build_program(thk_model* m, SeqBuf& sb) {
-    thk_ctx* ctx = m->ctx;
-    const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, V = m->hp.n_vocab, T = m->hp.n_ctx, S = m->eng_nsplit;
-    const int nl = m->l1 - m->l0;
-    unsigned long long* XG0 = m->eng_gran; unsigned long long* XG1 = XG0 + E; unsigned long long* QG = XG1 + E;
-    unsigned long long* OG = QG + 3 * (size_t)E; unsigned long long* UG = OG + E; unsigned long long* PG = UG + F;
-    (void)H; (void)S; (void)D;
-    const float* xin = (m->flags & THK_STAGE_EMBED) ? m->x : sb.hidden_in;
-    std::vector<EngOp> ops;
-    int prev_w2 = -1;
-    for (int i = 0; i < nl; ++i) {
-        const LayerW& L = m->layers[i];
-        float* kc = kcache_of(m, sb, i);
-        float* vc = vcache_of(m, sb, i);
-        EngOp q{};    // rms_norm*gain -> wq,wk,wv -> RoPE -> K/V append (th-llama.cpp:299-339)
-        q.kind = EOP_QKV; q.n_units = 3 * E / 2; q.C = E; eng_unit_geometry(q);
-        q.W[0] = L.wq; q.W[1] = L.wk; q.W[2] = L.wv; q.gain = L.attention_norm;
-        q.in_src = i == 0 ? EIN_PLAIN : EIN_GRAN; q.in_ptr = i == 0 ? (const void*)xin : (const void*)XG0; q.in_n = E; q.in_tag_op = prev_w2; q.in_dst = 1;
-        q.out_g = QG; q.kcache = kc; q.vcache = vc;
-        const int iq = (int)ops.size(); ops.push_back(q);
-        EngOp at{};   // attention over the cache in place (th-llama.cpp:341-397)
-        at.kind = EOP_ATTN; at.in_tag_op = iq; at.qg = QG; at.pg = PG; at.out_g = OG; at.kcache = kc; at.vcache = vc;
-        const int ia = (int)ops.size(); ops.push_back(at);
-        EngOp o{};    // wo -> + residual (th-llama.cpp:401-413)
-        o.kind = EOP_WO; o.n_units = E / 2; o.C = E; eng_unit_geometry(o); o.W[0] = L.wo;
-        o.in_src = EIN_GRAN; o.in_ptr = OG; o.in_n = E; o.in_tag_op = ia; o.in_dst = 0;
-        o.resid_src = i == 0 ? 2 : 1; o.resid_ptr = i == 0 ? (const void*)xin : (const void*)XG0; o.out_g = XG1;
-        const int io = (int)ops.size(); ops.push_back(o);
-        EngOp g{};    // rms_norm*gain -> w1,w3 -> silu*gate (th-llama.cpp:415-438)
-        g.kind = EOP_W13; g.n_units = F; g.C = E; eng_unit_geometry(g); g.dual = (g.row_bytes % 4096 == 0) ? 1 : 2; g.W[0] = L.w1; g.W[1] = L.w3; g.gain = L.ffn_norm;
-        g.in_src = EIN_GRAN; g.in_ptr = XG1; g.in_n = E; g.in_tag_op = io; g.in_dst = 1; g.out_g = UG;
-        const int ig = (int)ops.size(); ops.push_back(g);
-        EngOp d{};    // w2 -> + residual (th-llama.cpp:440-451)
-        d.kind = EOP_W2; d.n_units = E / 2; d.C = F; eng_unit_geometry(d); d.W[0] = L.w2;
-        d.in_src = EIN_GRAN; d.in_ptr = UG; d.in_n = F; d.in_tag_op = ig; d.in_dst = 0;
-        d.resid_src = 1; d.resid_ptr = XG1; d.out_g = XG0;
-        if (i == nl - 1) d.out_plain = (m->flags & THK_STAGE_HEAD) ? m->x : sb.hidden_out;
-        prev_w2 = (int)ops.size(); ops.push_back(d);
-    }
-    if (m->flags & THK_STAGE_HEAD) {   // final norm -> lm-head -> greedy keys (th-llama.cpp:240-268, :826-838)
-        EngOp h{};
-        h.kind = EOP_HEAD; h.n_units = V / 2; h.C = E; eng_unit_geometry(h); h.W[0] = m->output; h.gain = m->norm;
-        h.in_src = EIN_GRAN; h.in_ptr = XG0; h.in_n = E; h.in_tag_op = prev_w2; h.in_dst = 1; h.out_plain = sb.logits;
-        ops.push_back(h);
-    }
-    REQUIRE(ctx, ops.size() < 511, "engine program of %zu ops does not fit the 9-bit op tag", ops.size());
-    HIPCHK(ctx, hipMalloc((void**)&sb.eng_ops, ops.size() * sizeof(EngOp)));
-    HIPCHK(ctx, hipMemcpy(sb.eng_ops, ops.data(), ops.size() * sizeof(EngOp), hipMemcpyHostToDevice));
-    sb.eng_n_ops = (int)ops.size();
-    return THK_OK;
 }
 
 extern "C" int thk_model_finalize(thk_model* m) {
@@ -544,20 +446,6 @@ extern "C" int thk_model_finalize(thk_model* m) {
     return THK_OK;
 }
 
-// Bounded in-launch waits raise a device-side error word instead of hanging; surface it.
-static int check_engine_error(thk_model* m) {
-    if (m->engine && m->eng_words) {
-        unsigned e = 0;
-        HIPCHK(m->ctx, hipMemcpyAsync(&e, m->eng_words + 32, 4, hipMemcpyDeviceToHost, m->ctx->stream));
-        HIPCHK(m->ctx, hipStreamSynchronize(m->ctx->stream));
-        if (e) {
-            HIPCHK(m->ctx, hipMemsetAsync(m->eng_words + 32, 0, 4, m->ctx->stream));
-            return fail(m->ctx, THK_ERR_STATE, "decode engine: bounded wait timed out (code %u, op %u, workgroup %u)", (e >> 24) & 0x7f, (e >> 12) & 0xfff, e & 0xfff);
-        }
-    }
-    return THK_OK;
-}
-
 extern "C" int thk_model_reset_kv(thk_model* m, int32_t seq) {
     if (!m) return THK_ERR_INVALID;
     thk_ctx* ctx = m->ctx;
@@ -604,12 +492,14 @@ extern "C" int thk_model_seq_set(thk_model* m, int32_t seq, int32_t token, int32
     if (!m) return THK_ERR_INVALID;
     REQUIRE(m->ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
     REQUIRE(m->ctx, pos >= 0 && pos < m->hp.n_ctx && token >= 0 && token < m->hp.n_vocab, "token %d / pos %d out of range", token, pos);
+    HIPCHK(m->ctx, hipSetDevice(m->ctx->device));      // a host worker thread (capi_on_human_message) starts with device 0 current
     return set_seq_state(m, seq, token, pos, true);
 }
 extern "C" int thk_model_seq_set_token(thk_model* m, int32_t seq, int32_t token) {
     if (!m) return THK_ERR_INVALID;
     REQUIRE(m->ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
     REQUIRE(m->ctx, token >= 0 && token < m->hp.n_vocab, "token %d out of range", token);
+    HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
     hipLaunchKernelGGL(set_seq_token_kernel, dim3(1), dim3(64), 0, m->ctx->stream, m->seqs[seq].st, token);
     HIPCHK(m->ctx, hipGetLastError());
     return THK_OK;
@@ -646,6 +536,7 @@ static int ensure_multi_graph(thk_model* m, int seq, int n) {
 extern "C" int thk_model_decode_step(thk_model* m, int32_t seq, int advance) {
     if (!m) return THK_ERR_INVALID;
     REQUIRE(m->ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
+    HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
     int rc = check_room(m, seq, 1, advance);
     if (rc != THK_OK) return rc;
     rc = set_advance(m, seq, advance);
@@ -660,6 +551,7 @@ extern "C" int thk_model_prepare_steps(thk_model* m, int32_t seq, int32_t n_step
     if (!m) return THK_ERR_INVALID;
     REQUIRE(m->ctx, m->finalized && seq >= 0 && seq < m->n_seq && n_steps >= 0, "bad sequence %d / step count %d (or model not finalized)", seq, n_steps);
     if (!m->use_graph) return THK_OK;
+    HIPCHK(m->ctx, hipSetDevice(m->ctx->device));
     if (n_steps >= kMaxGraphSteps) { int rc = ensure_multi_graph(m, seq, kMaxGraphSteps); if (rc != THK_OK) return rc; }
     const int rem = n_steps % kMaxGraphSteps;
     if (rem >= 2) return ensure_multi_graph(m, seq, rem);
@@ -669,6 +561,7 @@ extern "C" int thk_model_decode_steps(thk_model* m, int32_t seq, int32_t n_steps
     if (!m) return THK_ERR_INVALID;
     thk_ctx* ctx = m->ctx;
     REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq && n_steps >= 0, "bad sequence %d / step count %d (or model not finalized)", seq, n_steps);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     int rc = check_room(m, seq, n_steps, advance);
     if (rc != THK_OK) return rc;
     rc = set_advance(m, seq, advance);
@@ -696,6 +589,7 @@ extern "C" int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out,
     if (!m) return THK_ERR_INVALID;
     thk_ctx* ctx = m->ctx;
     REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     SeqState h{};
     HIPCHK(ctx, hipMemcpyAsync(&h, m->seqs[seq].st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -707,6 +601,34 @@ extern "C" int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out,
     }
     if (n_out) *n_out = h.n_gen;
     if (pos_out) *pos_out = h.pos;
+    return check_engine_error(m);
+}
+
+// The logits of the sequence's last evaluated token, without the 4 * n_vocab-byte read-back: the k largest (value descending, ties
+// by ascending id) selected on the device, or the whole vector on request.
+extern "C" int thk_model_logits_topk(thk_model* m, int32_t seq, int32_t k, float* values_out, int32_t* ids_out) {
+    if (!m) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq && (m->flags & THK_STAGE_HEAD), "bad sequence %d, model not finalized, or a stage without the lm-head", seq);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return topk_to_host(ctx, m->seqs[seq].logits, m->hp.n_vocab, k, values_out, ids_out);
+}
+extern "C" int thk_model_read_logits(thk_model* m, int32_t seq, float* logits_out) {
+    if (!m || !logits_out) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq && (m->flags & THK_STAGE_HEAD), "bad sequence %d, model not finalized, or a stage without the lm-head", seq);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(logits_out, m->seqs[seq].logits, (size_t)m->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return THK_OK;
+}
+extern "C" int thk_model_seq_last_token(thk_model* m, int32_t seq, int32_t* token_out) {
+    if (!m || !token_out) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(token_out, &m->seqs[seq].st->token, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return check_engine_error(m);
 }
 
@@ -760,9 +682,27 @@ extern "C" int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long lon
     StepProf p;
     p.names_only = true;
     m->trace_on = true;
-    int rc = enqueue_step(m, seq, &p);
-    m->trace_on = false;
-    if (rc == THK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "sync failed while tracing");
+    int rc = THK_OK;
+    if (m->use_graph) {      // the timeline of a step as it is normally run: a replayed graph (two steps, the SECOND one is recorded)
+        hipGraph_t g = nullptr; hipGraphExec_t x = nullptr;
+        HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        m->trace_on = false;
+        rc = enqueue_step(m, seq, nullptr);
+        m->trace_on = true;
+        if (rc == THK_OK) rc = enqueue_step(m, seq, &p);
+        hipError_t e = hipStreamEndCapture(ctx->stream, &g);
+        m->trace_on = false;
+        if (rc == THK_OK && e != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "hipStreamEndCapture (trace): %s", hipGetErrorString(e));
+        if (rc == THK_OK && hipGraphInstantiate(&x, g, nullptr, nullptr, 0) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "hipGraphInstantiate (trace)");
+        if (rc == THK_OK && hipGraphLaunch(x, ctx->stream) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "hipGraphLaunch (trace)");
+        if (rc == THK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "sync failed while tracing");
+        if (x) hipGraphExecDestroy(x);
+        if (g) hipGraphDestroy(g);
+    } else {
+        rc = enqueue_step(m, seq, &p);
+        m->trace_on = false;
+        if (rc == THK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "sync failed while tracing");
+    }
     for (auto ev : p.events) hipEventDestroy(ev);
     if (rc != THK_OK) return rc;
     const size_t nk = p.names.size();
@@ -773,181 +713,3 @@ extern "C" int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long lon
     return THK_OK;
 }
 
-// Batched prompt prefill (config C3): the M prompt tokens go through the layers together so every
-// weight matrix is streamed ONCE and multiplied on the matrix cores (thk_prefill.hip), instead of
-// M mat-vec passes.  Semantics == feeding the tokens one at a time (the reference's own batch path
-// is disabled, th-llama.cpp:15, and its causal mask is only right at n_past == 0, Q5): causal
-// attention over the f32 cache, K/V rows appended at [n_past, n_past+M), logits of the last token.
-//
-// Per 128-token slab and layer, 11 launches: norm->X image | wq,wk,wv GEMM | reduce + RoPE + KV write | causal
-// attention -> X image | wo GEMM | reduce + residual | norm->X image | w1,w3 GEMM | reduce + SwiGLU -> X image |
-// w2 GEMM | reduce + residual.  (thk_prefill.hip explains the GEMM: LDS-DMA pipeline, stream-K, hi/lo split.)
-// The four GEMM plans of a slab of M tokens (qkv, wo, w13, w2) from the prefill_blocks_* / prefill_tile_* tunables.
-static int slab_plans(thk_model* m, int M, PrefillPlan out[4]) {
-    thk_ctx* ctx = m->ctx;
-    const int E = m->hp.n_embd, F = m->n_ff;
-    static const char* const kind[4] = {"qkv", "wo", "w13", "w2"};
-    const int R[4] = {E, E, F, E}, nmat[4] = {3, 1, 2, 1}, C[4] = {E, E, E, F};
-    for (int k = 0; k < 4; ++k) {
-        const int g = (int)tun(ctx, (std::string("prefill_blocks_") + kind[k]).c_str());
-        const int t = (int)tun(ctx, (std::string("prefill_tile_") + kind[k]).c_str());
-        REQUIRE(ctx, g >= 1 && g <= 256, "prefill_blocks_* tunables must be in [1, 256]");
-        out[k] = prefill_plan(M, R[k], nmat[k], C[k], g, t);
-    }
-    return THK_OK;
-}
-struct PrefillBufs { float *X, *Q, *ATT; int32_t* tok; char *imgE, *imgF; float* part; };
-static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
-static int prefill_workspace(thk_model* m, PrefillBufs* b) {
-    thk_ctx* ctx = m->ctx;
-    const int E = m->hp.n_embd;
-    const size_t per = align256((size_t)128 * E * 4);
-    // sized from the SAME plans prefill_slab builds (the prefill_blocks_* / prefill_tile_* tunables are read per call, and
-    // part_floats = G * maxseg * slot_floats is not monotonic in G, so a fixed G = 256 bound could be exceeded)
-    size_t part_floats = 0, img_e = 0, img_f = 0;
-    for (int M : {128}) {
-        PrefillPlan pl[4];
-        const int rc = slab_plans(m, M, pl);
-        if (rc != THK_OK) return rc;
-        for (int k = 0; k < 4; ++k) part_floats = std::max(part_floats, pl[k].part_floats);
-        img_e = std::max(img_e, std::max(std::max(pl[0].ximg_bytes, pl[1].ximg_bytes), pl[2].ximg_bytes));
-        img_f = std::max(img_f, pl[3].ximg_bytes);
-    }
-    const size_t imgE = align256(img_e), imgF = align256(img_f), part = align256(4 * part_floats);
-    const size_t bytes = 3 * per + 1024 + imgE + imgF + part;
-    if (m->prefill_ws_bytes < bytes) {
-        if (m->prefill_ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(m->prefill_ws)); m->prefill_ws = nullptr; }
-        hipError_t e = hipMalloc(&m->prefill_ws, bytes);
-        if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? THK_ERR_OOM : THK_ERR_HIP, "prefill workspace (%zu bytes): %s", bytes, hipGetErrorString(e));
-        m->prefill_ws_bytes = bytes;
-    }
-    char* p = (char*)m->prefill_ws;
-    b->X = (float*)p; p += per; b->Q = (float*)p; p += per; b->ATT = (float*)p; p += per;
-    b->tok = (int32_t*)p; p += 1024; b->imgE = p; p += imgE; b->imgF = p; p += imgF; b->part = (float*)p;
-    return THK_OK;
-}
-
-// Tile images of this stage's layer matrices (thk_prefill.hip, pack_w_kernel): made on the first prefill call and again when a
-// prefill_tile_* tunable changes.  Costs a second copy of the layer weights in HBM (12.4 GB for 7B of 288); if that does not
-// fit the GEMMs stay on the row-major matrices (still the HIP path, ~20 % slower).
-static int ensure_prefill_pack(thk_model* m) {
-    thk_ctx* ctx = m->ctx;
-    if (tun(ctx, "prefill_packed") == 0 || m->pk_failed) return THK_OK;
-    const int E = m->hp.n_embd, F = m->n_ff, nl = m->l1 - m->l0;
-    int tiles[4];
-    {
-        PrefillPlan pl[4];
-        const int rc = slab_plans(m, 128, pl);           // the tiles a full slab uses
-        if (rc != THK_OK) return rc;
-        for (int k = 0; k < 4; ++k) tiles[k] = pl[k].tile_rows;
-    }
-    if (m->prefill_pk && !m->pk_w.empty() && !memcmp(tiles, m->pk_tiles, sizeof tiles)) return THK_OK;
-    // wq wk wv wo w1 w2 w3: (rows, cols, tile)
-    const int R[7] = {E, E, E, E, F, E, F}, C[7] = {E, E, E, E, E, F, E}, T[7] = {tiles[0], tiles[0], tiles[0], tiles[1], tiles[2], tiles[3], tiles[2]};
-    size_t per_layer = 0, off[7];
-    const size_t kAlign = (size_t)2 << 20;                  // 2 MiB, as the weight slab (a 1 MiB phase costs the decode kernels 2 %)
-    for (int k = 0; k < 7; ++k) { off[k] = per_layer; per_layer += (prefill_pack_bytes(R[k], C[k], T[k]) + kAlign - 1) / kAlign * kAlign; }
-    const size_t bytes = per_layer * nl;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (m->prefill_pk_bytes < bytes) {
-        hipFree(m->prefill_pk); m->prefill_pk = nullptr; m->prefill_pk_bytes = 0;
-        if (hipMalloc(&m->prefill_pk, bytes) != hipSuccess) { (void)hipGetLastError(); m->prefill_pk = nullptr; m->pk_failed = true; m->pk_w.clear(); m->pk_tiles[0] = 0; return THK_OK; }
-        m->prefill_pk_bytes = bytes;
-    }
-    m->pk_w.assign(nl, {});
-    for (int i = 0; i < nl; ++i) {
-        const LayerW& L = m->layers[i];
-        const uint16_t* src[7] = {L.wq, L.wk, L.wv, L.wo, L.w1, L.w2, L.w3};
-        for (int k = 0; k < 7; ++k) {
-            char* dst = (char*)m->prefill_pk + (size_t)i * per_layer + off[k];
-            HIPCHK(ctx, launch_prefill_pack(src[k], R[k], C[k], T[k], dst, ctx->stream));
-            m->pk_w[i][k] = reinterpret_cast<const uint16_t*>(dst);
-        }
-    }
-    memcpy(m->pk_tiles, tiles, sizeof tiles);
-    return THK_OK;
-}
-
-// one slab of M <= 128 prompt tokens at positions [n_past, n_past + M) through every layer
-static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const int32_t* tokens, int M, int n_past) {
-    thk_ctx* ctx = m->ctx;
-    hipStream_t st = ctx->stream;
-    const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, T = m->hp.n_ctx;
-    PrefillPlan pl[4];
-    {
-        const int rc = slab_plans(m, M, pl);
-        if (rc != THK_OK) return rc;
-    }
-    PrefillPlan &pq = pl[0], &po = pl[1], &p13 = pl[2], &p2 = pl[3];
-    const bool pk = !m->pk_w.empty() && m->pk_tiles[0] == pq.tile_rows && m->pk_tiles[1] == po.tile_rows && m->pk_tiles[2] == p13.tile_rows && m->pk_tiles[3] == p2.tile_rows;
-    pq.packed = po.packed = p13.packed = p2.packed = pk ? 1 : 0;
-    HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));   // tokens may be a stack buffer
-    HIPCHK(ctx, launch_embed_rows(m->tok_embeddings, b.tok, M, E, b.X, st));
-    for (int i = 0; i < m->l1 - m->l0; ++i) {
-        const LayerW& L = m->layers[i];
-        float* kc = kcache_of(m, sb, i);
-        float* vc = vcache_of(m, sb, i);
-        const uint16_t* wqkv[3] = {pk ? m->pk_w[i][0] : L.wq, pk ? m->pk_w[i][1] : L.wk, pk ? m->pk_w[i][2] : L.wv};
-        const uint16_t* w13[2] = {pk ? m->pk_w[i][4] : L.w1, pk ? m->pk_w[i][6] : L.w3};
-        const uint16_t* wo = pk ? m->pk_w[i][3] : L.wo;
-        const uint16_t* w2 = pk ? m->pk_w[i][5] : L.w2;
-        HIPCHK(ctx, launch_prefill_ximg(b.X, L.attention_norm, M, E, b.imgE, st));
-        HIPCHK(ctx, launch_prefill_gemm(wqkv, pq, b.imgE, b.part, st));
-        HIPCHK(ctx, launch_prefill_reduce_qkv(b.part, pq, m->rope_tab, n_past, D, b.Q, kc, vc, m->kv_f16 != 0, st));
-        if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) {
-            HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, m->kv_f16 != 0, n_past, M, H, D, nullptr, b.imgE, st));   // writes wo's X image directly
-        } else {
-            HIPCHK(ctx, attn_prefill_dispatch(ctx, b.Q, kc, vc, n_past, M, H, D, b.ATT, m->kv_f16 != 0));
-            HIPCHK(ctx, launch_prefill_ximg(b.ATT, nullptr, M, E, b.imgE, st));
-        }
-        HIPCHK(ctx, launch_prefill_gemm(&wo, po, b.imgE, b.part, st));
-        HIPCHK(ctx, launch_prefill_reduce_store(b.part, po, b.X, true, st));
-        HIPCHK(ctx, launch_prefill_ximg(b.X, L.ffn_norm, M, E, b.imgE, st));
-        HIPCHK(ctx, launch_prefill_gemm(w13, p13, b.imgE, b.part, st));
-        HIPCHK(ctx, launch_prefill_reduce_swiglu(b.part, p13, b.imgF, st));
-        HIPCHK(ctx, launch_prefill_gemm(&w2, p2, b.imgF, b.part, st));
-        HIPCHK(ctx, launch_prefill_reduce_store(b.part, p2, b.X, true, st));
-    }
-    return THK_OK;
-}
-
-extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past, float* logits_out) {
-    if (!m) return THK_ERR_INVALID;
-    thk_ctx* ctx = m->ctx;
-    REQUIRE(ctx, m->finalized, "thk_model_prefill before thk_model_finalize");
-    REQUIRE(ctx, (m->flags & THK_STAGE_EMBED) && (m->flags & THK_STAGE_HEAD), "thk_model_prefill needs a full-model stage (embedding + head)");
-    REQUIRE(ctx, seq >= 0 && seq < m->n_seq && tokens, "bad sequence %d / null tokens", seq);
-    REQUIRE(ctx, n_tokens >= 1 && n_past >= 0 && n_past + n_tokens <= m->hp.n_ctx, "n_past=%d + n_tokens=%d exceeds n_ctx=%d", n_past, n_tokens, m->hp.n_ctx);
-    REQUIRE(ctx, m->hp.n_embd % 32 == 0 && m->n_ff % 32 == 0, "thk_model_prefill needs n_embd and n_ff to be multiples of 32");
-    for (int i = 0; i < n_tokens; ++i) REQUIRE(ctx, tokens[i] >= 0 && tokens[i] < m->hp.n_vocab, "token id %d out of range", tokens[i]);
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    PrefillBufs b{};
-    int rc = prefill_workspace(m, &b);
-    if (rc != THK_OK) return rc;
-    if ((rc = ensure_prefill_pack(m)) != THK_OK) return rc;
-    hipStream_t st = ctx->stream;
-    SeqBuf& sb = m->seqs[seq];
-    const int E = m->hp.n_embd, V = m->hp.n_vocab, M = n_tokens;
-    int last = 0;
-    for (int m0 = 0; m0 < M; m0 += 128) {     // slabs of <= 128 tokens; later slabs attend to the rows earlier ones cached
-        last = std::min(128, M - m0);
-        if ((rc = prefill_slab(m, sb, b, tokens + m0, last, n_past + m0)) != THK_OK) return rc;
-    }
-    {   // final norm + lm-head on the last token only (th-llama.cpp:253-262, aOffset = (r-1)*c)
-        GemvArgs a{};
-        a.W[0] = m->output; a.R = V; a.C = E;
-        const int NR = gemv_rows_per_group(E, GEMV_EPI_HEAD, m->var_head);
-        a.n_groups = (V + NR - 1) / NR;
-        a.x = b.X + (size_t)(last - 1) * E; a.gain = m->norm; a.y = sb.logits;
-        a.lm_faithful = m->lm_mode == THK_LMHEAD_FAITHFUL; q1_constants(V, &a.q1_split, &a.q1_cov);
-        a.block_best = m->block_best;
-        HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, m->nt != 0, st));
-        HIPCHK(ctx, hipMemcpyAsync(m->x, b.X + (size_t)(last - 1) * E, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
-    }
-    rc = set_seq_state(m, seq, tokens[M - 1], n_past + M - 1, false);
-    if (rc != THK_OK) return rc;
-    if (logits_out) HIPCHK(ctx, hipMemcpyAsync(logits_out, sb.logits, (size_t)V * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    return THK_OK;
-}

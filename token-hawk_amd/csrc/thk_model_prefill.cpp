@@ -1,0 +1,181 @@
+// thk_model_prefill.cpp — thk_model_prefill: the batched prompt pass (config C3) on the MFMA GEMM path of thk_prefill.hip.
+#include "thk_internal.hpp"
+
+// Batched prompt prefill (config C3): the M prompt tokens go through the layers together so every
+// weight matrix is streamed ONCE and multiplied on the matrix cores (thk_prefill.hip), instead of
+// M mat-vec passes.  Semantics == feeding the tokens one at a time (the reference's own batch path
+// is disabled, th-llama.cpp:15, and its causal mask is only right at n_past == 0, Q5): causal
+// attention over the f32 cache, K/V rows appended at [n_past, n_past+M), logits of the last token.
+//
+// Per 128-token slab and layer, 11 launches: norm->X image | wq,wk,wv GEMM | reduce + RoPE + KV write | causal
+// attention -> X image | wo GEMM | reduce + residual | norm->X image | w1,w3 GEMM | reduce + SwiGLU -> X image |
+// w2 GEMM | reduce + residual.  (thk_prefill.hip explains the GEMM: LDS-DMA pipeline, stream-K, hi/lo split.)
+// The four GEMM plans of a slab of M tokens (qkv, wo, w13, w2) from the prefill_blocks_* / prefill_tile_* tunables.
+static int slab_plans(thk_model* m, int M, PrefillPlan out[4]) {
+    thk_ctx* ctx = m->ctx;
+    const int E = m->hp.n_embd, F = m->n_ff;
+    static const char* const kind[4] = {"qkv", "wo", "w13", "w2"};
+    const int R[4] = {E, E, F, E}, nmat[4] = {3, 1, 2, 1}, C[4] = {E, E, E, F};
+    for (int k = 0; k < 4; ++k) {
+        const int g = (int)tun(ctx, (std::string("prefill_blocks_") + kind[k]).c_str());
+        const int t = (int)tun(ctx, (std::string("prefill_tile_") + kind[k]).c_str());
+        REQUIRE(ctx, g >= 1 && g <= 256, "prefill_blocks_* tunables must be in [1, 256]");
+        out[k] = prefill_plan(M, R[k], nmat[k], C[k], g, t);
+    }
+    return THK_OK;
+}
+struct PrefillBufs { float *X, *Q, *ATT; int32_t* tok; char *imgE, *imgF; float* part; };
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+static int prefill_workspace(thk_model* m, PrefillBufs* b) {
+    thk_ctx* ctx = m->ctx;
+    const int E = m->hp.n_embd;
+    const size_t per = align256((size_t)128 * E * 4);
+    // sized from the SAME plans prefill_slab builds (the prefill_blocks_* / prefill_tile_* tunables are read per call, and
+    // part_floats = G * maxseg * slot_floats is not monotonic in G, so a fixed G = 256 bound could be exceeded)
+    size_t part_floats = 0, img_e = 0, img_f = 0;
+    for (int M : {128}) {
+        PrefillPlan pl[4];
+        const int rc = slab_plans(m, M, pl);
+        if (rc != THK_OK) return rc;
+        for (int k = 0; k < 4; ++k) part_floats = std::max(part_floats, pl[k].part_floats);
+        img_e = std::max(img_e, std::max(std::max(pl[0].ximg_bytes, pl[1].ximg_bytes), pl[2].ximg_bytes));
+        img_f = std::max(img_f, pl[3].ximg_bytes);
+    }
+    const size_t imgE = align256(img_e), imgF = align256(img_f), part = align256(4 * part_floats);
+    const size_t bytes = 3 * per + 1024 + imgE + imgF + part;
+    if (m->prefill_ws_bytes < bytes) {
+        if (m->prefill_ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(m->prefill_ws)); m->prefill_ws = nullptr; }
+        hipError_t e = hipMalloc(&m->prefill_ws, bytes);
+        if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? THK_ERR_OOM : THK_ERR_HIP, "prefill workspace (%zu bytes): %s", bytes, hipGetErrorString(e));
+        m->prefill_ws_bytes = bytes;
+    }
+    char* p = (char*)m->prefill_ws;
+    b->X = (float*)p; p += per; b->Q = (float*)p; p += per; b->ATT = (float*)p; p += per;
+    b->tok = (int32_t*)p; p += 1024; b->imgE = p; p += imgE; b->imgF = p; p += imgF; b->part = (float*)p;
+    return THK_OK;
+}
+
+// Tile images of this stage's layer matrices (thk_prefill.hip, pack_w_kernel): made on the first prefill call and again when a
+// prefill_tile_* tunable changes.  Costs a second copy of the layer weights in HBM (12.4 GB for 7B of 288); if that does not
+// fit the GEMMs stay on the row-major matrices (still the HIP path, ~20 % slower).
+static int ensure_prefill_pack(thk_model* m) {
+    thk_ctx* ctx = m->ctx;
+    if (tun(ctx, "prefill_packed") == 0 || m->pk_failed) return THK_OK;
+    const int E = m->hp.n_embd, F = m->n_ff, nl = m->l1 - m->l0;
+    int tiles[4];
+    {
+        PrefillPlan pl[4];
+        const int rc = slab_plans(m, 128, pl);           // the tiles a full slab uses
+        if (rc != THK_OK) return rc;
+        for (int k = 0; k < 4; ++k) tiles[k] = pl[k].tile_rows;
+    }
+    if (m->prefill_pk && !m->pk_w.empty() && !memcmp(tiles, m->pk_tiles, sizeof tiles)) return THK_OK;
+    // wq wk wv wo w1 w2 w3: (rows, cols, tile)
+    const int R[7] = {E, E, E, E, F, E, F}, C[7] = {E, E, E, E, E, F, E}, T[7] = {tiles[0], tiles[0], tiles[0], tiles[1], tiles[2], tiles[3], tiles[2]};
+    size_t per_layer = 0, off[7];
+    const size_t kAlign = (size_t)2 << 20;                  // 2 MiB, as the weight slab (a 1 MiB phase costs the decode kernels 2 %)
+    for (int k = 0; k < 7; ++k) { off[k] = per_layer; per_layer += (prefill_pack_bytes(R[k], C[k], T[k]) + kAlign - 1) / kAlign * kAlign; }
+    const size_t bytes = per_layer * nl;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (m->prefill_pk_bytes < bytes) {
+        hipFree(m->prefill_pk); m->prefill_pk = nullptr; m->prefill_pk_bytes = 0;
+        if (hipMalloc(&m->prefill_pk, bytes) != hipSuccess) { (void)hipGetLastError(); m->prefill_pk = nullptr; m->pk_failed = true; m->pk_w.clear(); m->pk_tiles[0] = 0; return THK_OK; }
+        m->prefill_pk_bytes = bytes;
+    }
+    m->pk_w.assign(nl, {});
+    for (int i = 0; i < nl; ++i) {
+        const LayerW& L = m->layers[i];
+        const uint16_t* src[7] = {L.wq, L.wk, L.wv, L.wo, L.w1, L.w2, L.w3};
+        for (int k = 0; k < 7; ++k) {
+            char* dst = (char*)m->prefill_pk + (size_t)i * per_layer + off[k];
+            HIPCHK(ctx, launch_prefill_pack(src[k], R[k], C[k], T[k], dst, ctx->stream));
+            m->pk_w[i][k] = reinterpret_cast<const uint16_t*>(dst);
+        }
+    }
+    memcpy(m->pk_tiles, tiles, sizeof tiles);
+    return THK_OK;
+}
+
+// one slab of M <= 128 prompt tokens at positions [n_past, n_past + M) through every layer
+static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const int32_t* tokens, int M, int n_past) {
+    thk_ctx* ctx = m->ctx;
+    hipStream_t st = ctx->stream;
+    const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, T = m->hp.n_ctx;
+    PrefillPlan pl[4];
+    {
+        const int rc = slab_plans(m, M, pl);
+        if (rc != THK_OK) return rc;
+    }
+    PrefillPlan &pq = pl[0], &po = pl[1], &p13 = pl[2], &p2 = pl[3];
+    const bool pk = !m->pk_w.empty() && m->pk_tiles[0] == pq.tile_rows && m->pk_tiles[1] == po.tile_rows && m->pk_tiles[2] == p13.tile_rows && m->pk_tiles[3] == p2.tile_rows;
+    pq.packed = po.packed = p13.packed = p2.packed = pk ? 1 : 0;
+    HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));   // tokens may be a stack buffer
+    HIPCHK(ctx, launch_embed_rows(m->tok_embeddings, b.tok, M, E, b.X, st));
+    for (int i = 0; i < m->l1 - m->l0; ++i) {
+        const LayerW& L = m->layers[i];
+        float* kc = kcache_of(m, sb, i);
+        float* vc = vcache_of(m, sb, i);
+        const uint16_t* wqkv[3] = {pk ? m->pk_w[i][0] : L.wq, pk ? m->pk_w[i][1] : L.wk, pk ? m->pk_w[i][2] : L.wv};
+        const uint16_t* w13[2] = {pk ? m->pk_w[i][4] : L.w1, pk ? m->pk_w[i][6] : L.w3};
+        const uint16_t* wo = pk ? m->pk_w[i][3] : L.wo;
+        const uint16_t* w2 = pk ? m->pk_w[i][5] : L.w2;
+        HIPCHK(ctx, launch_prefill_ximg(b.X, L.attention_norm, M, E, b.imgE, st));
+        HIPCHK(ctx, launch_prefill_gemm(wqkv, pq, b.imgE, b.part, st));
+        HIPCHK(ctx, launch_prefill_reduce_qkv(b.part, pq, m->rope_tab, n_past, D, b.Q, kc, vc, m->kv_f16 != 0, st));
+        if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) {
+            HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, m->kv_f16 != 0, n_past, M, H, D, nullptr, b.imgE, st));   // writes wo's X image directly
+        } else {
+            HIPCHK(ctx, attn_prefill_dispatch(ctx, b.Q, kc, vc, n_past, M, H, D, b.ATT, m->kv_f16 != 0));
+            HIPCHK(ctx, launch_prefill_ximg(b.ATT, nullptr, M, E, b.imgE, st));
+        }
+        HIPCHK(ctx, launch_prefill_gemm(&wo, po, b.imgE, b.part, st));
+        HIPCHK(ctx, launch_prefill_reduce_store(b.part, po, b.X, true, st));
+        HIPCHK(ctx, launch_prefill_ximg(b.X, L.ffn_norm, M, E, b.imgE, st));
+        HIPCHK(ctx, launch_prefill_gemm(w13, p13, b.imgE, b.part, st));
+        HIPCHK(ctx, launch_prefill_reduce_swiglu(b.part, p13, b.imgF, st));
+        HIPCHK(ctx, launch_prefill_gemm(&w2, p2, b.imgF, b.part, st));
+        HIPCHK(ctx, launch_prefill_reduce_store(b.part, p2, b.X, true, st));
+    }
+    return THK_OK;
+}
+
+extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past, float* logits_out) {
+    if (!m) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized, "thk_model_prefill before thk_model_finalize");
+    REQUIRE(ctx, (m->flags & THK_STAGE_EMBED) && (m->flags & THK_STAGE_HEAD), "thk_model_prefill needs a full-model stage (embedding + head)");
+    REQUIRE(ctx, seq >= 0 && seq < m->n_seq && tokens, "bad sequence %d / null tokens", seq);
+    REQUIRE(ctx, n_tokens >= 1 && n_past >= 0 && n_past + n_tokens <= m->hp.n_ctx, "n_past=%d + n_tokens=%d exceeds n_ctx=%d", n_past, n_tokens, m->hp.n_ctx);
+    REQUIRE(ctx, m->hp.n_embd % 32 == 0 && m->n_ff % 32 == 0, "thk_model_prefill needs n_embd and n_ff to be multiples of 32");
+    for (int i = 0; i < n_tokens; ++i) REQUIRE(ctx, tokens[i] >= 0 && tokens[i] < m->hp.n_vocab, "token id %d out of range", tokens[i]);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PrefillBufs b{};
+    int rc = prefill_workspace(m, &b);
+    if (rc != THK_OK) return rc;
+    if ((rc = ensure_prefill_pack(m)) != THK_OK) return rc;
+    hipStream_t st = ctx->stream;
+    SeqBuf& sb = m->seqs[seq];
+    const int E = m->hp.n_embd, V = m->hp.n_vocab, M = n_tokens;
+    int last = 0;
+    for (int m0 = 0; m0 < M; m0 += 128) {     // slabs of <= 128 tokens; later slabs attend to the rows earlier ones cached
+        last = std::min(128, M - m0);
+        if ((rc = prefill_slab(m, sb, b, tokens + m0, last, n_past + m0)) != THK_OK) return rc;
+    }
+    {   // final norm + lm-head on the last token only (th-llama.cpp:253-262, aOffset = (r-1)*c)
+        GemvArgs a{};
+        a.W[0] = m->output; a.R = V; a.C = E;
+        const int NR = gemv_rows_per_group(E, GEMV_EPI_HEAD, m->var_head);
+        a.n_groups = (V + NR - 1) / NR;
+        a.x = b.X + (size_t)(last - 1) * E; a.gain = m->norm; a.y = sb.logits;
+        a.lm_faithful = m->lm_mode == THK_LMHEAD_FAITHFUL; q1_constants(V, &a.q1_split, &a.q1_cov);
+        a.block_best = m->block_best;
+        HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, m->nt != 0, st));
+        HIPCHK(ctx, hipMemcpyAsync(m->x, b.X + (size_t)(last - 1) * E, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
+    }
+    rc = set_seq_state(m, seq, tokens[M - 1], n_past + M - 1, false);
+    if (rc != THK_OK) return rc;
+    if (logits_out) HIPCHK(ctx, hipMemcpyAsync(logits_out, sb.logits, (size_t)V * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return THK_OK;
+}

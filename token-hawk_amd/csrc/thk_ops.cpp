@@ -149,6 +149,32 @@ extern "C" int thk_argmax(thk_ctx* ctx, const float* logits, int64_t V, int32_t*
     HIPCHK(ctx, launch_finish_token((const unsigned long long*)ctx->scratch, nblocks, nullptr, nullptr, 0, nullptr, id_out, 0, nullptr, ctx->stream));
     return THK_OK;
 }
+// The k largest entries of a device logits vector, value descending, ties by ascending index (a total order).  Selection and sort
+// run on the GPU (launch_topk); k x 8 bytes come back instead of V x 4.  Feeds the host sampler's top-k stage
+// (th-llama.cpp:814-907 partial-sorts all n_vocab candidates on the CPU after a 128 KB read-back).
+int topk_to_host(thk_ctx* ctx, const float* logits_dev, int64_t V, int32_t k, float* values_out, int32_t* ids_out) {
+    REQUIRE(ctx, logits_dev && values_out && ids_out, "top-k: null argument");
+    REQUIRE(ctx, V >= 1 && V <= 32768 && k >= 1 && k <= 1024 && k <= V, "top-k: V=%lld k=%d outside the device kernel's range (V <= 32768, k <= 1024)", (long long)V, k);
+    int rc = ensure_scratch(ctx, 1u << 20);
+    if (rc != THK_OK) return rc;
+    unsigned long long* keys_dev = (unsigned long long*)ctx->scratch;
+    HIPCHK(ctx, launch_topk(logits_dev, (int)V, k, keys_dev, ctx->stream));
+    std::vector<unsigned long long> keys((size_t)k);
+    HIPCHK(ctx, hipMemcpyAsync(keys.data(), keys_dev, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < k; ++i) {
+        const unsigned hi = (unsigned)(keys[i] >> 32), lo = (unsigned)(keys[i] & 0xFFFFFFFFull);
+        const unsigned bits = (hi & 0x80000000u) ? (hi & 0x7FFFFFFFu) : ~hi;     // inverse of argmax_key's order-preserving map
+        memcpy(&values_out[i], &bits, 4);
+        ids_out[i] = (int32_t)(0xFFFFFFFFu - lo);
+    }
+    return THK_OK;
+}
+extern "C" int thk_topk_f32(thk_ctx* ctx, const float* logits, int64_t V, int32_t k, float* values_out, int32_t* ids_out) {
+    if (!ctx) return THK_ERR_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return topk_to_host(ctx, logits, V, k, values_out, ids_out);
+}
 extern "C" int thk_embed_f16(thk_ctx* ctx, const void* table, int64_t E, int32_t token, float* x) {
     if (!ctx) return THK_ERR_INVALID;
     REQUIRE(ctx, table && x && E > 0 && token >= 0, "thk_embed_f16: bad arguments");

@@ -108,6 +108,7 @@ struct LlamaModel {
     // true (default): with greedy sampling (temp <= 0) generation runs in the device-resident loop (thk_model_decode_steps,
     // 4-byte token read-backs in chunks of 8) instead of one blocking 128 KB logits read-back per token; same text.
     bool greedyDeviceLoop = true;
+    bool deviceTopK = true;           // temp > 0: top-k candidates selected on the device instead of reading all n_vocab logits back per token
 
     std::function<void(std::string /*token*/, std::string /*messageSoFar*/)> onNewToken;
     std::function<void(std::string /*fullMessage*/)> onInferenceComplete;
@@ -165,6 +166,10 @@ inline tk_llama_token tk_llama_token_bos() { return 1; }
 inline tk_llama_token tk_llama_token_eos() { return 2; }
 tk_llama_token llama_sample_top_p_top_k(std::mt19937& rng, int n_vocab, const std::vector<tk_llama_token>& last_n_tokens, int top_k,
                                         float top_p, float temp, float repeat_penalty, const std::vector<float>& logits);
+// The same draw from the few largest raw logits (thk_model_logits_topk) instead of all n_vocab; false = take the full path (see thk_llama.cpp)
+int llama_topk_candidates_needed(int n_vocab, const std::vector<tk_llama_token>& last_n_tokens, int top_k, float repeat_penalty);
+bool llama_sample_from_topk(std::mt19937& rng, int n_vocab, const std::vector<tk_llama_token>& last_n_tokens, int top_k, float top_p, float temp,
+                            float repeat_penalty, const float* cand_logits, const int32_t* cand_ids, int n_cand, tk_llama_token* out);
 tk_llama_token llama_sample_top_p_top_k(std::shared_ptr<LlamaModel> m, const std::vector<tk_llama_token>& last_n_tokens, int top_k,
                                         float top_p, float temp, float repeat_penalty, std::vector<float>& logits);
 

@@ -117,6 +117,7 @@ EXPORT const char* capi_last_error() { static std::string copy; std::lock_guard<
 EXPORT void capi_model_unload() { join_worker(); g_model.reset(); }
 EXPORT void capi_set_prompt_prefill(int on) { if (g_model) g_model->prefillPrompt = on != 0; }
 EXPORT void capi_set_greedy_device_loop(int on) { if (g_model) g_model->greedyDeviceLoop = on != 0; }
+EXPORT void capi_set_device_topk(int on) { if (g_model) g_model->deviceTopK = on != 0; }
 EXPORT void capi_set_sampler(int top_k, float top_p, float temp, float repeat_penalty) {
     if (g_model) g_model->sampler = SamplerParams{top_k, top_p, temp, repeat_penalty, false};
 }
@@ -144,6 +145,27 @@ EXPORT void thh_sample(uint32_t seed, const float* logits, int n_vocab, int top_
     std::vector<float> lg(logits, logits + n_vocab);
     std::vector<tk_llama_token> last(last_n, last_n + n_last);
     for (int i = 0; i < n_draws; ++i) out[i] = llama_sample_top_p_top_k(rng, n_vocab, last, top_k, top_p, temp, repeat_penalty, lg);
+}
+// The candidate path of the sampler with the device's part played by the CPU: the K largest raw logits, value descending and ties by
+// ascending id (exactly what thk_topk_f32 returns), feed llama_sample_from_topk; a refusal (tie / too few candidates) takes the full
+// path, as th_eval does.  *n_fast counts the draws that did not need the whole vector.
+EXPORT void thh_sample_topk(uint32_t seed, const float* logits, int n_vocab, int top_k, float top_p, float temp, float repeat_penalty,
+                            const int32_t* last_n, int n_last, int n_draws, int32_t* out, int32_t* n_fast) {
+    std::mt19937 rng(seed);
+    std::vector<float> lg(logits, logits + n_vocab);
+    std::vector<tk_llama_token> last(last_n, last_n + n_last);
+    *n_fast = 0;
+    for (int i = 0; i < n_draws; ++i) {
+        const int K = llama_topk_candidates_needed(n_vocab, last, top_k, repeat_penalty);
+        std::vector<int32_t> order((size_t)n_vocab);
+        for (int j = 0; j < n_vocab; ++j) order[j] = j;
+        std::partial_sort(order.begin(), order.begin() + K, order.end(), [&](int32_t a, int32_t b) { return lg[a] > lg[b] || (lg[a] == lg[b] && a < b); });
+        std::vector<float> cv((size_t)K); std::vector<int32_t> ci(order.begin(), order.begin() + K);
+        for (int j = 0; j < K; ++j) cv[j] = lg[ci[j]];
+        tk_llama_token tok = -1;
+        if (temp > 0 && llama_sample_from_topk(rng, n_vocab, last, top_k, top_p, temp, repeat_penalty, cv.data(), ci.data(), K, &tok)) { out[i] = tok; *n_fast += 1; }
+        else out[i] = llama_sample_top_p_top_k(rng, n_vocab, last, top_k, top_p, temp, repeat_penalty, lg);
+    }
 }
 EXPORT int thh_parse_header(const void* data, int64_t size, int32_t* hp7, int64_t* consumed, int32_t* n_tokens_seen) {
     LlamaModel m; m.onError = [](std::string e) { g_last_error = e; };
@@ -201,6 +223,11 @@ EXPORT int thh_set_prefill(int64_t h, int on) {
 EXPORT int thh_set_greedy_device_loop(int64_t h, int on) {
     auto it = g_handles.find(h); if (it == g_handles.end()) return 0;
     it->second->greedyDeviceLoop = on != 0;
+    return 1;
+}
+EXPORT int thh_set_device_topk(int64_t h, int on) {
+    auto it = g_handles.find(h); if (it == g_handles.end()) return 0;
+    it->second->deviceTopK = on != 0;
     return 1;
 }
 // TensorBuffer (th.hpp:83-148) on a real device: allocate + upload through the constructor, move-construct and move-assign

@@ -120,15 +120,32 @@ tk_llama_token th_eval(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, const tk_lla
     if (!m || !m->dev) return -1;
     m->logits.resize((size_t)m->n_vocab);
     std::vector<int32_t> ids(tokens, tokens + n_tokens);
+    static const std::vector<tk_llama_token> none;
+    const SamplerParams& sp = m->sampler;
+    const std::vector<tk_llama_token>& last = sp.use_last_n_tokens ? m->last_n_tokens : none;
+    // Stochastic sampling without the 4 * n_vocab-byte read-back (the reference maps all logits after every token,
+    // th-llama.cpp:686-724): the device selects the few raw logits that can reach the sampler's top_k (thk_model_logits_topk) and
+    // the unchanged softmax / top-p / discrete_distribution runs on those.  Ties that would make the result depend on
+    // std::partial_sort's internals fall back to the full vector, so the draws are the reference's in every case.
+    if (m->deviceTopK && sp.temp > 0 && sp.top_k > 0 && sp.top_k < m->n_vocab && m->n_vocab <= 32768) {
+        const int K = llama_topk_candidates_needed(m->n_vocab, last, sp.top_k, sp.repeat_penalty);
+        if (K <= 1024) {
+            int rc = thk_model_eval(m->dev, 0, ids.data(), n_tokens, n_past, nullptr, nullptr);
+            std::vector<float> cv((size_t)K); std::vector<int32_t> ci((size_t)K);
+            if (rc == THK_OK) rc = thk_model_logits_topk(m->dev, 0, K, cv.data(), ci.data());
+            tk_llama_token tok = -1;
+            if (rc == THK_OK && llama_sample_from_topk(m->rng, m->n_vocab, last, sp.top_k, sp.top_p, sp.temp, sp.repeat_penalty, cv.data(), ci.data(), K, &tok)) return tok;
+            if (rc == THK_OK) rc = thk_model_read_logits(m->dev, 0, m->logits.data());
+            if (rc != THK_OK) { report_error(*m, std::string("th_eval failed: ") + thk_last_error(m->ctx)); return -1; }
+            return llama_sample_top_p_top_k(m->rng, m->n_vocab, last, sp.top_k, sp.top_p, sp.temp, sp.repeat_penalty, m->logits);
+        }
+    }
     const int rc = thk_model_eval(m->dev, 0, ids.data(), n_tokens, n_past, nullptr, m->logits.data());
     if (rc != THK_OK) {
         report_error(*m, std::string("th_eval failed: ") + thk_last_error(m->ctx));
         return -1;                                  // callers stop on a negative token (the reference returns 0 and carries on)
     }
-    static const std::vector<tk_llama_token> none;
-    const SamplerParams& sp = m->sampler;
-    return llama_sample_top_p_top_k(m->rng, m->n_vocab, sp.use_last_n_tokens ? m->last_n_tokens : none, sp.top_k, sp.top_p, sp.temp,
-                                    sp.repeat_penalty, m->logits);
+    return llama_sample_top_p_top_k(m->rng, m->n_vocab, last, sp.top_k, sp.top_p, sp.temp, sp.repeat_penalty, m->logits);
 }
 
 // Greedy generation without a per-token host round trip: the reference drains the GPU and maps 128 KB
@@ -136,19 +153,22 @@ tk_llama_token th_eval(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, const tk_lla
 // tokens are evaluated without any read-back, then the device-resident loop (greedy pick on the GPU, graph replays) runs in
 // chunks and only the 4-byte token ids come back; onNewToken fires per token exactly as in the eval path.
 static bool greedy_device_loop(std::shared_ptr<LlamaModel> m, int n_ctx, int64_t step) {
-    const int n_prompt_left = (int)m->embd_inp.size() - m->n_consumed;
+    int n_prompt_left = (int)m->embd_inp.size() - m->n_consumed;
     tk_llama_token cur;
     if (n_prompt_left > 0) {
-        std::vector<int32_t> ids(m->embd_inp.begin() + m->n_consumed, m->embd_inp.end());
-        if (m->n_past + n_prompt_left > n_ctx) return true;            // would not fit: nothing to generate (as the loop's n_past < n_ctx guard)
+        // as the token loop (its n_past < n_ctx guard): a prompt longer than the context is consumed up to n_ctx, then nothing is generated
+        const bool fits = m->n_past + n_prompt_left <= n_ctx;
+        if (!fits) n_prompt_left = std::max(0, n_ctx - m->n_past);
+        if (n_prompt_left == 0) return true;
+        std::vector<int32_t> ids(m->embd_inp.begin() + m->n_consumed, m->embd_inp.begin() + m->n_consumed + n_prompt_left);
         for (int32_t id : ids) { m->last_n_tokens.erase(m->last_n_tokens.begin()); m->last_n_tokens.push_back(id); }
         if (thk_model_seq_set(m->dev, 0, ids[0], m->n_past) != THK_OK) return false;       // clears the device token log
         if (thk_model_eval(m->dev, 0, ids.data(), n_prompt_left, m->n_past, nullptr, nullptr) != THK_OK) return false;
-        int32_t n_log = 0, pos = 0;
-        std::vector<int32_t> log((size_t)n_prompt_left);
-        if (thk_model_seq_get(m->dev, 0, log.data(), n_prompt_left, &n_log, &pos) != THK_OK || n_log != n_prompt_left) return false;
-        cur = log[(size_t)n_prompt_left - 1];                          // greedy continuation of the last prompt token
+        int32_t last = -1;                                             // greedy continuation of the last prompt token, read directly:
+        if (thk_model_seq_last_token(m->dev, 0, &last) != THK_OK || last < 0) return false;   // the device log only holds the first 4096 picks
+        cur = last;
         m->n_consumed += n_prompt_left; m->n_past += n_prompt_left; step += n_prompt_left;
+        if (!fits) return true;
     } else {
         cur = m->lastGeneratedToken;                                   // the prompt went through thk_model_prefill; its pick is already emitted
         step += 0;
@@ -269,6 +289,28 @@ void do_inference(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, std::string promp
 }
 
 // ------------------------------------------------------------------ sampler (th-llama.cpp:802-907)
+// softmax over the (already top-k'd, value-descending) candidates, nucleus cut, one discrete_distribution draw (th-llama.cpp:858-907)
+static tk_llama_token sample_from_candidates(std::mt19937& rng, std::vector<std::pair<float, tk_llama_token>>& cand, float top_p) {
+    float maxl = -std::numeric_limits<float>::infinity();
+    for (auto& kv : cand) maxl = std::max(maxl, kv.first);
+    std::vector<float> probs;
+    probs.reserve(cand.size());
+    double sum = 0.0;
+    for (auto& kv : cand) { const float p = expf(kv.first - maxl); probs.push_back(p); sum += p; }
+    for (auto& p : probs) p /= sum;
+    if (top_p < 1.0) {
+        double cum = 0.0;
+        for (int i = 0; i < (int)probs.size(); ++i) {
+            cum += probs[i];
+            if (cum >= top_p) { probs.resize(i + 1); cand.resize(i + 1); break; }
+        }
+        cum = 1.0 / cum;
+        for (auto& p : probs) p *= cum;
+    }
+    std::discrete_distribution<> dist(probs.begin(), probs.end());
+    return cand[dist(rng)].second;
+}
+
 tk_llama_token llama_sample_top_p_top_k(std::mt19937& rng, int n_vocab, const std::vector<tk_llama_token>& last_n_tokens, int top_k,
                                         float top_p, float temp, float repeat_penalty, const std::vector<float>& logits) {
     const float* pl = logits.data() + logits.size() - n_vocab;
@@ -291,24 +333,47 @@ tk_llama_token llama_sample_top_p_top_k(std::mt19937& rng, int n_vocab, const st
                           [](const std::pair<float, tk_llama_token>& a, const std::pair<float, tk_llama_token>& b) { return a.first > b.first; });
         cand.resize(top_k);
     }
-    float maxl = -std::numeric_limits<float>::infinity();
-    for (auto& kv : cand) maxl = std::max(maxl, kv.first);
-    std::vector<float> probs;
-    probs.reserve(cand.size());
-    double sum = 0.0;
-    for (auto& kv : cand) { const float p = expf(kv.first - maxl); probs.push_back(p); sum += p; }
-    for (auto& p : probs) p /= sum;
-    if (top_p < 1.0) {
-        double cum = 0.0;
-        for (int i = 0; i < (int)probs.size(); ++i) {
-            cum += probs[i];
-            if (cum >= top_p) { probs.resize(i + 1); cand.resize(i + 1); break; }
-        }
-        cum = 1.0 / cum;
-        for (auto& p : probs) p *= cum;
+    return sample_from_candidates(rng, cand, top_p);
+}
+
+// Raw-logit candidates the device must supply so that the top_k of the PENALISED, temperature-scaled values is among them: the
+// penalty only ever lowers a value (l * s / p for l >= 0, l * s * p for l < 0, p >= 1), so an entry outside the top (top_k + P + 1)
+// raw logits - P = distinct penalised ids - has at least top_k + 1 unpenalised entries strictly above it and cannot be one of the
+// top_k + 1 scaled values.  (The + 1 lets the caller see whether the top_k boundary is a tie.)
+int llama_topk_candidates_needed(int n_vocab, const std::vector<tk_llama_token>& last_n_tokens, int top_k, float repeat_penalty) {
+    if (top_k <= 0 || top_k >= n_vocab || repeat_penalty < 1.0f) return n_vocab;
+    std::vector<tk_llama_token> pen;
+    for (tk_llama_token t : last_n_tokens) if (t >= 0 && t < n_vocab) pen.push_back(t);
+    std::sort(pen.begin(), pen.end());
+    const int P = (int)(std::unique(pen.begin(), pen.end()) - pen.begin());
+    return std::min(n_vocab, top_k + P + 1);
+}
+
+// The same draw as llama_sample_top_p_top_k from the n_cand LARGEST raw logits (value descending, ties by ascending id: what
+// thk_model_logits_topk returns) instead of all n_vocab.  Returns false WITHOUT touching the generator when the result could
+// depend on how std::partial_sort orders equal values (a tie among the first top_k + 1 scaled values) or when too few candidates
+// were supplied: the caller then reads the whole vector back and takes the reference path, so every draw is the reference's.
+bool llama_sample_from_topk(std::mt19937& rng, int n_vocab, const std::vector<tk_llama_token>& last_n_tokens, int top_k, float top_p, float temp,
+                            float repeat_penalty, const float* cand_logits, const int32_t* cand_ids, int n_cand, tk_llama_token* out) {
+    if (temp <= 0 || top_k <= 0 || top_k >= n_vocab) return false;
+    if (n_cand < llama_topk_candidates_needed(n_vocab, last_n_tokens, top_k, repeat_penalty)) return false;
+    std::vector<std::pair<float, tk_llama_token>> cand;
+    cand.reserve(n_cand);
+    const float scale = 1.0f / temp;
+    for (int j = 0; j < n_cand; ++j) {
+        const float l = cand_logits[j];
+        const tk_llama_token i = cand_ids[j];
+        float v = l * scale;
+        if (std::find(last_n_tokens.begin(), last_n_tokens.end(), i) != last_n_tokens.end())
+            v = l < 0.0f ? l * scale * repeat_penalty : l * scale / repeat_penalty;
+        cand.emplace_back(v, i);
     }
-    std::discrete_distribution<> dist(probs.begin(), probs.end());
-    return cand[dist(rng)].second;
+    std::stable_sort(cand.begin(), cand.end(), [](const std::pair<float, tk_llama_token>& a, const std::pair<float, tk_llama_token>& b) { return a.first > b.first; });
+    for (int j = 0; j < top_k && j + 1 < (int)cand.size(); ++j)
+        if (cand[j].first == cand[j + 1].first) return false;          // partial_sort's order of equal values is its own business: take the reference path
+    cand.resize(top_k);
+    *out = sample_from_candidates(rng, cand, top_p);
+    return true;
 }
 tk_llama_token llama_sample_top_p_top_k(std::shared_ptr<LlamaModel> m, const std::vector<tk_llama_token>& last_n_tokens, int top_k,
                                         float top_p, float temp, float repeat_penalty, std::vector<float>& logits) {

@@ -36,8 +36,7 @@ shape = {"7b": thk.LLAMA_7B, "13b": thk.LLAMA_13B, "tiny": thk.TINY}[name]
 T = shape.n_ctx
 TICK_US = 0.01
 with thk.Context(0) as ctx:
-    ctx.set_tunable("use_graph", 0)
-    for k, v in tun.items():
+    for k, v in tun.items():               # use_graph=0 records eager launches; the default records a replayed graph
         ctx.set_tunable(k, v)
     m = thk.Model(ctx, shape)
     m.fill_synthetic()
