@@ -210,6 +210,13 @@ int thk_model_eval(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_t
  * weight tile images (tunable prefill_packed) and the workspace; later calls reuse them. */
 int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past,
                       float* logits_out);
+/* The prefill GEMMs stream "tile images" of the layer matrices: a second copy of this stage's layer weights in HBM (12.4 GB for
+ * 7B), built by the first thk_model_prefill call unless this call built it earlier - so that the time and the memory are paid
+ * when the embedder chooses.  Returns THK_ERR_OOM (thk_last_error explains) when the copy does not fit; prefill then still works
+ * on the row-major matrices, ~20 % slower.  A weight write or a prefill_tile_* change makes the next call (or prefill) rebuild. */
+int thk_model_prepare_prefill(thk_model* m);
+/* 1 when the next thk_model_prefill will stream tile images, 0 when it will stream the row-major matrices. */
+int thk_model_prefill_uses_tile_images(const thk_model* m);
 
 /* Stream-ordered decode loop (no host round trip per token; what bench.py times).
  * Device-resident per-sequence state: position, current token, generated-token log. */
@@ -248,6 +255,10 @@ int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out, int32_t ca
 /* Logits of the sequence's last evaluated token (head stages): the k largest via thk_topk_f32's kernel, or all n_vocab of them. */
 int thk_model_logits_topk(thk_model* m, int32_t seq, int32_t k, float* values_out, int32_t* ids_out);
 int thk_model_read_logits(thk_model* m, int32_t seq, float* logits_out);
+/* Device-side step clock (head stages): clock_out[i] = the chip-wide 100 MHz counter (s_memrealtime) at the end of the step that
+ * logged token i of thk_model_seq_get.  Differences are per-step durations taken on the GPU, inside replayed multi-step graphs,
+ * with nothing added to the stream.  No reference counterpart (the reference times whole passes on the host, th-llama.cpp:640-655). */
+int thk_model_seq_clock(thk_model* m, int32_t seq, unsigned long long* clock_out, int32_t cap, int32_t* n_out);
 /* The sequence's current token: the greedy pick of its last step (or what thk_model_seq_set / _set_token put there).  One
  * 4-byte read-back after a stream sync; unlike the log of thk_model_seq_get it does not depend on how many steps ran. */
 int thk_model_seq_last_token(thk_model* m, int32_t seq, int32_t* token_out);

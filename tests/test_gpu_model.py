@@ -137,6 +137,22 @@ def test_multi_step_graph_matches_single_steps(thk, orc, ctx):
     a.close(); b.close()
 
 
+def test_device_step_clock(thk, ctx):
+    """thk_model_seq_clock: one stamp of the chip-wide 100 MHz counter per logged step, strictly increasing, also inside
+    replayed multi-step graphs; seq_set clears it together with the token log."""
+    m = thk.Model(ctx, thk.TINY); m.fill_synthetic(); m.finalize()
+    m.seq_set(0, 1, 0)
+    m.decode_steps(40, 0, advance=True)
+    gen, n, pos = m.seq_get(0)
+    clk = m.seq_clock(0).astype(np.int64)
+    assert n == 40 and clk.size == 40 and (np.diff(clk) > 0).all()
+    assert 0 < np.diff(clk).mean() * 1e-2 < 5000            # a tiny-model step takes microseconds, not seconds (10 ns ticks)
+    m.seq_set(0, 1, 0)
+    m.decode_step(0, advance=True)
+    assert m.seq_clock(0).size == 1
+    m.close()
+
+
 def test_hold_position_protocol(thk, orc, ctx):
     """advance=0 re-evaluates the same cache slot (fixed-T benchmark protocol): idempotent logits."""
     m, om = make_pair(thk, orc, ctx, "TINY")
@@ -409,7 +425,16 @@ def test_prefill_tile_images_follow_weight_updates(thk, ctx):
     shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=256)
     toks = np.concatenate([[1], np.random.default_rng(5).integers(3, 2048, 127)]).astype(np.int32)
     m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
-    before = m.prefill(toks, 0).copy()                              # builds the images
+    assert not m.prefill_uses_tile_images()
+    m.prepare_prefill()                                             # explicit: the images (and the workspace) are paid for here ...
+    assert m.prefill_uses_tile_images()
+    before = m.prefill(toks, 0).copy()                              # ... not inside the first prefill call
+    ctx.set_tunable("prefill_packed", 0)
+    try:
+        m.reset_kv(0)
+        assert np.array_equal(m.prefill(toks, 0).view(np.uint32), before.view(np.uint32))     # row-major path: same bits
+    finally:
+        ctx.set_tunable("prefill_packed", 1)
     w = (np.random.default_rng(6).standard_normal((512, 512)) * 0.02).astype(np.float16)
     m.set_tensor("layers.1.attention.wo.weight", w.view(np.uint16))
     m.reset_kv(0)

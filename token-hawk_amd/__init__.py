@@ -311,6 +311,13 @@ class Model:
         self.ctx.check(self.ctx.lib.thk_model_read_logits(self.h, seq, out.ctypes.data), "thk_model_read_logits")
         return out
 
+    def prepare_prefill(self):
+        """Build the prefill workspace and the tile images of the layer matrices now (otherwise the first prefill() does)."""
+        self.ctx.check(self.ctx.lib.thk_model_prepare_prefill(self.h), "thk_model_prepare_prefill")
+
+    def prefill_uses_tile_images(self) -> bool:
+        return bool(self.ctx.lib.thk_model_prefill_uses_tile_images(self.h))
+
     def seq_set(self, seq: int, token: int, pos: int):
         self.ctx.check(self.ctx.lib.thk_model_seq_set(self.h, seq, token, pos), "thk_model_seq_set")
 
@@ -353,6 +360,13 @@ class Model:
         n, pos = C.c_int32(), C.c_int32()
         self.ctx.check(self.ctx.lib.thk_model_seq_get(self.h, seq, out.ctypes.data, cap, C.byref(n), C.byref(pos)), "thk_model_seq_get")
         return out[:min(n.value, cap)].copy(), n.value, pos.value
+
+    def seq_clock(self, seq: int = 0, cap: int = 4096):
+        """uint64 array: the 100 MHz device counter at the end of each logged step (see thk_model_seq_clock)."""
+        out = np.zeros(cap, np.uint64)
+        n = C.c_int32()
+        self.ctx.check(self.ctx.lib.thk_model_seq_clock(self.h, seq, out.ctypes.data, cap, C.byref(n)), "thk_model_seq_clock")
+        return out[:n.value].copy()
 
     def hidden_in_ptr(self, seq: int = 0) -> int:
         return int(self.ctx.lib.thk_model_hidden_in(self.h, seq) or 0)

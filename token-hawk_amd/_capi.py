@@ -72,6 +72,8 @@ SIGNATURES = {
     "thk_model_set_lmhead_mode": (C.c_int, [vp, C.c_int]),
     "thk_model_eval": (C.c_int, [vp, i32, vp, i32, i32, vp, vp]),
     "thk_model_prefill": (C.c_int, [vp, i32, vp, i32, i32, vp]),
+    "thk_model_prepare_prefill": (C.c_int, [vp]),
+    "thk_model_prefill_uses_tile_images": (C.c_int, [vp]),
     "thk_model_seq_set": (C.c_int, [vp, i32, i32, i32]),
     "thk_model_seq_set_token": (C.c_int, [vp, i32, i32]),
     "thk_model_decode_step": (C.c_int, [vp, i32, C.c_int]),
@@ -85,6 +87,7 @@ SIGNATURES = {
     "thk_model_logits_dev": (vp, [vp, i32]),
     "thk_model_seq_get": (C.c_int, [vp, i32, vp, i32, C.POINTER(i32), C.POINTER(i32)]),
     "thk_model_seq_last_token": (C.c_int, [vp, i32, C.POINTER(i32)]),
+    "thk_model_seq_clock": (C.c_int, [vp, i32, vp, i32, C.POINTER(i32)]),
     "thk_model_logits_topk": (C.c_int, [vp, i32, i32, vp, vp]),
     "thk_model_read_logits": (C.c_int, [vp, i32, vp]),
     "thk_model_bytes_per_token": (i64, [vp, i32]),

@@ -51,6 +51,7 @@ struct SeqBuf {
     float* kv = nullptr;             // [n_local_layers][2][n_ctx*E] f32 (or binary16 when the model was finalized with kv_f16)
     SeqState* st = nullptr;          // device
     int32_t* gen_log = nullptr;      // device, kGenLogCap
+    unsigned long long* clock_log = nullptr;   // device, kGenLogCap: s_memrealtime (100 MHz) at the end of the step that logged gen_log[i]
     float* hidden_in = nullptr;      // device f32[E]
     float* hidden_out = nullptr;     // device f32[E]
     float* logits = nullptr;         // device f32[V] (head stage)

@@ -954,7 +954,7 @@ hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token
 __global__ __launch_bounds__(kBlock) void finish_token_kernel(const unsigned long long* __restrict__ block_best, int nblocks,
                                                               SeqState* st, int32_t* gen_log, int log_cap,
                                                               const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch,
-                                                              unsigned long long* trace) {
+                                                              unsigned long long* trace, unsigned long long* clock_log) {
     __shared__ unsigned long long sm[kBlock];
     THK_STAMP(trace, 0, 0);
     unsigned long long b = 0ull;
@@ -970,7 +970,10 @@ __global__ __launch_bounds__(kBlock) void finish_token_kernel(const unsigned lon
         if (id_out) *id_out = tok;
         if (st) {
             st->token = tok;
-            if (gen_log && st->n_gen < log_cap) gen_log[st->n_gen] = tok;
+            if (gen_log && st->n_gen < log_cap) {
+                gen_log[st->n_gen] = tok;
+                if (clock_log) clock_log[st->n_gen] = __builtin_amdgcn_s_memrealtime();   // 100 MHz chip-wide counter: when this step finished
+            }
             st->n_gen += 1;
             if (advance_ptr && *advance_ptr && (n_ctx <= 0 || st->pos + 1 < n_ctx)) st->pos += 1;
         }
@@ -979,8 +982,9 @@ __global__ __launch_bounds__(kBlock) void finish_token_kernel(const unsigned lon
     THK_STAMP(trace, 0, 3);
 }
 hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
-                               const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st, unsigned long long* trace) {
-    hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(kBlock), 0, st, block_best, nblocks, st_dev, gen_log, log_cap, advance_ptr, id_out, n_ctx, epoch, trace);
+                               const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st, unsigned long long* trace,
+                               unsigned long long* clock_log) {
+    hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(kBlock), 0, st, block_best, nblocks, st_dev, gen_log, log_cap, advance_ptr, id_out, n_ctx, epoch, trace, clock_log);
     return hipGetLastError();
 }
 // Non-head stages only advance the position (same clamp, same epoch bump).

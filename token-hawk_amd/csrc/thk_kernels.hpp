@@ -78,7 +78,8 @@ hipError_t launch_kv_append(float* kc, float* vc, const float* k, const float* v
 hipError_t launch_embed_rows(const uint16_t* table, const int32_t* tokens_dev, int n, int E, float* x, hipStream_t st);
 hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token_val, int E, float* x, hipStream_t st, unsigned long long* trace = nullptr);
 hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
-                               const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st, unsigned long long* trace = nullptr);
+                               const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st, unsigned long long* trace = nullptr,
+                               unsigned long long* clock_log = nullptr);   // clock_log[i] = s_memrealtime (100 MHz) when the step that logged token i finished
 constexpr int kTraceBlocks = 2048;   // workgroups recorded per launch of the development timeline
 constexpr int kTraceWords = 8 * 4;    // u64 per workgroup: [wave (8)][stamp (4)]
 bool trace_compiled();               // true in a -DTHK_TRACE build (libthk_trace.so)

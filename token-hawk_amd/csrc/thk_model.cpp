@@ -140,7 +140,7 @@ extern "C" int thk_model_set_tensor(thk_model* m, const char* name, int dtype, i
     REQUIRE(ctx, t == dtype, "tensor '%s': dtype %d expected %d (only GGML f16 models are supported, README.md:5)", name, dtype, t);
     if (rc == 1) return THK_OK;   // another stage owns it
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    m->pk_tiles[0] = 0; m->pk_w.clear();   // the prefill tile images are stale now
+    m->pk_tiles[0] = 0; m->pk_w.clear(); m->pk_failed = false;   // the prefill tile images are stale now (and worth another try if they did not fit)
     HIPCHK(ctx, hipMemcpyAsync(dst, host, (size_t)(c * r) * (t == THK_F16 ? 2 : 4), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return THK_OK;
@@ -158,7 +158,7 @@ extern "C" int thk_model_set_tensor_dev(thk_model* m, const char* name, int dtyp
     REQUIRE(ctx, t == dtype, "tensor '%s': dtype %d expected %d (only GGML f16 models are supported, README.md:5)", name, dtype, t);
     if (rc == 1) return THK_OK;   // another stage owns it
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    m->pk_tiles[0] = 0; m->pk_w.clear();
+    m->pk_tiles[0] = 0; m->pk_w.clear(); m->pk_failed = false;
     HIPCHK(ctx, hipMemcpyAsync(dst, dev_ptr, (size_t)(c * r) * (t == THK_F16 ? 2 : 4), hipMemcpyDeviceToDevice, ctx->stream));
     return THK_OK;
 }
@@ -169,7 +169,7 @@ extern "C" int thk_model_fill_synthetic(thk_model* m, uint64_t seed, float sigma
     const float sc = synth_scale(sigma);
     hipStream_t st = ctx->stream;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    m->pk_tiles[0] = 0; m->pk_w.clear();
+    m->pk_tiles[0] = 0; m->pk_w.clear(); m->pk_failed = false;
     if (m->tok_embeddings) HIPCHK(ctx, launch_synth_f16(synth_key("tok_embeddings.weight", seed), sc, V * E, m->tok_embeddings, st));
     if (m->norm) HIPCHK(ctx, launch_synth_gain(synth_key("norm.weight", seed), sc, E, m->norm, st));
     if (m->output) HIPCHK(ctx, launch_synth_f16(synth_key("output.weight", seed), sc, V * E, m->output, st));
@@ -245,7 +245,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         HIPCHK(ctx, launch_engine(a, ctx->n_cu, st));
         if (m->flags & THK_STAGE_HEAD) {
             MARK("finish_token");
-            HIPCHK(ctx, launch_finish_token(m->block_best, ctx->n_cu, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, T, m->eng_words, st));
+            HIPCHK(ctx, launch_finish_token(m->block_best, ctx->n_cu, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, T, m->eng_words, st, nullptr, sb.clock_log));
         } else {
             MARK("advance_pos");
             HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, T, m->eng_words, st));
@@ -322,7 +322,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         MARK("norm_lmhead");
         if (m->skip_kernel != 6) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, nt, st));
         MARK("finish_token");
-        if (m->skip_kernel != 6) HIPCHK(ctx, launch_finish_token(m->block_best, m->grid_head, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, T, nullptr, st, trace_slab()));
+        if (m->skip_kernel != 6) HIPCHK(ctx, launch_finish_token(m->block_best, m->grid_head, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, T, nullptr, st, trace_slab(), sb.clock_log));
         else HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, T, nullptr, st));       // no arg-max keys were written: keep the token
     } else {
         MARK("advance_pos");
@@ -406,7 +406,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->seqs.resize(m->n_seq);
     for (auto& s : m->seqs) {
         ALLOCZ_OWN(s.kv, (size_t)nl * 2 * T * E * (m->kv_f16 ? 2 : 4));
-        ALLOCZ(s.st, sizeof(SeqState)); ALLOCZ(s.gen_log, (size_t)kGenLogCap * 4);
+        ALLOCZ(s.st, sizeof(SeqState)); ALLOCZ(s.gen_log, (size_t)kGenLogCap * 4); ALLOCZ(s.clock_log, (size_t)kGenLogCap * 8);
         ALLOCZ(s.hidden_in, E * 4); ALLOCZ(s.hidden_out, E * 4); ALLOCZ(s.advance, 4);
         if (m->flags & THK_STAGE_HEAD) ALLOCZ(s.logits, V * 4);
         s.advance_host = 0;
@@ -620,6 +620,26 @@ extern "C" int thk_model_read_logits(thk_model* m, int32_t seq, float* logits_ou
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMemcpyAsync(logits_out, m->seqs[seq].logits, (size_t)m->hp.n_vocab * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return THK_OK;
+}
+// Device-side step clock: clock_out[i] = value of the chip-wide 100 MHz counter (s_memrealtime) when the step that logged token i
+// (thk_model_seq_get) finished.  Differences of consecutive entries are per-step durations measured on the GPU itself, inside
+// replayed multi-step graphs, with nothing inserted into the stream (bench.py's p5/p50/p95).
+extern "C" int thk_model_seq_clock(thk_model* m, int32_t seq, unsigned long long* clock_out, int32_t cap, int32_t* n_out) {
+    if (!m || !clock_out || !n_out) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq && (m->flags & THK_STAGE_HEAD), "bad sequence %d, model not finalized, or a stage without the lm-head", seq);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    SeqState h{};
+    HIPCHK(ctx, hipMemcpyAsync(&h, m->seqs[seq].st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int n = h.n_gen < kGenLogCap ? h.n_gen : kGenLogCap;
+    if (n > cap) n = cap;
+    if (n > 0) {
+        HIPCHK(ctx, hipMemcpyAsync(clock_out, m->seqs[seq].clock_log, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    *n_out = n;
     return THK_OK;
 }
 extern "C" int thk_model_seq_last_token(thk_model* m, int32_t seq, int32_t* token_out) {

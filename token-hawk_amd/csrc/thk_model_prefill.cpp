@@ -55,12 +55,15 @@ static int prefill_workspace(thk_model* m, PrefillBufs* b) {
     return THK_OK;
 }
 
-// Tile images of this stage's layer matrices (thk_prefill.hip, pack_w_kernel): made on the first prefill call and again when a
-// prefill_tile_* tunable changes.  Costs a second copy of the layer weights in HBM (12.4 GB for 7B of 288); if that does not
-// fit the GEMMs stay on the row-major matrices (still the HIP path, ~20 % slower).
-static int ensure_prefill_pack(thk_model* m) {
+// Tile images of this stage's layer matrices (thk_prefill.hip, pack_w_kernel): a second copy of the layer weights in HBM (12.4 GB
+// for 7B of 288), made by thk_model_prepare_prefill - or lazily by the first thk_model_prefill - and again when a weight or a
+// prefill_tile_* tunable changed.  If the slab does not fit, the GEMMs stay on the row-major matrices (still the HIP path, ~20 %
+// slower): thk_model_prefill_uses_tile_images reports which, thk_last_error says why, and the next weight write, tunable change or
+// explicit prepare call tries again.
+static int ensure_prefill_pack(thk_model* m, bool explicit_call) {
     thk_ctx* ctx = m->ctx;
-    if (tun(ctx, "prefill_packed") == 0 || m->pk_failed) return THK_OK;
+    if (tun(ctx, "prefill_packed") == 0) return THK_OK;
+    if (m->pk_failed && !explicit_call) return THK_OK;
     const int E = m->hp.n_embd, F = m->n_ff, nl = m->l1 - m->l0;
     int tiles[4];
     {
@@ -79,7 +82,11 @@ static int ensure_prefill_pack(thk_model* m) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     if (m->prefill_pk_bytes < bytes) {
         hipFree(m->prefill_pk); m->prefill_pk = nullptr; m->prefill_pk_bytes = 0;
-        if (hipMalloc(&m->prefill_pk, bytes) != hipSuccess) { (void)hipGetLastError(); m->prefill_pk = nullptr; m->pk_failed = true; m->pk_w.clear(); m->pk_tiles[0] = 0; return THK_OK; }
+        if (hipMalloc(&m->prefill_pk, bytes) != hipSuccess) {
+            (void)hipGetLastError(); m->prefill_pk = nullptr; m->pk_failed = true; m->pk_w.clear(); m->pk_tiles[0] = 0;
+            (void)fail(ctx, THK_ERR_OOM, "prefill tile images (%zu bytes) do not fit: the prefill GEMMs stream the row-major matrices instead (~20 %% slower)", bytes);
+            return explicit_call ? THK_ERR_OOM : THK_OK;      // the lazy path degrades (query: thk_model_prefill_uses_tile_images), an explicit prepare reports
+        }
         m->prefill_pk_bytes = bytes;
     }
     m->pk_w.assign(nl, {});
@@ -93,8 +100,25 @@ static int ensure_prefill_pack(thk_model* m) {
         }
     }
     memcpy(m->pk_tiles, tiles, sizeof tiles);
+    m->pk_failed = false;
     return THK_OK;
 }
+// Pay for the prefill path now (workspace + tile images: time and HBM) instead of inside the first thk_model_prefill call.
+extern "C" int thk_model_prepare_prefill(thk_model* m) {
+    if (!m) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized, "thk_model_prepare_prefill before thk_model_finalize");
+    REQUIRE(ctx, (m->flags & THK_STAGE_EMBED) && (m->flags & THK_STAGE_HEAD), "thk_model_prepare_prefill needs a full-model stage (embedding + head)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    PrefillBufs b{};
+    int rc = prefill_workspace(m, &b);
+    if (rc != THK_OK) return rc;
+    rc = ensure_prefill_pack(m, true);
+    if (rc == THK_OK) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return rc;
+}
+// 1: the next thk_model_prefill streams tile images; 0: row-major matrices (not prepared yet, prefill_packed = 0, or the slab did not fit)
+extern "C" int thk_model_prefill_uses_tile_images(const thk_model* m) { return (m && m->prefill_pk && !m->pk_w.empty() && !m->pk_failed) ? 1 : 0; }
 
 // one slab of M <= 128 prompt tokens at positions [n_past, n_past + M) through every layer
 static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const int32_t* tokens, int M, int n_past) {
@@ -153,7 +177,7 @@ extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* token
     PrefillBufs b{};
     int rc = prefill_workspace(m, &b);
     if (rc != THK_OK) return rc;
-    if ((rc = ensure_prefill_pack(m)) != THK_OK) return rc;
+    if ((rc = ensure_prefill_pack(m, false)) != THK_OK) return rc;
     hipStream_t st = ctx->stream;
     SeqBuf& sb = m->seqs[seq];
     const int E = m->hp.n_embd, V = m->hp.n_vocab, M = n_tokens;

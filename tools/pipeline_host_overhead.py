@@ -23,10 +23,13 @@ thk = graft.load_package()
 from token_hawk_amd.pipeline import HipStage, PipelineDriver  # noqa: E402
 
 layers = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+tunables = dict(a.split("=") for a in sys.argv[2:])             # name=value ...
 S, steps = 8, 40
 shape = thk.ModelShape(n_layer=layers)                       # 7B widths, `layers` layers
 dev = torch.device("cuda", 0)
 ctx = thk.Context(0)
+for k_, v_ in tunables.items():
+    ctx.set_tunable(k_, int(v_))
 stage = HipStage(thk, ctx, shape, 0, 1, S, dev)
 uid = C.create_string_buffer(128)
 assert ctx.lib.thk_pp_get_unique_id(uid) == 0
@@ -58,7 +61,7 @@ t_enqueue = time.perf_counter() - t0
 ctx.sync()
 t_wall = time.perf_counter() - t0
 n_micro = S * steps
-out = {"stand_in": f"{layers}-layer LLaMA-7B stage (+embed +lm-head) on one MI355X, T={T}, PipelineDriver + native RCCL self ring",
+out = {"tunables": tunables, "stand_in": f"{layers}-layer LLaMA-7B stage (+embed +lm-head) on one MI355X, T={T}, PipelineDriver + native RCCL self ring",
        "micro_steps": n_micro,
        "host_enqueue_us_per_micro_step_stage_only": round(host_stage * 1e6, 1),
        "gpu_us_per_micro_step_stage_only": round(gpu_stage * 1e6, 1),
