@@ -52,8 +52,9 @@ def parse():
     p.add_argument("--lmhead", default="correct", choices=["correct", "faithful"])
     p.add_argument("--force-pipeline", action="store_true",
                    help="run the N>1 code path (process group, HipStage, ring driver with a self send/recv) even with one rank; plumbing check")
-    p.add_argument("--transport", default="native", choices=["torch", "native"],
-                   help="N>1 hidden-state hand-off: torch.distributed P2P ops (backend nccl = RCCL) or libthk's thk_pp_* (RCCL directly)")
+    p.add_argument("--transport", default="native", choices=["torch", "native", "peer"],
+                   help="N>1 hidden-state hand-off: torch.distributed P2P ops (backend nccl = RCCL), libthk's thk_pp_* (RCCL directly, default) or "
+                        "thk_peer_* (no library: stores into the next stage's IPC-mapped mailbox + flag; opt-in, never exercised across xGMI)")
     p.add_argument("--kv", default="f32", choices=["f32", "f16"],
                    help="KV-cache storage: f32 as the reference (default, the headline configuration) or the optional binary16 cache (s_kv = 2 in bytes/token)")
     p.add_argument("--cpu-baseline-layers", type=int, default=0,
@@ -396,6 +397,12 @@ def main():
         else:
             stage = HipStage(thk, ctx, shape, rank, N, S, dev)
             model = stage.model
+            if args.transport == "peer":
+                # mailbox transport: every rank exports its mailbox (64-byte hipIpc handle), opens its successor's
+                handles = [None] * N
+                dist.all_gather_object(handles, stage.attach_peer_transport(S))
+                stage.connect_peer(handles[(rank + 1) % N] if N > 1 else None)
+                dist.barrier()
             if args.transport == "native":
                 # libthk's own RCCL path (measured ~15 us per hand-off vs ~190 us through torch P2P ops); every rank
                 # must agree, so success is all-reduced and the torch transport is the fallback.
@@ -485,6 +492,8 @@ def main():
         if PIPE:
             drv.drain(advance=False)                          # the items still inside the ring leave it after the timed region
             torch.cuda.synchronize(dev)
+            if getattr(stage, "peer", None) is not None:
+                stage.peer_check()                            # a bounded hand-off wait that gave up would have produced garbage
         dist_ms = None
         if rank == 0 and N == 1 and not PIPE and not args.no_extras:
             # straight after the timed region, before anything allocates or frees device memory: a freed 13.5 GB model (the
@@ -621,6 +630,8 @@ def main():
             os.write(json_fd, (json.dumps(result) + "\n").encode())
         if stage is not None and getattr(stage, "pp", None) is not None:
             ctx.lib.thk_pp_destroy(stage.pp)
+        if stage is not None and getattr(stage, "peer", None) is not None:
+            ctx.lib.thk_peer_destroy(stage.peer)
         model.close()
         ctx.close()
     if dist is not None:

@@ -298,6 +298,25 @@ int thk_pp_recv_hidden(thk_pp* pp, thk_model* m, int32_t seq, int peer);   /* in
 int thk_pp_send_token(thk_pp* pp, thk_model* m, int32_t seq, int peer);    /* last stage -> stage 0: 4-byte greedy token */
 int thk_pp_recv_token(thk_pp* pp, thk_model* m, int32_t seq, int peer);
 
+/* ---- the same hand-off without a communication library (token-hawk_amd/csrc/thk_peer.hip; SURVEY.md 8(e) fallback): each
+ * stage owns a mailbox in its HBM, exported with hipIpcGetMemHandle (dmabuf IPC: HSA_ENABLE_IPC_MODE_LEGACY=0); the producing
+ * stage's stream stores the hidden state (n_embd*4 bytes) or the 4-byte token straight into the NEXT stage's mailbox and
+ * raises a sequence-numbered flag, the consuming stage's stream waits for the flag (bounded, ~2 s) and copies the payload into
+ * thk_model_hidden_in / thk_model_token_dev.  Opt-in (bench.py --transport peer).  Usage per stage: create -> export the
+ * 64-byte handle -> hand it to the PREVIOUS stage by any means -> connect(handle of the NEXT stage; NULL = single-stage ring)
+ * -> per micro-step send(...) then recv(...) on the context's stream -> check for time-outs at sync points.
+ * No reference counterpart (the reference is single-device). */
+typedef struct thk_peer thk_peer;
+#define THK_PEER_HANDLE_BYTES 64
+enum { THK_PEER_HIDDEN = 0, THK_PEER_TOKEN = 1 };
+int thk_peer_create(thk_ctx* ctx, thk_model* stage, int32_t n_seq, thk_peer** out);
+int thk_peer_export(thk_peer* p, void* handle_out64);
+int thk_peer_connect(thk_peer* p, const void* next_handle64);
+int thk_peer_send(thk_peer* p, int32_t seq, int kind);   /* kind: THK_PEER_HIDDEN (thk_model_hidden_out) | THK_PEER_TOKEN (thk_model_token_dev) */
+int thk_peer_recv(thk_peer* p, int32_t seq, int kind);   /* into thk_model_hidden_in | thk_model_token_dev */
+int thk_peer_check(thk_peer* p);                         /* THK_ERR_STATE if a wait timed out since the last check */
+int thk_peer_destroy(thk_peer* p);
+
 /* Tuning knobs (integers, by name) so the bench can sweep launch geometry without
  * rebuilding.  Decode knobs must be set before thk_model_finalize; prefill knobs are read
  * per call.  Unknown names return THK_ERR_NOTFOUND.

@@ -138,7 +138,7 @@ def test_driver_with_native_transport_single_rank_ring(thk, orc):
     stage.model.close(); ctx.close()
 
 
-@pytest.mark.parametrize("transport", ["native", "torch"])
+@pytest.mark.parametrize("transport", ["native", "torch", "peer"])
 def test_bench_pipeline_path_end_to_end_on_one_gpu(transport):
     """`bench.py --force-pipeline --model tiny`: the N>1 code path of the benchmark itself (process group on RCCL, HipStage, ring
     kept full across prime / steady / drain, stage timing, JSON line) runs end to end with one rank and a self send/recv, and the
@@ -150,7 +150,7 @@ def test_bench_pipeline_path_end_to_end_on_one_gpu(transport):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    env["MASTER_PORT"] = str(29800 + os.getpid() % 150 + (0 if transport == "native" else 1))
+    env["MASTER_PORT"] = str(29800 + os.getpid() % 150 + {"native": 0, "torch": 1, "peer": 2}[transport])
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-pipeline", "--model", "tiny", "--steps", "6", "--warmup", "2",
                         "--transport", transport, "--no-cpu-baseline", "--no-kernel-profile"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -164,3 +164,112 @@ def test_bench_pipeline_path_end_to_end_on_one_gpu(transport):
         assert key in d, key
     assert len(d["stage_ms_no_handoff"]) == 1 and 0 < d["ideal_efficiency_bound"] <= 1.0
     assert "extras" not in d and "cpu_baseline" not in d              # N>1 protocol: no single-GPU extras on the pipeline path
+
+
+def test_driver_with_peer_mailbox_transport_single_rank_ring(thk, orc):
+    """PipelineDriver on the mailbox transport (thk_peer_*, world 1: the stage is its own successor, no IPC): the token is
+    pushed into the stage's own mailbox and waited for by the next micro-step; same tokens as the oracle, no time-out."""
+    import torch
+    from token_hawk_amd.pipeline import HipStage, PipelineDriver
+    dev = torch.device("cuda", 0)
+    ctx = thk.Context(0)
+    stage = HipStage(thk, ctx, thk.TINY, 0, 1, 1, dev)
+    handle = stage.attach_peer_transport(1)
+    assert len(handle) == 64
+    stage.connect_peer(None)
+    drv = PipelineDriver(stage, 0, 1, 1, force_ring=True)
+    prompt = np.array([[1], [40], [900]], np.int32)
+    stage.set_seq(0, 1, 0)
+    drv.run(3, advance=True, forced_tokens=prompt)
+    drv.prime(advance=True); drv.steady(5, advance=True); drv.drain(advance=True)
+    stage.peer_check()
+    got = stage.generated(0)
+    om = orc.OracleModel(orc.TINY); om.fill_synthetic()
+    for i, t in enumerate(prompt[:, 0].tolist()):
+        lg, _ = om.eval(t, i)
+    tok, exp = orc.greedy(lg), []
+    exp.append(tok)
+    for i in range(5):
+        lg, _ = om.eval(tok, 3 + i); tok = orc.greedy(lg); exp.append(tok)
+    assert got[2:] == exp
+    ctx.lib.thk_peer_destroy(stage.peer)
+    stage.model.close(); ctx.close()
+
+
+def _peer_worker(rank, world, port, n_prompt, n_gen, q):
+    """One pipeline stage per PROCESS, both on GPU 0: the hidden state and the token cross the process boundary through
+    hipIpc-mapped mailboxes (thk_peer_*); gloo only carries the 64-byte handles and the barriers."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import __graft_entry__ as graft
+        thk = graft.load_package()
+        from token_hawk_amd.pipeline import HipStage, PipelineDriver
+        dev = torch.device("cuda", 0)
+        shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=4, n_ctx=64)
+        S = world
+        ctx = thk.Context(0)
+        stage = HipStage(thk, ctx, shape, rank, world, S, dev)
+        handles = [None] * world
+        dist.all_gather_object(handles, stage.attach_peer_transport(S))
+        stage.connect_peer(handles[(rank + 1) % world])
+        dist.barrier()
+        drv = PipelineDriver(stage, rank, world, S)
+        rng = np.random.default_rng(7)
+        prompts = rng.integers(3, 2048, (n_prompt, S)); prompts[0, :] = 1
+        for s in range(S):
+            stage.set_seq(s, int(prompts[0, s]), 0)
+        drv.run(n_prompt, advance=True, forced_tokens=prompts)
+        drv.prime(advance=True); drv.steady(n_gen, advance=True); drv.drain(advance=True)
+        ctx.sync()
+        stage.peer_check()
+        dist.barrier()
+        if rank == world - 1:
+            full = thk.Model(ctx, shape, n_seq=S); full.fill_synthetic(); full.finalize()
+            ok = True
+            for s in range(S):
+                full.seq_set(s, int(prompts[0, s]), 0)
+                full.eval(prompts[:, s].astype(np.int32), 0, seq=s, want_logits=False)      # logs the greedy pick after every prompt token
+                exp = full.seq_get(s)[0].tolist()
+                extra = 1 if s < world - 1 else 0                                         # prime + steady + drain issue N - 1 + n_gen * S items
+                full.seq_set(s, exp[-1], n_prompt)
+                full.decode_steps(n_gen + extra, s, advance=True)
+                exp += full.seq_get(s)[0].tolist()                                        # n_prompt + n_gen + extra picks
+                got = stage.generated(s)
+                ok = ok and got == exp
+                if got != exp:
+                    print("MISMATCH", s, got, exp, flush=True)
+            full.close()
+            q.put(bool(ok))
+        dist.barrier()
+        ctx.lib.thk_peer_destroy(stage.peer)
+        stage.model.close(); ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_process_pipeline_through_peer_mailboxes_on_one_gpu():
+    """A REAL two-stage HipStage pipeline: two processes (one per stage, both on GPU 0), layers 0-1 + embedding in one, layers
+    2-3 + lm-head in the other, two sequences in flight, ring kept full (prime / steady / drain).  Hidden states and tokens cross
+    the process boundary through IPC-mapped device mailboxes (no RCCL: two ranks cannot share a GPU there).  The generated
+    tokens must equal the un-split model's."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctxm.Process(target=_peer_worker, args=(r, 2, port, 3, 6, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) is True

@@ -107,6 +107,13 @@ SIGNATURES = {
     "thk_pp_recv_hidden": (C.c_int, [vp, vp, i32, C.c_int]),
     "thk_pp_send_token": (C.c_int, [vp, vp, i32, C.c_int]),
     "thk_pp_recv_token": (C.c_int, [vp, vp, i32, C.c_int]),
+    "thk_peer_create": (C.c_int, [vp, vp, i32, pp]),
+    "thk_peer_export": (C.c_int, [vp, vp]),
+    "thk_peer_connect": (C.c_int, [vp, vp]),
+    "thk_peer_send": (C.c_int, [vp, i32, C.c_int]),
+    "thk_peer_recv": (C.c_int, [vp, i32, C.c_int]),
+    "thk_peer_check": (C.c_int, [vp]),
+    "thk_peer_destroy": (C.c_int, [vp]),
     "thk_set_tunable": (C.c_int, [vp, C.c_char_p, i64]),
     "thk_get_tunable": (C.c_int, [vp, C.c_char_p, C.POINTER(i64)]),
 }

@@ -1,0 +1,178 @@
+// thk_peer.hip — the pipeline hand-off WITHOUT a communication library (SURVEY.md §8e fallback): every stage owns a
+// "mailbox" in its own HBM, exported to the previous stage with hipIpcGetMemHandle (dmabuf IPC; HSA_ENABLE_IPC_MODE_LEGACY=0);
+// the producing stage's stream runs a one-workgroup kernel that stores the f32 hidden state (or the 4-byte token) straight
+// into the consumer's mailbox over xGMI and then raises a sequence-numbered flag next to it; the consuming stage's stream
+// runs a kernel that waits for the flag and copies the payload into the model's hidden_in / token slot.
+//
+//   * One ncclSend/ncclRecv pair costs two kernel launches plus RCCL's proxy bookkeeping per 16 KB; here the hand-off is the
+//     16 KB store itself + one 8-byte flag.  It is an OPT-IN alternative (bench.py --transport peer), not the default: on this
+//     project's hardware access it could only be exercised with two processes on ONE GPU (tests/test_gpu_pipeline.py), never
+//     across xGMI.
+//   * Ordering: payload with system-scope stores, __threadfence_system(), explicit s_waitcnt vmcnt(0) (the compiler may drop
+//     the wait between a release fence and a following store, MI355X_MICROARCH.md), then the flag with a system-scope release
+//     store.  The consumer polls the flag with system-scope acquire loads (one lane, s_sleep) and reads the payload with
+//     system-scope loads, so no cached copy on either side is ever trusted.
+//   * Flags are monotonically increasing per (sequence, kind); sender and receiver keep their own device-resident counters, so
+//     the kernels take constant arguments (a captured graph would replay them) and nothing is ever reset.
+//   * Flow control is the ring itself: a stage produces item i + S for a sequence only after the token/hidden of item i has
+//     travelled through every other stage, so a mailbox slot is never overwritten before it was read (S = N sequences in flight).
+//   * Every wait is bounded (~2 s on the 100 MHz counter): a missing peer raises an error word (thk_peer_check) instead of
+//     hanging the GPU.
+// Reference: none - the reference is single-device.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/thk.h"
+
+struct thk_ctx;
+extern "C" void* thk_ctx_stream(thk_ctx* ctx);
+namespace thk { int ctx_fail(thk_ctx* ctx, int code, const char* msg); int ctx_device(thk_ctx* ctx); }
+
+namespace {
+typedef unsigned long long u64;
+constexpr int kLine = 16;                         // u64 per 128-byte line
+constexpr u64 kTimeoutTicks = 200000000ull;       // 2 s of the 100 MHz s_memrealtime counter
+
+// producer: src (this GPU) -> dst (next stage's mailbox slot), then flag = ++sent
+// n_words == 0: the payload is ONE 32-bit word (the token id, which sits at a 4-byte offset inside the sequence state)
+__global__ __launch_bounds__(256) void peer_push_kernel(const u64* __restrict__ src, int n_words, u64* dst, u64* flag, u64* sent) {
+    for (int i = threadIdx.x; i < n_words; i += 256) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (n_words == 0 && threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned*>(dst), *reinterpret_cast<const unsigned*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const u64 v = *sent + 1;
+        *sent = v;
+        __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// consumer: wait for flag >= ++received (bounded), then slot (own mailbox) -> dst (hidden_in / token)
+__global__ __launch_bounds__(256) void peer_wait_kernel(const u64* slot, int n_words, u64* __restrict__ dst, const u64* flag, u64* received, unsigned* err) {
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        const u64 want = *received + 1;
+        const u64 t0 = __builtin_amdgcn_s_memrealtime();
+        int good = 1;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+            __builtin_amdgcn_s_sleep(16);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > kTimeoutTicks) { good = 0; break; }
+        }
+        if (good) *received = want;
+        else __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ok = good;
+    }
+    __syncthreads();
+    if (!ok) return;
+    for (int i = threadIdx.x; i < n_words; i += 256) dst[i] = __hip_atomic_load(slot + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (n_words == 0 && threadIdx.x == 0)
+        *reinterpret_cast<unsigned*>(dst) = __hip_atomic_load(reinterpret_cast<const unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+// Mailbox of one stage (exported): per sequence a hidden slot of E/2 words and a token slot of one word (padded to a line),
+// then one flag line per (sequence, kind).  Counters (sent / received) and the error word are private.
+struct thk_peer {
+    thk_ctx* ctx = nullptr;
+    thk_model* model = nullptr;
+    int n_seq = 1, hidden_words = 0;
+    u64* box = nullptr;          // own mailbox (device)
+    size_t box_words = 0;
+    u64* next_box = nullptr;     // the next stage's mailbox as mapped into this process
+    bool next_is_ipc = false;
+    u64* counters = nullptr;     // [n_seq][2 kinds][sent, received] + error word, private
+    unsigned* err = nullptr;
+    size_t hidden_off(int s) const { return (size_t)s * hidden_words; }
+    size_t token_off(int s) const { return (size_t)n_seq * hidden_words + (size_t)s * kLine; }
+    size_t flag_off(int s, int kind) const { return (size_t)n_seq * hidden_words + (size_t)n_seq * kLine + ((size_t)s * 2 + kind) * kLine; }
+};
+#define PEERCHK(p, call)                                                                                 \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) { char b_[256]; snprintf(b_, sizeof b_, "%s failed: %s", #call, hipGetErrorString(e_)); return thk::ctx_fail((p), THK_ERR_HIP, b_); } \
+    } while (0)
+
+extern "C" int thk_peer_create(thk_ctx* ctx, thk_model* stage, int32_t n_seq, thk_peer** out) {
+    if (!ctx || !stage || !out || n_seq < 1) return THK_ERR_INVALID;
+    *out = nullptr;
+    const int E = thk_model_n_embd(stage);
+    if (E <= 0 || (E & 1) || !thk_model_hidden_in(stage, n_seq - 1)) return thk::ctx_fail(ctx, THK_ERR_INVALID, "thk_peer_create: the stage must be finalized with at least n_seq sequences");
+    PEERCHK(ctx, hipSetDevice(thk::ctx_device(ctx)));
+    thk_peer* p = new thk_peer();
+    p->ctx = ctx; p->model = stage; p->n_seq = n_seq; p->hidden_words = (E / 2 + kLine - 1) / kLine * kLine;
+    p->box_words = p->flag_off(n_seq, 0);
+    hipStream_t st = (hipStream_t)thk_ctx_stream(ctx);
+    hipError_t e = hipMalloc((void**)&p->box, p->box_words * 8);          // its own allocation: the IPC handle covers exactly the mailbox
+    if (e == hipSuccess) e = hipMalloc((void**)&p->counters, ((size_t)n_seq * 4 + 2) * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(p->box, 0, p->box_words * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(p->counters, 0, ((size_t)n_seq * 4 + 2) * 8, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { hipFree(p->box); hipFree(p->counters); delete p; return thk::ctx_fail(ctx, THK_ERR_HIP, "thk_peer_create: mailbox allocation failed"); }
+    p->err = reinterpret_cast<unsigned*>(p->counters + (size_t)n_seq * 4);
+    *out = p;
+    return THK_OK;
+}
+extern "C" int thk_peer_export(thk_peer* p, void* handle_out64) {
+    if (!p || !handle_out64) return THK_ERR_INVALID;
+    static_assert(sizeof(hipIpcMemHandle_t) == THK_PEER_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    hipIpcMemHandle_t h;
+    PEERCHK(p->ctx, hipSetDevice(thk::ctx_device(p->ctx)));
+    PEERCHK(p->ctx, hipIpcGetMemHandle(&h, p->box));
+    memcpy(handle_out64, &h, sizeof h);
+    return THK_OK;
+}
+// next_handle64 == NULL: a single-stage ring (the stage is its own successor: same process, no IPC)
+extern "C" int thk_peer_connect(thk_peer* p, const void* next_handle64) {
+    if (!p) return THK_ERR_INVALID;
+    PEERCHK(p->ctx, hipSetDevice(thk::ctx_device(p->ctx)));
+    if (!next_handle64) { p->next_box = p->box; p->next_is_ipc = false; return THK_OK; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, next_handle64, sizeof h);
+    void* ptr = nullptr;
+    PEERCHK(p->ctx, hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess));
+    p->next_box = (u64*)ptr; p->next_is_ipc = true;
+    return THK_OK;
+}
+static int peer_io(thk_peer* p, int32_t seq, int kind, bool send) {
+    if (!p || seq < 0 || seq >= p->n_seq || (kind != THK_PEER_HIDDEN && kind != THK_PEER_TOKEN)) return THK_ERR_INVALID;
+    if (!p->next_box) return thk::ctx_fail(p->ctx, THK_ERR_STATE, "thk_peer: thk_peer_connect first");
+    hipStream_t st = (hipStream_t)thk_ctx_stream(p->ctx);
+    const int words = kind == THK_PEER_HIDDEN ? thk_model_n_embd(p->model) / 2 : 0;
+    const size_t off = kind == THK_PEER_HIDDEN ? p->hidden_off(seq) : p->token_off(seq);
+    u64* cnt = p->counters + ((size_t)seq * 2 + kind) * 2;
+    if (send) {
+        const void* src = kind == THK_PEER_HIDDEN ? thk_model_hidden_out(p->model, seq) : thk_model_token_dev(p->model, seq);
+        hipLaunchKernelGGL(peer_push_kernel, dim3(1), dim3(256), 0, st, (const u64*)src, words, p->next_box + off, p->next_box + p->flag_off(seq, kind), cnt);
+    } else {
+        void* dst = kind == THK_PEER_HIDDEN ? thk_model_hidden_in(p->model, seq) : thk_model_token_dev(p->model, seq);
+        hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(256), 0, st, (const u64*)(p->box + off), words, (u64*)dst, (const u64*)(p->box + p->flag_off(seq, kind)), cnt + 1, p->err);
+    }
+    PEERCHK(p->ctx, hipGetLastError());
+    return THK_OK;
+}
+extern "C" int thk_peer_send(thk_peer* p, int32_t seq, int kind) { return peer_io(p, seq, kind, true); }
+extern "C" int thk_peer_recv(thk_peer* p, int32_t seq, int kind) { return peer_io(p, seq, kind, false); }
+// THK_ERR_STATE when a bounded wait gave up since the last check (the stream is synchronized first)
+extern "C" int thk_peer_check(thk_peer* p) {
+    if (!p) return THK_ERR_INVALID;
+    hipStream_t st = (hipStream_t)thk_ctx_stream(p->ctx);
+    unsigned e = 0;
+    PEERCHK(p->ctx, hipMemcpyAsync(&e, p->err, 4, hipMemcpyDeviceToHost, st));
+    PEERCHK(p->ctx, hipStreamSynchronize(st));
+    if (e) {
+        PEERCHK(p->ctx, hipMemsetAsync(p->err, 0, 4, st));
+        return thk::ctx_fail(p->ctx, THK_ERR_STATE, "thk_peer: a hand-off wait timed out (the previous stage never delivered)");
+    }
+    return THK_OK;
+}
+extern "C" int thk_peer_destroy(thk_peer* p) {
+    if (!p) return THK_OK;
+    hipSetDevice(thk::ctx_device(p->ctx));
+    hipStreamSynchronize((hipStream_t)thk_ctx_stream(p->ctx));
+    if (p->next_is_ipc && p->next_box) hipIpcCloseMemHandle(p->next_box);
+    hipFree(p->box); hipFree(p->counters);
+    delete p;
+    return THK_OK;
+}

@@ -71,6 +71,33 @@ class HipStage:
             ctx.check((lib.thk_pp_recv_hidden if kind == "hidden" else lib.thk_pp_recv_token)(pp, h, seq, peer), "thk_pp_recv")
         ctx.check(lib.thk_pp_group_end(pp), "thk_pp_group_end")
 
+    def attach_peer_transport(self, n_seq: int):
+        """The mailbox transport (thk_peer_*, no communication library).  Returns this stage's 64-byte IPC handle; hand it to the
+        PREVIOUS stage, then call connect_peer() with the handle of the NEXT stage (None: single-stage ring)."""
+        import ctypes as C
+        ctx = self.model.ctx
+        peer = C.c_void_p()
+        ctx.check(ctx.lib.thk_peer_create(ctx.h, self.model.h, n_seq, C.byref(peer)), "thk_peer_create")
+        self.peer = peer
+        buf = C.create_string_buffer(64)
+        ctx.check(ctx.lib.thk_peer_export(peer, buf), "thk_peer_export")
+        return bytes(buf.raw)
+
+    def connect_peer(self, next_handle):
+        ctx = self.model.ctx
+        ctx.check(ctx.lib.thk_peer_connect(self.peer, next_handle), "thk_peer_connect")
+
+    def peer_exchange(self, sends, recvs):
+        """sends/recvs: lists of (kind, seq); every send is enqueued before any wait (a single-stage ring waits for itself)."""
+        ctx, lib = self.model.ctx, self.model.ctx.lib
+        for kind, seq in sends:
+            ctx.check(lib.thk_peer_send(self.peer, seq, 0 if kind == "hidden" else 1), "thk_peer_send")
+        for kind, seq in recvs:
+            ctx.check(lib.thk_peer_recv(self.peer, seq, 0 if kind == "hidden" else 1), "thk_peer_recv")
+
+    def peer_check(self):
+        self.model.ctx.check(self.model.ctx.lib.thk_peer_check(self.peer), "thk_peer_check")
+
     def set_seq(self, seq: int, token: int, pos: int):
         self.model.seq_set(seq, token, pos)
 
@@ -121,6 +148,12 @@ class PipelineDriver:
         live = (lambda i: lo <= i and (hi is None or i < hi))
         i_done = j - r                                   # item this rank just finished
         i_prev = j - ((r - 1) % N)                       # item the previous rank just finished
+        if getattr(st, "peer", None) is not None:        # mailbox transport (thk_peer_*): stores into the next stage's memory, no library
+            sends = [("token" if st.is_last else "hidden", i_done % S)] if live(i_done) else []
+            recvs = [("token" if st.is_first else "hidden", i_prev % S)] if live(i_prev) else []
+            if sends or recvs:
+                st.peer_exchange(sends, recvs)
+            return
         if getattr(st, "pp", None) is not None:          # native RCCL transport (thk_pp_*), same schedule
             sends, recvs = [], []
             if live(i_done):
