@@ -243,6 +243,14 @@ int thk_model_prepare_steps(thk_model* m, int32_t seq, int32_t n_steps);
 /* 1 when the finalized model runs a decode step as ONE persistent loader/consumer launch (thk_engine.hip;
  * tunable "engine" = 1, default 0, shape permitting), 0 when it runs 5 fused launches per layer. */
 int thk_model_uses_engine(const thk_model* m);
+/* 1 when thk_model_decode_step(s) of this model currently take the overlapped dispatch (tunable "overlap_dispatch" = 1, read at
+ * every call): the step's launches go to a user-mode queue of libthk's own as AQL packets WITHOUT the barrier bit, each kernel
+ * waits for its predecessor inside (thk_ovl.cpp).  Same results, same stream-ordered meaning of the calls; only for whole models
+ * (embedding .. lm-head) of the LLaMA-7B/13B widths - any other model makes the decode calls fail while the tunable is set. */
+int thk_model_uses_overlap(const thk_model* m);
+/* Development aid: copy out one of the working buffers the last decode step left behind ("x" final hidden state, "q", "u",
+ * "part_o", "part_ml": the LAST layer's), to compare two launch paths stage by stage on a one-layer model. */
+int thk_model_debug_buffer(thk_model* m, const char* name, float* out, int64_t cap, int64_t* n_out);
 /* Development aid (tunable engine_trace=1 before finalize): the last step's per-workgroup, per-op s_memtime stamps,
  * [n_cu][n_ops][8] 64-bit words (slot meaning in thk_engine.hip). */
 int thk_model_engine_trace(thk_model* m, unsigned long long* out, int64_t cap_words, int32_t* n_cu, int32_t* n_ops);

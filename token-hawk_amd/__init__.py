@@ -355,6 +355,23 @@ class Model:
         """True when decode steps run as one persistent loader/consumer launch (thk_engine.hip)."""
         return bool(self.ctx.lib.thk_model_uses_engine(self.h))
 
+    def seq_last_token(self, seq: int = 0) -> int:
+        """The sequence's current token (the last greedy pick): a 4-byte read-back after a stream synchronisation."""
+        t = C.c_int32()
+        self.ctx.check(self.ctx.lib.thk_model_seq_last_token(self.h, seq, C.byref(t)), "thk_model_seq_last_token")
+        return int(t.value)
+
+    def debug_buffer(self, name: str):
+        """Development aid: a working buffer the last decode step left behind ("x", "q", "u", "part_o", "part_ml")."""
+        out = np.empty(1 << 20, np.float32)
+        n = C.c_int64()
+        self.ctx.check(self.ctx.lib.thk_model_debug_buffer(self.h, name.encode(), out.ctypes.data, out.size, C.byref(n)), "thk_model_debug_buffer")
+        return out[:n.value].copy()
+
+    def uses_overlap(self) -> bool:
+        """True when decode_step(s) currently take the overlapped dispatch (tunable overlap_dispatch = 1; thk_ovl.cpp)."""
+        return bool(self.ctx.lib.thk_model_uses_overlap(self.h))
+
     def seq_get(self, seq: int = 0, cap: int = 4096):
         out = np.empty(cap, np.int32)
         n, pos = C.c_int32(), C.c_int32()

@@ -32,6 +32,8 @@ void default_tunables(thk_ctx* ctx) {
     ctx->tun["attn_waves"] = 8;           // waves per attention block (4 or 8)
     ctx->tun["fold_embed"] = 1;           // the embedding row is fetched by layer 0's qkv prologue instead of a launch of its own
     ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
+    ctx->tun["overlap_dispatch"] = 0;     // thk_model_decode_step(s): the step's launches as AQL packets WITHOUT the barrier bit on a queue of our own,
+                                          // dependencies enforced inside the kernels (thk_ovl.cpp); read at every call, so it can be switched between calls
     ctx->tun["measure_skip_kernel"] = 0;  // bench.py: marginal cost of one kernel = step time with minus without it (results are garbage then);
                                           // refused unless the process runs with THK_MEASURE_HOOKS=1 (never in a product)
     ctx->tun["measure_gain_alias"] = 0;   // measurement only (THK_MEASURE_HOOKS=1): the RMS prologues read the activation vector in place of the gain vector
@@ -143,6 +145,7 @@ extern "C" int thk_ctx_destroy(thk_ctx* ctx) {
     if (!ctx) return THK_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    ovl_destroy(ctx);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->rope_tab) hipFree(ctx->rope_tab);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -152,7 +155,7 @@ extern "C" int thk_ctx_destroy(thk_ctx* ctx) {
 extern "C" int thk_sync(thk_ctx* ctx) {
     if (!ctx) return THK_ERR_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return THK_OK;
+    return ovl_check_error_ctx(ctx);
 }
 extern "C" const char* thk_last_error(thk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 extern "C" void* thk_ctx_stream(thk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }

@@ -1,0 +1,716 @@
+// thk_decode_bodies.hpp — device bodies of the decode step's kernels (fused mat-vec with its prologues / epilogues, attention),
+// shared by the two ways they are launched:
+//   thk_kernels.hip      the HIP kernels (stream launches, hipGraph replays): OVL = false
+//   thk_ovl_kernels.hip  the kernels of the overlapped dispatch (thk_ovl.cpp: a private user-mode queue whose packets carry no
+//                        barrier bit): OVL = true adds the in-kernel dependency protocol and agent-coherent accesses
+// Internal; device code only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "thk_kernels.hpp"
+#include "thk_device.hpp"
+
+namespace thk {
+
+#ifndef THK_OVL_DBG
+#define THK_OVL_DBG 0      // development bisection of the overlapped kernels (bit 0 plain residual loads, 1 plain split-partial loads, 2 plain residual stores, 3 no polling)
+#endif
+
+// Development timeline (libthk_trace.so only, built with -DTHK_TRACE; tools/step_trace.py): every wave stamps the 100 MHz
+// s_memrealtime counter at up to four points of its kernel into [workgroup][wave (8)][4].  Scalar instructions only (the stamp
+// is written with s_store_dwordx2, flushed by s_dcache_wb at the last one): no VGPR, no exec-mask branch, so the register
+// allocation and occupancy of the traced build stay those of the product build.  In the product build the macro is empty.
+#ifdef THK_TRACE
+__device__ __forceinline__ void thk_stamp(unsigned long long* tr, int bid, int slot) {
+    if (tr) {                                                            // kernel argument: a scalar branch
+        unsigned long long t;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+        const unsigned off = __builtin_amdgcn_readfirstlane(((unsigned)bid * 8u + (threadIdx.x >> 6)) * 32u + (unsigned)slot * 8u);
+        asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(t), "s"(tr), "s"(off));
+        if (slot == 3) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
+    }
+}
+// THK_TRACE=1 stamps kernel entry and exit only (register allocation identical to the product build, checked with
+// -Rpass-analysis=kernel-resource-usage); THK_TRACE=2 adds the two inner stamps, which cost the mat-vec kernels 20+ VGPRs.
+#define THK_STAMP(tr, bid, slot) do { if (THK_TRACE >= 2 || (slot) == 0 || (slot) == 3) thk_stamp((tr), (bid), (slot)); } while (0)
+#else
+#define THK_STAMP(tr, bid, slot) do { } while (0)
+#endif
+
+template <int WPB = kWaves>
+__device__ __forceinline__ float block_sum(float v, float* red /* >= WPB floats of LDS */) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (WPB == 4) t = (red[0] + red[1]) + (red[2] + red[3]);
+    else { t = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])); }
+    return t;
+}
+
+// ---------------------------------------------------------------- LDS x-vector layout
+// A row is walked in "slots" of 64 lanes x 8 elements (1 KiB of f16 per wave-instruction).
+// Lane l of slot c needs elements [(c*64+l)*8, +8).  They are stored as two float4
+// arrays so consecutive lanes hit consecutive 16-byte slots (conflict-free ds_read_b128):
+//   lo[c*64+l] = elems 0..3, hi[c*64+l] = elems 4..7 ; hi starts at ns*256 floats.
+// The arrays are zero-padded to ns whole slots, so a lane past the end of a row (C % 512
+// == 256) multiplies a clamped, valid weight vector by zeros: no divergent branch is
+// needed in the streaming loop.
+__device__ __forceinline__ int xs_index(int e, int ns) {   // float index in LDS for element e
+    const int g = e >> 3, j = e & 7;
+    return (j < 4 ? 0 : (ns << 8)) + (g << 2) + (j & 3);
+}
+
+// Store index for float4 #i of the padded vector; threads past the end (only possible when the
+// slot count is odd) are steered to a dummy 16-byte slot behind the vector instead of branching.
+__device__ __forceinline__ int xs_store_index(int i, int ns) {
+    return (i < (ns << 7)) ? xs_index(i << 2, ns) : (ns << 9) + 8;
+}
+
+// ---------------------------------------------------------------- GEMV prologues
+// All run with the whole block; on return xs[] holds the activation vector and a
+// __syncthreads() has been executed.
+
+// Each thread owns float4 #(tid + k*256), k < KP, of the (zero padded) vector.  Prologues are
+// split in two phases so the kernel can order its memory traffic:
+//   issue()  - fire all global loads of the activation vector (L2-resident, back to back)
+//   [the kernel then fires the wave's first batch of WEIGHT loads]
+//   finish() - wait for the activation loads only (vmcnt counts in order, so they had to be
+//              issued first), reduce / combine, write LDS, __syncthreads()
+// => the prologue's latency and math hide under the HBM latency of the first weight batch.
+// With a run-time slot count (NS == 0) issue() is empty and finish() loops.
+template <int NS, int WPB> struct PrologueK { static constexpr int value = NS ? (NS * 128 + WPB * 64 - 1) / (WPB * 64) : 1; };
+
+// plain copy (th.cpp K1 with no fused producer)
+template <int NS, int WPB, bool COH>
+struct ProCopy {
+    static constexpr int KP = PrologueK<NS, WPB>::value;
+    static constexpr int BT = WPB * 64;
+    f4 v[KP];
+    __device__ __forceinline__ void issue(const GemvArgs& a) {
+        if (NS == 0) return;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) v[k] = ld_f4<COH>(a.x, min((int)(threadIdx.x + k * BT) << 2, a.C - 4));
+    }
+    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns, int) {
+        const int C = a.C;
+        if (NS != 0) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = threadIdx.x + k * BT;
+                const f4 o = ((i << 2) < C) ? v[k] : f4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = o;
+            }
+        } else {
+            for (int i = threadIdx.x; i < (ns << 7); i += BT) {
+                f4 o = {0.f, 0.f, 0.f, 0.f};
+                if ((i << 2) < C) o = ld_f4<COH>(a.x, i << 2);
+                *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = o;
+            }
+        }
+        __syncthreads();
+    }
+};
+
+// RMSNorm + gain (K4 th.cpp:1169-1198, K5 :1311-1313): xs = (x * inv) * g
+// EMB: the input vector is the embedding row of the sequence's current token (loader :185-195, th-llama.cpp:577-584: x =
+// f32(table[token,:])), fetched here instead of by a launch of its own; block 0 also writes the f32 row to a.x_out, which
+// the layer's residual add reads two launches later.
+template <int NS, bool EMB, int WPB, bool COH>
+struct ProRms {
+    static constexpr int KP = PrologueK<NS, WPB>::value;
+    static constexpr int BT = WPB * 64;
+    f4 v[KP], g[KP];
+    __device__ __forceinline__ f4 ldx(const GemvArgs& a, const _Float16* row, int ic) {
+        if (EMB) {
+            const h4 h = *reinterpret_cast<const h4*>(row + ic);
+            return f4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        }
+        return ld_f4<COH>(a.x, ic);
+    }
+    __device__ __forceinline__ void issue(const GemvArgs& a) {
+        if (NS == 0) return;
+        const _Float16* row = EMB ? reinterpret_cast<const _Float16*>(a.embed) + (size_t)(*a.tok_ptr) * a.C : nullptr;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            const int ic = min((int)(threadIdx.x + k * BT) << 2, a.C - 4);     // branch-free: clamp, select later
+            v[k] = ldx(a, row, ic);
+            g[k] = *reinterpret_cast<const f4*>(a.gain + ic);
+        }
+    }
+    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float* red, int ns, int bid) {
+        const int C = a.C;
+        if (NS != 0) {
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = threadIdx.x + k * BT;
+                if ((i << 2) >= C) v[k] = f4{0.f, 0.f, 0.f, 0.f};
+                else if (EMB && bid == 0) st_f4<COH>(a.x_out, i << 2, v[k]);
+                ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+            }
+            ss = block_sum<WPB>(ss, red);
+            const float inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = threadIdx.x + k * BT;
+                f4 o;
+                o.x = (v[k].x * inv) * g[k].x; o.y = (v[k].y * inv) * g[k].y; o.z = (v[k].z * inv) * g[k].z; o.w = (v[k].w * inv) * g[k].w;
+                *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = o;
+            }
+        } else {
+            const _Float16* row = EMB ? reinterpret_cast<const _Float16*>(a.embed) + (size_t)(*a.tok_ptr) * C : nullptr;
+            float ss = 0.f;
+            for (int i = threadIdx.x; i < (ns << 7); i += BT) {
+                f4 t = {0.f, 0.f, 0.f, 0.f};
+                if ((i << 2) < C) {
+                    t = ldx(a, row, i << 2);
+                    if (EMB && bid == 0) st_f4<COH>(a.x_out, i << 2, t);
+                }
+                ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+                *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = t;   // raw copy, normalised below
+            }
+            ss = block_sum<WPB>(ss, red);
+            const float inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
+            for (int i = threadIdx.x; i < (C >> 2); i += BT) {
+                const f4 gg = *reinterpret_cast<const f4*>(a.gain + (i << 2));
+                f4* p = reinterpret_cast<f4*>(xs + xs_index(i << 2, ns));
+                f4 t = *p;   // same thread wrote it
+                t.x = (t.x * inv) * gg.x; t.y = (t.y * inv) * gg.y; t.z = (t.z * inv) * gg.z; t.w = (t.w * inv) * gg.w;
+                *p = t;
+            }
+        }
+        __syncthreads();
+    }
+};
+
+// Attention split combine: xs[h*D+d] = sum_s o_s[d] * e^{m_s-M} / sum_s l_s * e^{m_s-M}
+// NSP = compile-time split count so all 2*NSP loads of a float4 are issued together.
+template <int NSP>
+__device__ __forceinline__ f4 attn_merge(const float2 (&ml)[NSP], const f4 (&ov)[NSP]) {
+    float M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) M = fmaxf(M, ml[s].x);
+    float L = 0.f; f4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NSP; ++s) {
+        const float sc = (ml[s].x == -INFINITY) ? 0.f : expf(ml[s].x - M);
+        L += ml[s].y * sc; o += ov[s] * sc;
+    }
+    return o * (1.0f / L);
+}
+template <int NS, int NSP, int WPB, bool COH>
+struct ProAttn {
+    static constexpr int KP = PrologueK<NS, WPB>::value;
+    static constexpr int BT = WPB * 64;
+    float2 ml[KP][NSP];
+    f4 ov[KP][NSP];
+    __device__ __forceinline__ void load1(const GemvArgs& a, int e, float2 (&m)[NSP], f4 (&o)[NSP]) {
+        const int h = e / a.D, d = e - h * a.D;
+#pragma unroll
+        for (int s = 0; s < NSP; ++s) {
+            m[s] = ld_f2<COH>(a.part_ml, (h * NSP + s) * 2);
+            o[s] = ld_f4<COH>(a.part_o, (h * NSP + s) * a.D + d);
+        }
+    }
+    __device__ __forceinline__ void issue(const GemvArgs& a) {
+        if (NS == 0) return;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) load1(a, min((int)(threadIdx.x + k * BT) << 2, a.C - 4), ml[k], ov[k]);
+    }
+    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns, int) {
+        const int C = a.C;
+        if (NS != 0) {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int i = threadIdx.x + k * BT;
+                f4 res = attn_merge<NSP>(ml[k], ov[k]);
+                if ((i << 2) >= C) res = f4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = res;
+            }
+        } else {
+            for (int i = threadIdx.x; i < (ns << 7); i += BT) {
+                f4 res = {0.f, 0.f, 0.f, 0.f};
+                if ((i << 2) < C) { float2 m[NSP]; f4 o[NSP]; load1(a, i << 2, m, o); res = attn_merge<NSP>(m, o); }
+                *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = res;
+            }
+        }
+        __syncthreads();
+    }
+};
+template <int NS, int PRO, int NSP, int WPB, bool COH> struct ProSelect { typedef ProCopy<NS, WPB, COH> type; };
+template <int NS, int NSP, int WPB, bool COH> struct ProSelect<NS, GEMV_PRO_RMS, NSP, WPB, COH> { typedef ProRms<NS, false, WPB, COH> type; };
+template <int NS, int NSP, int WPB, bool COH> struct ProSelect<NS, GEMV_PRO_RMS_EMBED, NSP, WPB, COH> { typedef ProRms<NS, true, WPB, COH> type; };
+template <int NS, int NSP, int WPB, bool COH> struct ProSelect<NS, GEMV_PRO_ATTN, NSP, WPB, COH> { typedef ProAttn<NS, (NSP > 0 ? NSP : 1), WPB, (COH && !(THK_OVL_DBG & 2))> type; };
+
+// ---------------------------------------------------------------- GEMV core
+enum { PRO_COPY = GEMV_PRO_COPY, PRO_RMS = GEMV_PRO_RMS, PRO_ATTN = GEMV_PRO_ATTN, PRO_RMS_EMBED = GEMV_PRO_RMS_EMBED };
+enum { EPI_STORE = GEMV_EPI_STORE, EPI_RESID = GEMV_EPI_RESID, EPI_ROPE_KV = GEMV_EPI_ROPE_KV, EPI_SWIGLU = GEMV_EPI_SWIGLU,
+       EPI_HEAD = GEMV_EPI_HEAD };
+
+template <bool NT>
+__device__ __forceinline__ h8 ldw(const h8* p) {
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
+
+// One launch = one fused op.  Work unit = "row group": NR weight rows streamed
+// together by one wave.  Group g of EPI_* means:
+//   STORE/RESID/HEAD : rows NR*g .. NR*g+NR-1 of W[0]
+//   ROPE_KV (NR=2)   : rows 2g,2g+1 of the virtual [3E,E] stack W[0]=wq,W[1]=wk,W[2]=wv
+//   SWIGLU (NR=2)    : row g of W[0]=w1 and row g of W[1]=w3
+// NS = compile-time slot count (C = NS*512 or NS*512-256), 0 = run-time (any C % 256 == 0).
+// U = slots per load batch (NS % U == 0 when NS != 0): NR*U 16-byte loads per lane are issued
+// back to back with no intervening branch or wait.
+// bid / nblk: this block's index and the number of blocks working on the op (== blockIdx.x / gridDim.x).
+// OVL: the launch belongs to the overlapped dispatch (thk_ovl.cpp) - the activation vector, residuals and every output are
+// accessed agent-coherently, the workgroup waits for its predecessor AFTER requesting its first weight batch and arrives on its
+// own counters at the end (thk_device.hpp).
+template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool PIPE, int WPB = kWaves, bool OVL = false>
+__device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, const int nblk) {
+    static_assert(!PIPE || (NS != 0 && U == NS), "the pipelined loop keeps one whole row group in flight");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int C = a.C;
+    const int nvec = C >> 3;                                  // 16-byte vectors per row
+    const int ns = NS ? NS : ((nvec + 63) >> 6);
+    float* xs = smem;                 // ns*512 floats
+    float* red = smem + (ns << 9);    // floats 0-7: reduction, 8-11: dummy store slot, 12-27: EPI_HEAD scratch (one u64 per wave), 28: OVL flag
+    // the wave index is read into an SGPR: row numbers and row pointers become scalar, so every weight load is
+    // `global_load_dwordx4 v, v_lane_offset, s[row]` instead of carrying a 64-bit address per lane
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_global = bid * WPB + wave;
+    const int total_waves = nblk * WPB;
+    const f4* xlo = reinterpret_cast<const f4*>(xs);
+    const f4* xhi = reinterpret_cast<const f4*>(xs + (ns << 8));
+    const int half_c = C >> 1;
+    const int vlast = nvec - 1;
+
+    // row pointers of group g (wave-uniform; independent of the activation vector)
+    auto row_ptrs = [&](int g, const h8* (&rp)[NR]) {
+        if (EPI == EPI_ROPE_KV) {
+            const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E;
+            const uint16_t* base = which == 0 ? a.W[0] : (which == 1 ? a.W[1] : a.W[2]);
+            rp[0] = reinterpret_cast<const h8*>(base + (size_t)rr * C);
+            rp[1 % NR] = reinterpret_cast<const h8*>(base + (size_t)(rr + 1) * C);
+        } else if (EPI == EPI_SWIGLU) {
+            rp[0] = reinterpret_cast<const h8*>(a.W[0] + (size_t)g * C);
+            rp[1 % NR] = reinterpret_cast<const h8*>(a.W[1] + (size_t)g * C);
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                int row = NR * g + r; if (row >= a.R) row = a.R - 1;   // tail rows recomputed, not stored
+                rp[r] = reinterpret_cast<const h8*>(a.W[0] + (size_t)row * C);
+            }
+        }
+    };
+    // issue the NR*U 16-byte loads of slots [c0, c0+U) back to back (no branch, no wait)
+    auto load_batch = [&](const h8* const (&rp)[NR], int c0, h8 (&w)[NR][U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = (c0 + u) * 64 + lane;
+            const int vc = (NS == 0 || c0 + u == NS - 1) ? min(v, vlast) : v;   // only the last slot can overrun
+#pragma unroll
+            for (int r = 0; r < NR; ++r) w[r][u] = ldw<NT>(rp[r] + vc);
+        }
+    };
+    auto compute_batch = [&](int c0, const h8 (&w)[NR][U], float (&acc)[NR], float (&acc_hi)[NR]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (NS == 0 && c0 + u >= ns) break;                 // run-time slot count: wave-uniform
+            const int v = (c0 + u) * 64 + lane;
+            const f4 xl = xlo[v], xh = xhi[v];
+            if (EPI == EPI_HEAD) {
+                const bool hi = (v << 3) >= half_c;             // second K half (th.cpp:3549-3568)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const float p = dot8(w[r][u], xl, xh, 0.f);
+                    acc[r] += hi ? 0.f : p; acc_hi[r] += hi ? p : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[r] = dot8(w[r][u], xl, xh, acc[r]);
+            }
+        }
+    };
+
+    unsigned long long best = 0ull;   // EPI_HEAD running arg-max of this wave (valid in lane 0)
+
+    // Epilogue operands of a group (residuals / RoPE cos,sin).  The pipelined loop fetches them BEFORE it refills the ring with
+    // the next group's weights: vmcnt retires in order, so a load issued behind the refill could only be waited for by draining
+    // the whole prefetch.
+    struct EpiOps { float resid[NR]; float cs, sn; };
+    const int pos_pipe = (PIPE && EPI == EPI_ROPE_KV) ? (a.pos_ptr ? *a.pos_ptr : a.pos_val) : 0;
+    auto epi_fetch = [&](int g, EpiOps& eo) {
+        if (EPI == EPI_RESID) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) eo.resid[r] = ld_f1<(OVL && !(THK_OVL_DBG & 1))>(a.resid + min(NR * g + r, a.R - 1));      // wave-uniform address: one request
+        } else if (EPI == EPI_ROPE_KV) {
+            const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E, j = rr % a.D;
+            const float2 t = *reinterpret_cast<const float2*>(a.rope_tab + ((size_t)pos_pipe * (a.D >> 1) + (j >> 1)) * 2);
+            eo.cs = t.x; eo.sn = t.y;
+        }
+    };
+    auto finish_group = [&](int g, float (&acc)[NR], float (&acc_hi)[NR], const EpiOps* eo = nullptr) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) { acc[r] = wave_sum(acc[r]); if (EPI == EPI_HEAD) acc_hi[r] = wave_sum(acc_hi[r]); }
+        if (EPI == EPI_STORE) {
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) st_f1<OVL>(a.y + NR * g + r, acc[r]);
+            }
+        } else if (EPI == EPI_RESID) {       // K11 th.cpp:2136-2147: c = a + b
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) st_f1<(OVL && !(THK_OVL_DBG & 4))>(a.y + NR * g + r, (eo ? eo->resid[r] : ld_f1<(OVL && !(THK_OVL_DBG & 1))>(a.resid + NR * g + r)) + acc[r]);
+            }
+        } else if (EPI == EPI_ROPE_KV) {     // K6 th.cpp:1476-1490 + K/V append th-llama.cpp:332-339
+            if (lane == 0) {
+                const int pos = PIPE ? pos_pipe : (a.pos_ptr ? *a.pos_ptr : a.pos_val);
+                const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E;
+                float y0 = acc[0], y1 = acc[1 % NR];
+                if (which < 2) {
+                    const int j = rr % a.D;    // even
+                    const float cs = eo ? eo->cs : a.rope_tab[((size_t)pos * (a.D >> 1) + (j >> 1)) * 2];
+                    const float sn = eo ? eo->sn : a.rope_tab[((size_t)pos * (a.D >> 1) + (j >> 1)) * 2 + 1];
+                    const float t0 = y0 * cs - y1 * sn, t1 = y0 * sn + y1 * cs;
+                    y0 = t0; y1 = t1;
+                }
+                if (which != 0 && a.kv_f16) {     // optional f16 cache: RNE rounding at the append (v_cvt_f16_f32)
+                    _Float16* dh = reinterpret_cast<_Float16*>(which == 1 ? a.kcache : a.vcache) + (size_t)pos * a.E;
+                    st_h1<OVL>(dh + rr, (_Float16)y0); st_h1<OVL>(dh + rr + 1, (_Float16)y1);
+                } else {
+                    float* dst = which == 0 ? a.y : (which == 1 ? a.kcache + (size_t)pos * a.E : a.vcache + (size_t)pos * a.E);
+                    st_f1<OVL>(dst + rr, y0); st_f1<OVL>(dst + rr + 1, y1);
+                }
+            }
+        } else if (EPI == EPI_SWIGLU) {      // K12 th.cpp:2706-2707, K13 :2512-2524
+            if (lane == 0) { const float u1 = acc[0]; st_f1<OVL>(a.y + g, (u1 / (1.0f + expf(-u1))) * acc[1 % NR]); }
+        } else {                              // EPI_HEAD: K3 th.cpp:3926-3943 (+Q1 switch)
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int row = NR * g + r;
+                    if (row < a.R) {
+                        const bool covered = !a.lm_faithful || (row % a.q1_split) < a.q1_cov;
+                        const float v = covered ? acc[r] + acc_hi[r] : acc[r];
+                        st_f1<OVL>(a.y + row, v);
+                        const unsigned long long k = argmax_key(v, (unsigned)row);
+                        best = k > best ? k : best;
+                    }
+                }
+            }
+        }
+    };
+
+    THK_STAMP(a.trace, bid, 0);
+    // --- memory traffic is ordered: activation loads, then the wave's first weight batch (weights
+    // do not depend on the activations), then the prologue math while the weights are in flight.
+    int g = wave_global;
+    const bool has_first = g < a.n_groups;
+    const h8* rp0[NR];
+    h8 w0[NR][U];
+    row_ptrs(has_first ? g : a.n_groups - 1, rp0);   // idle waves (more waves than groups) load a valid row:
+    typename ProSelect<NS, PRO, NSP, WPB, OVL>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
+    if (!OVL || (THK_OVL_DBG & 16)) pro.issue(a);
+    __builtin_amdgcn_sched_barrier(0);
+    load_batch(rp0, 0, w0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (OVL) {       // the weights are on their way; now the predecessor has to be done before its outputs are touched
+        if (!(THK_OVL_DBG & 64)) ovl_wait(a.ovl, reinterpret_cast<int*>(red + 28));
+        if (!(THK_OVL_DBG & 16)) pro.issue(a);
+    }
+    pro.finish(a, xs, red, ns, bid);
+    THK_STAMP(a.trace, bid, 1);
+
+    if constexpr (PIPE) {
+        // Software-pipelined stream: the ring w0 holds one whole row group (NR*NS 16-byte loads per lane).  Slot c of the NEXT
+        // group is requested as soon as slot c of the current one has been consumed, so the wave keeps a constant NR*NS KiB in
+        // flight from its first load to its last - no drain between batches or groups even at one wave per SIMD.
+        auto slot_loads = [&](const h8* const (&rp)[NR], int c, h8 (&w)[NR][U]) {
+            const int v = c * 64 + lane;
+            const int vc = (c == NS - 1) ? min(v, vlast) : v;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) w[r][c] = ldw<NT>(rp[r] + vc);
+        };
+        auto slot_fma = [&](int c, const h8 (&w)[NR][U], float (&acc)[NR], float (&acc_hi)[NR]) {
+            const int v = c * 64 + lane;
+            const f4 xl = xlo[v], xh = xhi[v];
+            if (EPI == EPI_HEAD) {
+                const bool hi = (v << 3) >= half_c;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const float p = dot8(w[r][c], xl, xh, 0.f);
+                    acc[r] += hi ? 0.f : p; acc_hi[r] += hi ? p : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[r] = dot8(w[r][c], xl, xh, acc[r]);
+            }
+        };
+        if (has_first) {
+            for (int gn = g + total_waves; gn < a.n_groups; g = gn, gn += total_waves) {     // steady state: every consume is followed by a refill
+                const h8* rpn[NR];
+                row_ptrs(gn, rpn);
+                EpiOps eo;
+                epi_fetch(g, eo);
+                float acc[NR], acc_hi[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
+                __builtin_amdgcn_sched_barrier(0);                                            // the operand loads stay ahead of the refills
+#pragma unroll
+                for (int c = 0; c < NS; ++c) {
+                    slot_fma(c, w0, acc, acc_hi);
+                    __builtin_amdgcn_sched_barrier(0);                                        // keep refill c right behind consume c
+                    slot_loads(rpn, c, w0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                finish_group(g, acc, acc_hi, &eo);
+            }
+            EpiOps eo;                                                                        // last group: nothing left to request
+            epi_fetch(g, eo);
+            __builtin_amdgcn_sched_barrier(0);
+            float acc[NR], acc_hi[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
+#pragma unroll
+            for (int c = 0; c < NS; ++c) slot_fma(c, w0, acc, acc_hi);
+            THK_STAMP(a.trace, bid, 2);
+            finish_group(g, acc, acc_hi, &eo);
+        }
+    } else {
+    if (has_first) {
+            float acc[NR], acc_hi[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
+            compute_batch(0, w0, acc, acc_hi);
+            THK_STAMP(a.trace, bid, 2);
+            if (NS != 0) {
+#pragma unroll
+                for (int c0 = U; c0 < NS; c0 += U) {
+                    h8 w[NR][U];
+                    load_batch(rp0, c0, w);
+                    __builtin_amdgcn_sched_barrier(0);   // keep all NR*U loads ahead of the first use
+                    compute_batch(c0, w, acc, acc_hi);
+                }
+            } else {
+                for (int c0 = U; c0 < ns; c0 += U) {
+                    h8 w[NR][U];
+                    load_batch(rp0, c0, w);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_batch(c0, w, acc, acc_hi);
+                }
+            }
+            finish_group(g, acc, acc_hi);
+            g += total_waves;
+        }
+        for (; g < a.n_groups; g += total_waves) {
+            const h8* rp[NR];
+            row_ptrs(g, rp);
+            float acc[NR], acc_hi[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) { acc[r] = 0.f; acc_hi[r] = 0.f; }
+            if (NS != 0) {
+#pragma unroll
+                for (int c0 = 0; c0 < NS; c0 += U) {
+                    h8 w[NR][U];
+                    load_batch(rp, c0, w);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_batch(c0, w, acc, acc_hi);
+                }
+            } else {
+                for (int c0 = 0; c0 < ns; c0 += U) {
+                    h8 w[NR][U];
+                    load_batch(rp, c0, w);
+                    __builtin_amdgcn_sched_barrier(0);
+                    compute_batch(c0, w, acc, acc_hi);
+                }
+            }
+            finish_group(g, acc, acc_hi);
+        }
+    }
+    THK_STAMP(a.trace, bid, 3);
+    if (EPI == EPI_HEAD) {
+        unsigned long long* wb = reinterpret_cast<unsigned long long*>(red + 12);   // 16-byte aligned
+        __syncthreads();
+        if (lane == 0) wb[wave] = best;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long b = wb[0];
+            for (int w = 1; w < WPB; ++w) b = wb[w] > b ? wb[w] : b;
+            st_u64<OVL>(a.block_best + bid, b);
+        }
+    }
+    if (OVL && !(THK_OVL_DBG & 32)) ovl_arrive(a.ovl, bid);
+}
+// ---------------------------------------------------------------- attention (decode)
+// grid = H * nsplit blocks; block (h, s) owns positions [s*tc, (s+1)*tc) of head h.
+// A position's head slice is D contiguous floats; D/4 lanes x float4 cover it, so a
+// wave-instruction fetches PPW = 64/(D/4) positions.  Each wave runs an online
+// softmax over its positions, the four waves are merged through LDS, and the block
+// writes (m, l, o[D]) for the split (or the normalised output when nsplit == 1).
+// Scores: S = (q.k) * 1/sqrt(D) scaled after the sum (th.cpp:527-529, th-llama.cpp:518);
+// softmax K10 th.cpp:1901-1957.
+// WAVES waves per block share one (head, split): more waves = fewer positions per wave, so every
+// wave needs a single load batch (one HBM round trip) at T = 512 with 4 splits.
+// one position's 4-element slice for this lane: f32 cache (16 bytes) or f16 cache (8 bytes, widened by v_cvt_f32_f16)
+template <bool KVH, bool COH>
+__device__ __forceinline__ f4 ld_kv4(const float* base, size_t elem_off) {
+    if (COH) {        // sc1 | nt: the row the predecessor has just appended must come from the memory side; nothing here is re-read
+        if (KVH) {
+            const u2v t = __builtin_amdgcn_raw_buffer_load_b64(coh_rsrc(base), (int)(elem_off * 2), 0, kAuxSc1 | kAuxNt);
+            const h4 h = __builtin_bit_cast(h4, t);
+            return f4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+        }
+        return ld_f4<true, kAuxSc1 | kAuxNt>(base, (int)elem_off);
+    }
+    if (KVH) {
+        const h4 h = __builtin_nontemporal_load(reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(base) + elem_off));
+        return f4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    }
+    return __builtin_nontemporal_load(reinterpret_cast<const f4*>(base + elem_off));
+}
+template <int D, int WAVES, bool KVH, bool OVL = false>
+__device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
+    constexpr int LPP = D / 4;          // lanes per position
+    constexpr int PPW = 64 / LPP;       // positions per wave-instruction
+    constexpr int UB = 8;               // wave-instructions per batch (K and V each)
+    __shared__ float sm_o[WAVES][D];
+    __shared__ float sm_ml[WAVES][2];
+    __shared__ int sm_flag;
+
+    // prefill: nq > 1 causal queries share one launch; query qi sits at position pos + qi
+    const int per_q = a.H * a.nsplit;
+    const int qi = a.nq > 1 ? bid / per_q : 0;
+    const int hb = bid - qi * per_q;
+    const int h = hb / a.nsplit, s = hb - h * a.nsplit;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = lane / LPP, li = lane - grp * LPP;
+    THK_STAMP(a.trace, bid, 0);
+    if (OVL) ovl_wait(a.ovl, &sm_flag);
+    const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + qi + 1;
+    const int E = a.H * D;
+    const int t0 = s * a.tc, t1 = min(t0 + a.tc, T);
+
+    const f4 q = ld_f4<OVL>(a.q, qi * E + h * D + li * 4);
+    const size_t hoff = (size_t)(h * D + li * 4);      // element offset of this lane's slice inside a cache row
+
+    float m = -INFINITY, l = 0.f;
+    f4 o = {0.f, 0.f, 0.f, 0.f};
+    // wave w takes positions t0 + (it*WAVES + w)*PPW*UB + u*PPW + grp.  Loads are branch-free:
+    // positions past the end are clamped to a valid row and masked out of the softmax.
+    // (Round 3 tried fetching the first batch BEFORE the device-resident position is known - every row below n_ctx is
+    // allocated - to take the position's round trip off the critical path: 0.6 us per launch SLOWER on MI355X, removed.)
+    for (int tb = t0 + wave * (PPW * UB); tb < t1; tb += WAVES * PPW * UB) {
+        f4 kv[UB], vv[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int t = min(tb + u * PPW + grp, t1 - 1);
+            kv[u] = ld_kv4<KVH, OVL>(a.kcache, (size_t)t * E + hoff);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int t = min(tb + u * PPW + grp, t1 - 1);
+            vv[u] = ld_kv4<KVH, OVL>(a.vcache, (size_t)t * E + hoff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float sc[UB];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int t = tb + u * PPW + grp;
+            float d = q.x * kv[u].x + q.y * kv[u].y + q.z * kv[u].z + q.w * kv[u].w;
+            d = group_sum<LPP>(d) * a.scale;
+            sc[u] = (t < t1) ? d : -INFINITY;
+            bm = fmaxf(bm, sc[u]);
+        }
+        bm = wave_max(bm);                      // wave-uniform, finite (tb < t1 => lane group 0 valid)
+        const float mn = fmaxf(m, bm);
+        const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
+        l *= alpha; o *= alpha;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const float p = expf(sc[u] - mn);   // exp(-inf) == 0 for masked positions
+            l += p; o += vv[u] * p;
+        }
+        m = mn;
+        THK_STAMP(a.trace, bid, 1);
+    }
+    // merge the PPW lane groups of the wave (same m): sum l and o across groups
+    if (PPW >= 2) { l += __shfl_xor(l, LPP); o.x += __shfl_xor(o.x, LPP); o.y += __shfl_xor(o.y, LPP); o.z += __shfl_xor(o.z, LPP); o.w += __shfl_xor(o.w, LPP); }
+    if (PPW >= 4) { l += __shfl_xor(l, 2 * LPP); o.x += __shfl_xor(o.x, 2 * LPP); o.y += __shfl_xor(o.y, 2 * LPP); o.z += __shfl_xor(o.z, 2 * LPP); o.w += __shfl_xor(o.w, 2 * LPP); }
+    if (lane < LPP) *reinterpret_cast<f4*>(&sm_o[wave][lane * 4]) = o;
+    if (lane == 0) { sm_ml[wave][0] = m; sm_ml[wave][1] = l; }
+    __syncthreads();
+    THK_STAMP(a.trace, bid, 2);
+    if (threadIdx.x < D) {
+        const int d = threadIdx.x;
+        float M = -INFINITY;
+        for (int w = 0; w < WAVES; ++w) M = fmaxf(M, sm_ml[w][0]);
+        float L = 0.f, od = 0.f;
+        for (int w = 0; w < WAVES; ++w) {
+            const float mw = sm_ml[w][0];
+            const float f = (mw == -INFINITY) ? 0.f : expf(mw - M);
+            L += sm_ml[w][1] * f; od += sm_o[w][d] * f;
+        }
+        if (a.out) {   // nsplit == 1: finished output, [H*D]
+            st_f1<OVL>(a.out + (size_t)qi * E + h * D + d, od / L);
+        } else {       // split partial: combined by the consumer's prologue (ProAttn) or by attn_combine_kernel
+            st_f1<OVL>(a.part_o + (size_t)(h * a.nsplit + s) * D + d, od);
+            if (d == 0) { st_f1<OVL>(a.part_ml + (h * a.nsplit + s) * 2, M); st_f1<OVL>(a.part_ml + (h * a.nsplit + s) * 2 + 1, L); }
+        }
+    }
+    THK_STAMP(a.trace, bid, 3);
+    if (OVL) ovl_arrive(a.ovl, bid);
+}
+
+// ---------------------------------------------------------------- the step's last launch
+// Greedy pick + sequence bookkeeping after the head kernel: reduce the per-block
+// best keys, write the token (first max wins, th-llama.cpp:826-838), log it,
+// advance the position when asked.
+// n_ctx > 0: the position only advances while pos + 1 < n_ctx, so a decode loop that outruns the host-side check
+// (thk_model_decode_step(s) refuse it) can never index the caches or the RoPE table out of bounds.
+// epoch != NULL: the engine's tag epoch is bumped here, i.e. after the engine launch of this step and before the next.
+// OVL: waits for the head kernel (hence, transitively, for every launch of the step), then zeroes the step's arrival counters;
+// the next step's first packet carries the barrier bit, so nobody is polling them.
+template <bool OVL>
+__device__ __forceinline__ void finish_token_body(const FinishArgs& a) {
+    __shared__ unsigned long long sm[kBlock];
+    __shared__ int sm_flag;
+    THK_STAMP(a.trace, 0, 0);
+    if (OVL) ovl_wait(a.ovl, &sm_flag);
+    unsigned long long b = 0ull;
+    for (int i = threadIdx.x; i < a.nblocks; i += kBlock) {
+        const unsigned long long k = OVL ? __hip_atomic_load(a.block_best + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.block_best[i];
+        b = k > b ? k : b;
+    }
+    sm[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) { const unsigned long long o = sm[threadIdx.x + s]; if (o > sm[threadIdx.x]) sm[threadIdx.x] = o; }
+        __syncthreads();
+    }
+    if (OVL) {
+        for (int i = threadIdx.x; i < a.ovl_n_launches * kOvlShards; i += kBlock)
+            __hip_atomic_store(a.ovl_counters + (size_t)(i / kOvlShards) * kOvlLaunchWords + (i % kOvlShards) * kOvlShardWords, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+        SeqState* st = a.st;
+        const int32_t tok = (int32_t)(0xFFFFFFFFu - (unsigned)(sm[0] & 0xFFFFFFFFull));
+        if (a.id_out) *a.id_out = tok;
+        if (st) {
+            st->token = tok;
+            if (a.gen_log && st->n_gen < a.log_cap) {
+                a.gen_log[st->n_gen] = tok;
+                if (a.clock_log) a.clock_log[st->n_gen] = __builtin_amdgcn_s_memrealtime();   // 100 MHz chip-wide counter: when this step finished
+            }
+            st->n_gen += 1;
+            if (a.advance_ptr && *a.advance_ptr && (a.n_ctx <= 0 || st->pos + 1 < a.n_ctx)) st->pos += 1;
+        }
+        if (a.epoch) *a.epoch += 1u;
+    }
+    THK_STAMP(a.trace, 0, 3);
+}
+
+}  // namespace thk

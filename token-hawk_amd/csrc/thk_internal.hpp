@@ -40,6 +40,7 @@ struct thk_ctx {
     size_t scratch_bytes = 0;
     float* rope_tab = nullptr;      // operator-API RoPE table
     size_t rope_tab_floats = 0;
+    void* ovl = nullptr;            // overlapped dispatch: the private queue and its code object (thk_ovl.cpp), created on first use
 };
 
 struct LayerW {
@@ -63,6 +64,7 @@ struct SeqBuf {
     int pos_host = 0;                // position the NEXT step evaluates (every change goes through this API, so the host knows it exactly)
     EngOp* eng_ops = nullptr;        // device: this sequence's engine program (cache / hidden-state pointers differ per sequence)
     int eng_n_ops = 0;
+    void* ovl_prog = nullptr;        // overlapped dispatch: this sequence's step as AQL packets + device-resident kernel arguments (thk_ovl.cpp)
 };
 
 static const int kGenLogCap = 4096;
@@ -110,6 +112,10 @@ struct thk_model {
     unsigned long long* eng_trace = nullptr;   // development timeline (tunable engine_trace), [n_cu][n_ops][8]
     unsigned long long* trace_buf = nullptr;   // development timeline of the launch path (thk_model_step_trace, THK_TRACE builds)
     bool trace_on = false;
+    // overlapped dispatch (thk_ovl.cpp)
+    unsigned* ovl_counters = nullptr;    // device: kOvlLaunchWords arrival-counter words per launch of a step
+    unsigned* ovl_err = nullptr;         // device: the queue's error word
+    bool ovl_rec = false;                // enqueue_step is recording a step program: link every launch to its predecessor
 };
 
 // ---------------------------------------------------------------- model internals shared by thk_model*.cpp
@@ -127,6 +133,14 @@ int set_seq_state(thk_model* m, int seq, int token, int pos, bool reset_gen);   
 bool engine_plan(thk_model* m);                                                 // thk_model_engine.cpp
 int engine_build_program(thk_model* m, SeqBuf& sb);
 int check_engine_error(thk_model* m);
+// overlapped dispatch (thk_ovl.cpp)
+int enqueue_step_recorded(thk_model* m, int seq);      // thk_model.cpp: enqueue_step with thk::ovl_recorder set (nothing is launched)
+bool ovl_eligible(const thk_model* m, const char** why);
+int ovl_decode_steps(thk_model* m, int seq, int n_steps);
+int ovl_check_error(thk_model* m);
+int ovl_check_error_ctx(thk_ctx* ctx);
+void ovl_free_seq(SeqBuf& sb);
+void ovl_destroy(thk_ctx* ctx);
 
 // ---------------------------------------------------------------- helpers (thk_ctx.cpp)
 int fail(thk_ctx* ctx, int code, const char* fmt, ...);

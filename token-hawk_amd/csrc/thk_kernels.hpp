@@ -23,6 +23,16 @@ struct SeqState {
 enum { GEMV_PRO_COPY = 0, GEMV_PRO_RMS = 1, GEMV_PRO_ATTN = 2, GEMV_PRO_RMS_EMBED = 3 };
 enum { GEMV_EPI_STORE = 0, GEMV_EPI_RESID = 1, GEMV_EPI_ROPE_KV = 2, GEMV_EPI_SWIGLU = 3, GEMV_EPI_HEAD = 4 };
 
+// Overlapped dispatch (thk_ovl.cpp): how a launch finds its predecessor and announces itself (thk_device.hpp, ovl_wait / ovl_arrive).
+constexpr int kOvlShards = 16, kOvlShardWords = 32, kOvlLaunchWords = kOvlShards * kOvlShardWords;   // arrival counters of one launch
+struct OvlLink {
+    const unsigned* wait;   // the predecessor's arrival counters; NULL = nothing to wait for (the packet carries the barrier bit)
+    unsigned wait_n;        // the predecessor's workgroup count
+    unsigned* done;         // this launch's arrival counters (NULL: nobody waits for it)
+    int n_blocks;           // this launch's workgroup count (gridDim is a hidden argument the private queue does not fill)
+    unsigned* err;          // set to 1 by a wait that expired
+};
+
 struct GemvArgs {
     const uint16_t* W[3];   // f16 row-major [R,C] matrices (see gemv_kernel for their meaning per epilogue)
     int R;                  // rows of W[0] (STORE/RESID/HEAD)
@@ -42,6 +52,7 @@ struct GemvArgs {
     // EPI_HEAD
     int lm_faithful; int q1_split; int q1_cov; unsigned long long* block_best;
     unsigned long long* trace;   // development timeline, [blocks][8 waves][4] (only read by a THK_TRACE build; NULL otherwise)
+    OvlLink ovl;                 // overlapped dispatch only
 };
 
 struct AttnArgs {
@@ -58,7 +69,27 @@ struct AttnArgs {
     float* part_o;             // [H, nsplit, D]
     float* part_ml;            // [H, nsplit, 2]
     unsigned long long* trace; // development timeline, [blocks][8 waves][4] (only read by a THK_TRACE build; NULL otherwise)
+    OvlLink ovl;               // overlapped dispatch only
 };
+
+// the step's last launch (greedy pick + sequence bookkeeping), as one argument block
+struct FinishArgs {
+    const unsigned long long* block_best; int nblocks;
+    SeqState* st; int32_t* gen_log; int log_cap;
+    const int* advance_ptr; int32_t* id_out; int n_ctx; unsigned* epoch;
+    unsigned long long* trace; unsigned long long* clock_log;
+    OvlLink ovl;               // overlapped dispatch only ...
+    unsigned* ovl_counters; int ovl_n_launches;   // ... where this launch also zeroes every arrival counter of the step
+};
+
+// Recording instead of launching: while ovl_recorder is set (thk_ovl.cpp builds a sequence's step program), launch_gemv,
+// launch_attn_decode and launch_finish_token_args append {kernel name in libthk_ovl.hsaco, geometry, argument block} to it.
+struct OvlRecorder {
+    struct Launch { char name[64]; int grid, block, lds_dynamic; unsigned char args[384]; int arg_bytes; };
+    Launch* v; int n, cap; bool overflow;
+    void add(const char* name, int grid, int block, int lds_dynamic, const void* args, int arg_bytes);
+};
+extern thread_local OvlRecorder* ovl_recorder;
 
 // nru (0..7) selects the (rows per wave iteration, slots per load batch) variant for the column class of C;
 // see gemv_variant() in thk_kernels.hip.  Row groups = ceil(rows / gemv_rows_per_group).
@@ -80,6 +111,7 @@ hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token
 hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
                                const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st, unsigned long long* trace = nullptr,
                                unsigned long long* clock_log = nullptr);   // clock_log[i] = s_memrealtime (100 MHz) when the step that logged token i finished
+hipError_t launch_finish_token_args(const FinishArgs& a, hipStream_t st);
 constexpr int kTraceBlocks = 2048;   // workgroups recorded per launch of the development timeline
 constexpr int kTraceWords = 8 * 4;    // u64 per workgroup: [wave (8)][stamp (4)]
 bool trace_compiled();               // true in a -DTHK_TRACE build (libthk_trace.so)

@@ -79,6 +79,7 @@ static void free_seq(SeqBuf& s) {
     if (s.graph) hipGraphDestroy(s.graph);
     for (auto& g : s.multi) { if (g.second.second) hipGraphExecDestroy(g.second.second); if (g.second.first) hipGraphDestroy(g.second.first); }
     hipFree(s.eng_ops);
+    ovl_free_seq(s);
     hipFree(s.kv);            // st, gen_log, hidden_in/out, logits, advance live in the model's arena
     s = SeqBuf();
 }
@@ -89,6 +90,7 @@ static void free_working(thk_model* m) {
     m->arena_chunks.clear(); m->arena_off = m->arena_cap = 0;
     hipFree(m->prefill_ws); hipFree(m->prefill_pk); m->prefill_pk = nullptr; m->prefill_pk_bytes = 0; m->pk_w.clear(); m->pk_tiles[0] = 0; m->pk_failed = false;
     m->eng_trace = nullptr;
+    hipFree(m->ovl_counters); m->ovl_counters = nullptr;
     m->eng_gran = nullptr; m->eng_words = nullptr; m->engine = 0;
     m->x = m->q = m->u = m->attn_out = m->part_o = m->part_ml = nullptr; m->block_best = nullptr; m->rope_tab = nullptr;
     m->prefill_ws = nullptr; m->prefill_ws_bytes = 0;
@@ -225,6 +227,13 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
     const bool nt = m->nt != 0;
     const int nl = m->l1 - m->l0;
     const float* xin = sb.hidden_in;
+    // overlapped dispatch: while a step program is recorded every launch is linked to its predecessor's arrival counters
+    int ovl_k = 0; const unsigned* ovl_prev = nullptr; unsigned ovl_prev_n = 0;
+    auto ovl_link = [&](OvlLink& L, int grid) {
+        if (!m->ovl_rec) return;
+        L.wait = ovl_prev; L.wait_n = ovl_prev_n; L.done = m->ovl_counters + (size_t)ovl_k * kOvlLaunchWords; L.n_blocks = grid; L.err = m->ovl_err;
+        ovl_prev = L.done; ovl_prev_n = (unsigned)grid; ++ovl_k;
+    };
     int trace_k = 0;                                     // development timeline (thk_model_step_trace): one [kTraceBlocks][8][4] slab per launch
     auto trace_slab = [&]() -> unsigned long long* { return m->trace_on ? m->trace_buf + (size_t)(trace_k++) * kTraceBlocks * kTraceWords : nullptr; };
     const bool fold_embed = (m->flags & THK_STAGE_EMBED) && m->fold_embed && !m->engine && nl > 0 && m->skip_kernel != 1;
@@ -267,6 +276,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             if (emb) { a.embed = m->tok_embeddings; a.tok_ptr = &sb.st->token; a.x_out = m->x; }
             if (m->gain_alias && !emb) a.gain = a.x;
             a.trace = trace_slab();
+            if (m->skip_kernel != 1) ovl_link(a.ovl, m->grid_qkv);
             MARK("norm_qkv_rope_kv");
             if (m->skip_kernel != 1) HIPCHK(ctx, launch_gemv(emb ? GEMV_PRO_RMS_EMBED : GEMV_PRO_RMS, GEMV_EPI_ROPE_KV, m->var_qkv, a, m->grid_qkv, nt, st));
         }
@@ -283,9 +293,11 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.x = m->attn_out; a.part_o = m->part_o; a.part_ml = m->part_ml; a.H = H; a.D = D; a.nsplit = m->nsplit;
             a.resid = xr_in; a.y = m->x;
             t.trace = trace_slab();
+            if (m->skip_kernel != 2) ovl_link(t.ovl, H * m->nsplit);
             MARK("attn_decode");
             if (m->skip_kernel != 2) HIPCHK(ctx, launch_attn_decode(t, st));
             a.trace = trace_slab();
+            if (m->skip_kernel != 3) ovl_link(a.ovl, m->grid_wo);
             MARK("attn_wo_resid");
             if (m->skip_kernel != 3) HIPCHK(ctx, launch_gemv(m->nsplit == 1 ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, m->var_wo, a, m->grid_wo, nt, st));
         }
@@ -295,6 +307,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.x = m->x; a.gain = L.ffn_norm; a.y = m->u;
             if (m->gain_alias) a.gain = a.x;
             a.trace = trace_slab();
+            if (m->skip_kernel != 4) ovl_link(a.ovl, m->grid_w13);
             MARK("norm_w13_swiglu");
             if (m->skip_kernel != 4) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_SWIGLU, m->var_w13, a, m->grid_w13, nt, st));
         }
@@ -306,6 +319,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.x = m->u; a.resid = m->x;
             a.y = (i == nl - 1 && !(m->flags & THK_STAGE_HEAD)) ? sb.hidden_out : m->x;
             a.trace = trace_slab();
+            if (m->skip_kernel != 5) ovl_link(a.ovl, m->grid_w2);
             MARK("w2_resid");
             if (m->skip_kernel != 5) HIPCHK(ctx, launch_gemv(GEMV_PRO_COPY, GEMV_EPI_RESID, m->var_w2, a, m->grid_w2, nt, st));
         }
@@ -319,10 +333,19 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         a.lm_faithful = m->lm_mode == THK_LMHEAD_FAITHFUL; q1_constants(V, &a.q1_split, &a.q1_cov);
         a.block_best = m->block_best;
         a.trace = trace_slab();
+        if (m->skip_kernel != 6) ovl_link(a.ovl, m->grid_head);
         MARK("norm_lmhead");
         if (m->skip_kernel != 6) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, nt, st));
         MARK("finish_token");
-        if (m->skip_kernel != 6) HIPCHK(ctx, launch_finish_token(m->block_best, m->grid_head, sb.st, sb.gen_log, kGenLogCap, sb.advance, nullptr, T, nullptr, st, trace_slab(), sb.clock_log));
+        if (m->skip_kernel != 6) {
+            FinishArgs f{};
+            f.block_best = m->block_best; f.nblocks = m->grid_head; f.st = sb.st; f.gen_log = sb.gen_log; f.log_cap = kGenLogCap; f.advance_ptr = sb.advance;
+            f.n_ctx = T; f.trace = trace_slab(); f.clock_log = sb.clock_log;
+            ovl_link(f.ovl, 1);
+            f.ovl.done = nullptr;                       // nobody waits for the step's last launch: the next step's first packet carries the barrier bit
+            f.ovl_counters = m->ovl_counters; f.ovl_n_launches = ovl_k;
+            HIPCHK(ctx, launch_finish_token_args(f, st));
+        }
         else HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, T, nullptr, st));       // no arg-max keys were written: keep the token
     } else {
         MARK("advance_pos");
@@ -331,6 +354,8 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
     MARK(nullptr);
     return THK_OK;
 }
+
+int enqueue_step_recorded(thk_model* m, int seq) { return enqueue_step(m, seq, nullptr); }
 
 __global__ void set_seq_state_kernel(SeqState* st, int token, int pos, int reset_gen) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { st->token = token; st->pos = pos; if (reset_gen) st->n_gen = 0; }
@@ -541,7 +566,7 @@ extern "C" int thk_model_decode_step(thk_model* m, int32_t seq, int advance) {
     if (rc != THK_OK) return rc;
     rc = set_advance(m, seq, advance);
     if (rc != THK_OK) return rc;
-    rc = run_step(m, seq);
+    rc = tun(m->ctx, "overlap_dispatch") != 0 ? ovl_decode_steps(m, seq, 1) : run_step(m, seq);
     if (rc == THK_OK && advance) m->seqs[seq].pos_host += 1;
     return rc;
 }
@@ -567,6 +592,11 @@ extern "C" int thk_model_decode_steps(thk_model* m, int32_t seq, int32_t n_steps
     rc = set_advance(m, seq, advance);
     if (rc != THK_OK) return rc;
     SeqBuf& sb = m->seqs[seq];
+    if (tun(ctx, "overlap_dispatch") != 0) {           // the same launches as AQL packets without the barrier bit (thk_ovl.cpp)
+        rc = ovl_decode_steps(m, seq, n_steps);
+        if (rc == THK_OK && advance) sb.pos_host += n_steps;
+        return rc;
+    }
     int left = n_steps;
     if (m->use_graph) {
         while (left >= 2) {                          // 20 = one 20-step graph; 200 = 6 x 32 + 8
@@ -650,6 +680,28 @@ extern "C" int thk_model_seq_last_token(thk_model* m, int32_t seq, int32_t* toke
     HIPCHK(ctx, hipMemcpyAsync(token_out, &m->seqs[seq].st->token, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return check_engine_error(m);
+}
+
+// Development aid: the working buffers a decode step leaves behind (the LAST layer's q, split partials and u, the final hidden
+// state), so that two launch paths can be compared stage by stage on a one-layer model (tools/dev/ovl_debug.py).
+extern "C" int thk_model_debug_buffer(thk_model* m, const char* name, float* out, int64_t cap, int64_t* n_out) {
+    if (!m || !name || !out || !n_out) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized, "model not finalized");
+    const size_t E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff;
+    const float* p = nullptr; size_t n = 0;
+    if (!strcmp(name, "x")) { p = m->x; n = E; }
+    else if (!strcmp(name, "q")) { p = m->q; n = E; }
+    else if (!strcmp(name, "u")) { p = m->u; n = F; }
+    else if (!strcmp(name, "part_o")) { p = m->part_o; n = H * m->nsplit * D; }
+    else if (!strcmp(name, "part_ml")) { p = m->part_ml; n = H * m->nsplit * 2; }
+    else return fail(ctx, THK_ERR_NOTFOUND, "no working buffer '%s' (x, q, u, part_o, part_ml)", name);
+    REQUIRE(ctx, (int64_t)n <= cap, "buffer '%s' holds %zu floats", name, n);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(out, p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *n_out = (int64_t)n;
+    return THK_OK;
 }
 
 extern "C" int64_t thk_model_bytes_per_token(const thk_model* m, int32_t T) {
