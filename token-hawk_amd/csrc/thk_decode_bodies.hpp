@@ -12,8 +12,12 @@
 
 namespace thk {
 
-#ifndef THK_OVL_DBG
-#define THK_OVL_DBG 0      // development bisection of the overlapped kernels (bit 0 plain residual loads, 1 plain split-partial loads, 2 plain residual stores, 3 no polling)
+// How an overlapped kernel reads what its predecessor wrote (always written through, sc1):
+//   THK_OVL_INV = 0  every such load is agent-coherent itself (sc1: served from the memory side, never from this XCD's L2)
+//   THK_OVL_INV = 1  the polling wave invalidates this CU's L1 and this XCD's L2 once the predecessor is done (buffer_inv sc1),
+//                    then the loads are plain: the first workgroup of an XCD misses, the others hit in L2
+#ifndef THK_OVL_INV
+#define THK_OVL_INV 0
 #endif
 
 // Development timeline (libthk_trace.so only, built with -DTHK_TRACE; tools/step_trace.py): every wave stamps the 100 MHz
@@ -118,7 +122,7 @@ struct ProCopy {
 // EMB: the input vector is the embedding row of the sequence's current token (loader :185-195, th-llama.cpp:577-584: x =
 // f32(table[token,:])), fetched here instead of by a launch of its own; block 0 also writes the f32 row to a.x_out, which
 // the layer's residual add reads two launches later.
-template <int NS, bool EMB, int WPB, bool COH>
+template <int NS, bool EMB, int WPB, bool COH, bool COHS>
 struct ProRms {
     static constexpr int KP = PrologueK<NS, WPB>::value;
     static constexpr int BT = WPB * 64;
@@ -148,7 +152,7 @@ struct ProRms {
             for (int k = 0; k < KP; ++k) {
                 const int i = threadIdx.x + k * BT;
                 if ((i << 2) >= C) v[k] = f4{0.f, 0.f, 0.f, 0.f};
-                else if (EMB && bid == 0) st_f4<COH>(a.x_out, i << 2, v[k]);
+                else if (EMB && bid == 0) st_f4<COHS>(a.x_out, i << 2, v[k]);
                 ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
             }
             ss = block_sum<WPB>(ss, red);
@@ -167,7 +171,7 @@ struct ProRms {
                 f4 t = {0.f, 0.f, 0.f, 0.f};
                 if ((i << 2) < C) {
                     t = ldx(a, row, i << 2);
-                    if (EMB && bid == 0) st_f4<COH>(a.x_out, i << 2, t);
+                    if (EMB && bid == 0) st_f4<COHS>(a.x_out, i << 2, t);
                 }
                 ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
                 *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = t;   // raw copy, normalised below
@@ -240,10 +244,11 @@ struct ProAttn {
         __syncthreads();
     }
 };
-template <int NS, int PRO, int NSP, int WPB, bool COH> struct ProSelect { typedef ProCopy<NS, WPB, COH> type; };
-template <int NS, int NSP, int WPB, bool COH> struct ProSelect<NS, GEMV_PRO_RMS, NSP, WPB, COH> { typedef ProRms<NS, false, WPB, COH> type; };
-template <int NS, int NSP, int WPB, bool COH> struct ProSelect<NS, GEMV_PRO_RMS_EMBED, NSP, WPB, COH> { typedef ProRms<NS, true, WPB, COH> type; };
-template <int NS, int NSP, int WPB, bool COH> struct ProSelect<NS, GEMV_PRO_ATTN, NSP, WPB, COH> { typedef ProAttn<NS, (NSP > 0 ? NSP : 1), WPB, (COH && !(THK_OVL_DBG & 2))> type; };
+// COH: loads of the predecessor's outputs are agent-coherent; COHS: stores are written through (overlapped dispatch)
+template <int NS, int PRO, int NSP, int WPB, bool COH, bool COHS> struct ProSelect { typedef ProCopy<NS, WPB, COH> type; };
+template <int NS, int NSP, int WPB, bool COH, bool COHS> struct ProSelect<NS, GEMV_PRO_RMS, NSP, WPB, COH, COHS> { typedef ProRms<NS, false, WPB, COH, COHS> type; };
+template <int NS, int NSP, int WPB, bool COH, bool COHS> struct ProSelect<NS, GEMV_PRO_RMS_EMBED, NSP, WPB, COH, COHS> { typedef ProRms<NS, true, WPB, COH, COHS> type; };
+template <int NS, int NSP, int WPB, bool COH, bool COHS> struct ProSelect<NS, GEMV_PRO_ATTN, NSP, WPB, COH, COHS> { typedef ProAttn<NS, (NSP > 0 ? NSP : 1), WPB, COH> type; };
 
 // ---------------------------------------------------------------- GEMV core
 enum { PRO_COPY = GEMV_PRO_COPY, PRO_RMS = GEMV_PRO_RMS, PRO_ATTN = GEMV_PRO_ATTN, PRO_RMS_EMBED = GEMV_PRO_RMS_EMBED };
@@ -272,11 +277,12 @@ template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool PIPE, 
 __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, const int nblk) {
     static_assert(!PIPE || (NS != 0 && U == NS), "the pipelined loop keeps one whole row group in flight");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool OVL_LD = OVL && !THK_OVL_INV;           // loads of the predecessor's outputs are coherent themselves
     const int C = a.C;
     const int nvec = C >> 3;                                  // 16-byte vectors per row
     const int ns = NS ? NS : ((nvec + 63) >> 6);
     float* xs = smem;                 // ns*512 floats
-    float* red = smem + (ns << 9);    // floats 0-7: reduction, 8-11: dummy store slot, 12-27: EPI_HEAD scratch (one u64 per wave), 28: OVL flag
+    float* red = smem + (ns << 9);    // floats 0-7: reduction, 8-11: dummy store slot, 12-27: EPI_HEAD scratch (one u64 per wave)
     // the wave index is read into an SGPR: row numbers and row pointers become scalar, so every weight load is
     // `global_load_dwordx4 v, v_lane_offset, s[row]` instead of carrying a 64-bit address per lane
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -345,7 +351,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     auto epi_fetch = [&](int g, EpiOps& eo) {
         if (EPI == EPI_RESID) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r) eo.resid[r] = ld_f1<(OVL && !(THK_OVL_DBG & 1))>(a.resid + min(NR * g + r, a.R - 1));      // wave-uniform address: one request
+            for (int r = 0; r < NR; ++r) eo.resid[r] = ld_f1<OVL_LD>(a.resid + min(NR * g + r, a.R - 1));      // wave-uniform address: one request
         } else if (EPI == EPI_ROPE_KV) {
             const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E, j = rr % a.D;
             const float2 t = *reinterpret_cast<const float2*>(a.rope_tab + ((size_t)pos_pipe * (a.D >> 1) + (j >> 1)) * 2);
@@ -363,7 +369,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         } else if (EPI == EPI_RESID) {       // K11 th.cpp:2136-2147: c = a + b
             if (lane == 0) {
 #pragma unroll
-                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) st_f1<(OVL && !(THK_OVL_DBG & 4))>(a.y + NR * g + r, (eo ? eo->resid[r] : ld_f1<(OVL && !(THK_OVL_DBG & 1))>(a.resid + NR * g + r)) + acc[r]);
+                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) st_f1<OVL>(a.y + NR * g + r, (eo ? eo->resid[r] : ld_f1<OVL_LD>(a.resid + NR * g + r)) + acc[r]);
             }
         } else if (EPI == EPI_ROPE_KV) {     // K6 th.cpp:1476-1490 + K/V append th-llama.cpp:332-339
             if (lane == 0) {
@@ -412,14 +418,14 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     const h8* rp0[NR];
     h8 w0[NR][U];
     row_ptrs(has_first ? g : a.n_groups - 1, rp0);   // idle waves (more waves than groups) load a valid row:
-    typename ProSelect<NS, PRO, NSP, WPB, OVL>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
-    if (!OVL || (THK_OVL_DBG & 16)) pro.issue(a);
+    typename ProSelect<NS, PRO, NSP, WPB, OVL_LD, OVL>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
+    if (!OVL) pro.issue(a);
     __builtin_amdgcn_sched_barrier(0);
     load_batch(rp0, 0, w0);
     __builtin_amdgcn_sched_barrier(0);
     if (OVL) {       // the weights are on their way; now the predecessor has to be done before its outputs are touched
-        if (!(THK_OVL_DBG & 64)) ovl_wait(a.ovl, reinterpret_cast<int*>(red + 28));
-        if (!(THK_OVL_DBG & 16)) pro.issue(a);
+        ovl_wait<THK_OVL_INV != 0>(a.ovl);
+        pro.issue(a);
     }
     pro.finish(a, xs, red, ns, bid);
     THK_STAMP(a.trace, bid, 1);
@@ -542,7 +548,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
             st_u64<OVL>(a.block_best + bid, b);
         }
     }
-    if (OVL && !(THK_OVL_DBG & 32)) ovl_arrive(a.ovl, bid);
+    if (OVL) ovl_arrive(a.ovl, bid);
 }
 // ---------------------------------------------------------------- attention (decode)
 // grid = H * nsplit blocks; block (h, s) owns positions [s*tc, (s+1)*tc) of head h.
@@ -578,7 +584,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     constexpr int UB = 8;               // wave-instructions per batch (K and V each)
     __shared__ float sm_o[WAVES][D];
     __shared__ float sm_ml[WAVES][2];
-    __shared__ int sm_flag;
+    constexpr bool OVL_LD = OVL && !THK_OVL_INV;
 
     // prefill: nq > 1 causal queries share one launch; query qi sits at position pos + qi
     const int per_q = a.H * a.nsplit;
@@ -588,12 +594,12 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPP, li = lane - grp * LPP;
     THK_STAMP(a.trace, bid, 0);
-    if (OVL) ovl_wait(a.ovl, &sm_flag);
+    if (OVL) ovl_wait<THK_OVL_INV != 0>(a.ovl);
     const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + qi + 1;
     const int E = a.H * D;
     const int t0 = s * a.tc, t1 = min(t0 + a.tc, T);
 
-    const f4 q = ld_f4<OVL>(a.q, qi * E + h * D + li * 4);
+    const f4 q = ld_f4<OVL_LD>(a.q, qi * E + h * D + li * 4);
     const size_t hoff = (size_t)(h * D + li * 4);      // element offset of this lane's slice inside a cache row
 
     float m = -INFINITY, l = 0.f;
@@ -607,12 +613,12 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int t = min(tb + u * PPW + grp, t1 - 1);
-            kv[u] = ld_kv4<KVH, OVL>(a.kcache, (size_t)t * E + hoff);
+            kv[u] = ld_kv4<KVH, OVL_LD>(a.kcache, (size_t)t * E + hoff);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int t = min(tb + u * PPW + grp, t1 - 1);
-            vv[u] = ld_kv4<KVH, OVL>(a.vcache, (size_t)t * E + hoff);
+            vv[u] = ld_kv4<KVH, OVL_LD>(a.vcache, (size_t)t * E + hoff);
         }
         __builtin_amdgcn_sched_barrier(0);
         float sc[UB];
@@ -677,9 +683,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
 template <bool OVL>
 __device__ __forceinline__ void finish_token_body(const FinishArgs& a) {
     __shared__ unsigned long long sm[kBlock];
-    __shared__ int sm_flag;
     THK_STAMP(a.trace, 0, 0);
-    if (OVL) ovl_wait(a.ovl, &sm_flag);
+    if (OVL) ovl_wait<false>(a.ovl);
     unsigned long long b = 0ull;
     for (int i = threadIdx.x; i < a.nblocks; i += kBlock) {
         const unsigned long long k = OVL ? __hip_atomic_load(a.block_best + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.block_best[i];

@@ -129,11 +129,10 @@ __device__ __forceinline__ void st_u64(unsigned long long* p, unsigned long long
 // predecessor's workgroup count: wave 0 polls (one shard per lane, summed with a butterfly), the other waves sit at the barrier.
 // The counters are zeroed by the step's last launch.  A wait is bounded (0.5 s of the 100 MHz clock); the first one that expires
 // sets *err, and every later wait of the chain returns at once, so a broken chain ends in well under a second per step.
-__device__ __forceinline__ void ovl_wait(const OvlLink& L, int* flag_lds) {
-    (void)flag_lds;
-#ifdef THK_OVL_DBG
-    if (THK_OVL_DBG & 8) { __syncthreads(); return; }
-#endif
+// INV: once the predecessor is done the polling wave drops this CU's L1 and this XCD's clean L2 lines (buffer_inv sc1), so the
+// workgroup may read the predecessor's (written-through) outputs with plain, L2-cacheable loads.
+template <bool INV>
+__device__ __forceinline__ void ovl_wait(const OvlLink& L) {
     if ((threadIdx.x >> 6) == 0 && L.wait) {
         const int lane = threadIdx.x & 63;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -148,6 +147,9 @@ __device__ __forceinline__ void ovl_wait(const OvlLink& L, int* flag_lds) {
                 break;
             }
         }
+#if !defined(THK_OVL_INV) || THK_OVL_INV != 2      /* 2 = measurement only: plain loads WITHOUT the invalidate (wrong results possible) */
+        if (INV) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+#endif
     }
     __syncthreads();
 }

@@ -356,6 +356,18 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
 }
 
 int enqueue_step_recorded(thk_model* m, int seq) { return enqueue_step(m, seq, nullptr); }
+// launch names of a step in order, nothing launched (the recorder swallows the launches)
+static int enqueue_step_names(thk_model* m, int seq, StepProf* p) {
+    std::vector<OvlRecorder::Launch> store(5 * (m->l1 - m->l0) + 8);
+    OvlRecorder rec{store.data(), 0, (int)store.size(), false};
+    const bool on = m->trace_on;
+    m->trace_on = false;
+    ovl_recorder = &rec;
+    const int rc = enqueue_step(m, seq, p);
+    ovl_recorder = nullptr;
+    m->trace_on = on;
+    return rc;
+}
 
 __global__ void set_seq_state_kernel(SeqState* st, int token, int pos, int reset_gen) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { st->token = token; st->pos = pos; if (reset_gen) st->n_gen = 0; }
@@ -755,7 +767,15 @@ extern "C" int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long lon
     p.names_only = true;
     m->trace_on = true;
     int rc = THK_OK;
-    if (m->use_graph) {      // the timeline of a step as it is normally run: a replayed graph (two steps, the SECOND one is recorded)
+    if (tun(ctx, "overlap_dispatch") != 0) {   // the overlapped dispatch: a step program recorded with the trace slabs, two steps (the second one's stamps remain)
+        SeqBuf& sb = m->seqs[seq];
+        ovl_free_seq(sb);
+        rc = enqueue_step_names(m, seq, &p);
+        if (rc == THK_OK) rc = ovl_decode_steps(m, seq, 2);
+        m->trace_on = false;
+        if (rc == THK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "sync failed while tracing");
+        ovl_free_seq(sb);                       // the next ordinary call records a program without stamps
+    } else if (m->use_graph) {      // the timeline of a step as it is normally run: a replayed graph (two steps, the SECOND one is recorded)
         hipGraph_t g = nullptr; hipGraphExec_t x = nullptr;
         HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         m->trace_on = false;

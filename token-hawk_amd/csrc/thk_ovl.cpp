@@ -89,7 +89,7 @@ std::string hsaco_path() {
     if (dladdr((const void*)&thk_model_create, &info) && info.dli_fname) {
         std::string p = info.dli_fname;
         const size_t slash = p.rfind('/');
-        return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/libthk_ovl.hsaco";
+        return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + (trace_compiled() ? "/libthk_ovl_trace.hsaco" : "/libthk_ovl.hsaco");
     }
     return "libthk_ovl.hsaco";
 }
@@ -248,7 +248,8 @@ static int build_program(thk_model* m, int seq, OvlQueue* Q) {
         // (plain stores of the sequence state) releases at agent scope; nothing in between needs a fence at its end: what crosses a
         // launch is written through
         static const bool all_barriers = getenv("THK_OVL_BARRIER") != nullptr;      // development: the overlapped kernels behind ordinary barrier packets
-        P->headers.push_back(make_header(i == 0 || all_barriers, HSA_FENCE_SCOPE_AGENT, (i == rec.n - 1 || all_barriers) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE));
+        static const int acq_inner = getenv("THK_OVL_ACQ") ? atoi(getenv("THK_OVL_ACQ")) : HSA_FENCE_SCOPE_AGENT;     // development: acquire scope of the packets inside a step
+        P->headers.push_back(make_header(i == 0 || all_barriers, (i == 0 || all_barriers) ? HSA_FENCE_SCOPE_AGENT : acq_inner, (i == rec.n - 1 || all_barriers) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE));
     }
     sb.ovl_prog = P;
     return THK_OK;

@@ -13,12 +13,16 @@ ap.add_argument("--full", action="store_true")
 ap.add_argument("--model", default="7b")
 ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--tunable", action="append", default=[], help="name=value, set before finalize")
+ap.add_argument("--no-parity", action="store_true")
 args = ap.parse_args()
 thk = graft.load_package()
 import torch
 
 def parity(shape, n, label):
     with thk.Context(0) as ctx:
+        for kv in args.tunable:
+            k, v = kv.split("="); ctx.set_tunable(k, int(v))
         m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
         out = {}
         for mode in (0, 1, 0, 1):
@@ -52,14 +56,17 @@ def parity(shape, n, label):
         m.close()
         return bool(same_t) and d < 1e-5 and a[0] == a[1]
 
-ok = parity(thk.ModelShape(n_embd=4096, n_head=32, n_layer=2), 24, "7B-width x2 layers")
-ok = parity(thk.ModelShape(n_embd=5120, n_head=40, n_layer=1), 12, "13B-width x1 layer") and ok
-print("PARITY", "OK" if ok else "FAILED", flush=True)
+if not args.no_parity:
+    ok = parity(thk.ModelShape(n_embd=4096, n_head=32, n_layer=2), 24, "7B-width x2 layers")
+    ok = parity(thk.ModelShape(n_embd=5120, n_head=40, n_layer=1), 12, "13B-width x1 layer") and ok
+    print("PARITY", "OK" if ok else "FAILED", flush=True)
 
 if args.full:
     shape = {"7b": thk.LLAMA_7B, "13b": thk.LLAMA_13B}[args.model]
     T = shape.n_ctx
     with thk.Context(0) as ctx:
+        for kv in args.tunable:
+            k, v = kv.split("="); ctx.set_tunable(k, int(v))
         m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
         res = {0: [], 1: []}
         m.prepare_steps(args.steps)
