@@ -34,6 +34,8 @@ void default_tunables(thk_ctx* ctx) {
     ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
     ctx->tun["overlap_dispatch"] = 0;     // thk_model_decode_step(s): the step's launches as AQL packets WITHOUT the barrier bit on a queue of our own,
                                           // dependencies enforced inside the kernels (thk_ovl.cpp); read at every call, so it can be switched between calls
+    ctx->tun["overlap_keep_barrier"] = 118;// overlapped dispatch: launch kinds whose packets KEEP the barrier bit (1 qkv, 2 attention, 4 wo, 8 w1|w3, 16 w2,
+                                          // 32 lm-head, 64 greedy pick); read when a sequence's step program is built (first overlapped call after finalize)
     ctx->tun["measure_skip_kernel"] = 0;  // bench.py: marginal cost of one kernel = step time with minus without it (results are garbage then);
                                           // refused unless the process runs with THK_MEASURE_HOOKS=1 (never in a product)
     ctx->tun["measure_gain_alias"] = 0;   // measurement only (THK_MEASURE_HOOKS=1): the RMS prologues read the activation vector in place of the gain vector

@@ -1,8 +1,8 @@
-// thk_decode_bodies.hpp — device bodies of the decode step's kernels (fused mat-vec with its prologues / epilogues, attention),
-// shared by the two ways they are launched:
-//   thk_kernels.hip      the HIP kernels (stream launches, hipGraph replays): OVL = false
-//   thk_ovl_kernels.hip  the kernels of the overlapped dispatch (thk_ovl.cpp: a private user-mode queue whose packets carry no
-//                        barrier bit): OVL = true adds the in-kernel dependency protocol and agent-coherent accesses
+// thk_decode_bodies.hpp — device bodies of the decode step's kernels (fused mat-vec with its prologues / epilogues, attention,
+// greedy pick), shared by the two ways they are launched:
+//   thk_kernels.hip      the HIP kernels (stream launches, hipGraph replays): OVL = 0
+//   thk_ovl_kernels.hip  the kernels of the overlapped dispatch (thk_ovl.cpp: a private user-mode queue on which chosen packets
+//                        carry no barrier bit): OVL flavours add the in-kernel dependency protocol and agent-coherent accesses
 // Internal; device code only.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -12,13 +12,15 @@
 
 namespace thk {
 
-// How an overlapped kernel reads what its predecessor wrote (always written through, sc1):
-//   THK_OVL_INV = 0  every such load is agent-coherent itself (sc1: served from the memory side, never from this XCD's L2)
-//   THK_OVL_INV = 1  the polling wave invalidates this CU's L1 and this XCD's L2 once the predecessor is done (buffer_inv sc1),
-//                    then the loads are plain: the first workgroup of an XCD misses, the others hit in L2
-#ifndef THK_OVL_INV
-#define THK_OVL_INV 0
-#endif
+// Flavours of a kernel of the overlapped dispatch (template argument OVL; 0 = the stream-ordered kernel):
+//   OVL_WAIT    its packet carries no barrier bit: it waits for its predecessor inside and reads earlier launches' outputs coherently
+//   OVL_ARRIVE  its successor's packet carries no barrier bit: it writes through and arrives on its counters
+//   OVL_QUEUE   launched from the private queue at all (no gridDim builtin) - set on every kernel of thk_ovl_kernels.hip
+enum { OVL_WAIT = 1, OVL_ARRIVE = 2, OVL_QUEUE = 4 };
+// A waiting kernel reads what earlier launches of the step wrote with agent-coherent loads (sc1: served from the memory side,
+// never from this XCD's L2).  Measured alternatives on MI355X, 7B step: invalidating L1 / L2 once per workgroup after the wait
+// (buffer_inv sc1) and loading plainly 2.81 ms against 2.55 ms; plain loads without any invalidate (wrong, an upper bound for
+// cacheable loads) 2.505 ms against 2.517 ms - the coherent loads are not what the protocol costs.
 
 // Development timeline (libthk_trace.so only, built with -DTHK_TRACE; tools/step_trace.py): every wave stamps the 100 MHz
 // s_memrealtime counter at up to four points of its kernel into [workgroup][wave (8)][4].  Scalar instructions only (the stamp
@@ -273,11 +275,13 @@ __device__ __forceinline__ h8 ldw(const h8* p) {
 // OVL: the launch belongs to the overlapped dispatch (thk_ovl.cpp) - the activation vector, residuals and every output are
 // accessed agent-coherently, the workgroup waits for its predecessor AFTER requesting its first weight batch and arrives on its
 // own counters at the end (thk_device.hpp).
-template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool PIPE, int WPB = kWaves, bool OVL = false>
+template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool PIPE, int WPB = kWaves, int OVL = 0>
 __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, const int nblk) {
     static_assert(!PIPE || (NS != 0 && U == NS), "the pipelined loop keeps one whole row group in flight");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool OVL_LD = OVL && !THK_OVL_INV;           // loads of the predecessor's outputs are coherent themselves
+    constexpr bool OVL_W = (OVL & OVL_WAIT) != 0, OVL_A = (OVL & OVL_ARRIVE) != 0;
+    constexpr bool OVL_LD = OVL_W;         // loads of earlier launches' outputs are coherent themselves
+    constexpr bool OVL_ST = OVL_A;       // outputs are written through
     const int C = a.C;
     const int nvec = C >> 3;                                  // 16-byte vectors per row
     const int ns = NS ? NS : ((nvec + 63) >> 6);
@@ -364,12 +368,12 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         if (EPI == EPI_STORE) {
             if (lane == 0) {
 #pragma unroll
-                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) st_f1<OVL>(a.y + NR * g + r, acc[r]);
+                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) st_f1<OVL_ST>(a.y + NR * g + r, acc[r]);
             }
         } else if (EPI == EPI_RESID) {       // K11 th.cpp:2136-2147: c = a + b
             if (lane == 0) {
 #pragma unroll
-                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) st_f1<OVL>(a.y + NR * g + r, (eo ? eo->resid[r] : ld_f1<OVL_LD>(a.resid + NR * g + r)) + acc[r]);
+                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) st_f1<OVL_ST>(a.y + NR * g + r, (eo ? eo->resid[r] : ld_f1<OVL_LD>(a.resid + NR * g + r)) + acc[r]);
             }
         } else if (EPI == EPI_ROPE_KV) {     // K6 th.cpp:1476-1490 + K/V append th-llama.cpp:332-339
             if (lane == 0) {
@@ -385,14 +389,14 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
                 }
                 if (which != 0 && a.kv_f16) {     // optional f16 cache: RNE rounding at the append (v_cvt_f16_f32)
                     _Float16* dh = reinterpret_cast<_Float16*>(which == 1 ? a.kcache : a.vcache) + (size_t)pos * a.E;
-                    st_h1<OVL>(dh + rr, (_Float16)y0); st_h1<OVL>(dh + rr + 1, (_Float16)y1);
+                    st_h1<OVL_ST>(dh + rr, (_Float16)y0); st_h1<OVL_ST>(dh + rr + 1, (_Float16)y1);
                 } else {
                     float* dst = which == 0 ? a.y : (which == 1 ? a.kcache + (size_t)pos * a.E : a.vcache + (size_t)pos * a.E);
-                    st_f1<OVL>(dst + rr, y0); st_f1<OVL>(dst + rr + 1, y1);
+                    st_f1<OVL_ST>(dst + rr, y0); st_f1<OVL_ST>(dst + rr + 1, y1);
                 }
             }
         } else if (EPI == EPI_SWIGLU) {      // K12 th.cpp:2706-2707, K13 :2512-2524
-            if (lane == 0) { const float u1 = acc[0]; st_f1<OVL>(a.y + g, (u1 / (1.0f + expf(-u1))) * acc[1 % NR]); }
+            if (lane == 0) { const float u1 = acc[0]; st_f1<OVL_ST>(a.y + g, (u1 / (1.0f + expf(-u1))) * acc[1 % NR]); }
         } else {                              // EPI_HEAD: K3 th.cpp:3926-3943 (+Q1 switch)
             if (lane == 0) {
 #pragma unroll
@@ -401,7 +405,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
                     if (row < a.R) {
                         const bool covered = !a.lm_faithful || (row % a.q1_split) < a.q1_cov;
                         const float v = covered ? acc[r] + acc_hi[r] : acc[r];
-                        st_f1<OVL>(a.y + row, v);
+                        st_f1<OVL_ST>(a.y + row, v);
                         const unsigned long long k = argmax_key(v, (unsigned)row);
                         best = k > best ? k : best;
                     }
@@ -418,13 +422,13 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     const h8* rp0[NR];
     h8 w0[NR][U];
     row_ptrs(has_first ? g : a.n_groups - 1, rp0);   // idle waves (more waves than groups) load a valid row:
-    typename ProSelect<NS, PRO, NSP, WPB, OVL_LD, OVL>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
-    if (!OVL) pro.issue(a);
+    typename ProSelect<NS, PRO, NSP, WPB, OVL_LD, OVL_ST>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
+    if (!OVL_W) pro.issue(a);
     __builtin_amdgcn_sched_barrier(0);
     load_batch(rp0, 0, w0);
     __builtin_amdgcn_sched_barrier(0);
-    if (OVL) {       // the weights are on their way; now the predecessor has to be done before its outputs are touched
-        ovl_wait<THK_OVL_INV != 0>(a.ovl);
+    if (OVL_W) {     // the weights are on their way; now the predecessor has to be done before its outputs are touched
+        ovl_wait(a.ovl);
         pro.issue(a);
     }
     pro.finish(a, xs, red, ns, bid);
@@ -545,10 +549,10 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         if (threadIdx.x == 0) {
             unsigned long long b = wb[0];
             for (int w = 1; w < WPB; ++w) b = wb[w] > b ? wb[w] : b;
-            st_u64<OVL>(a.block_best + bid, b);
+            st_u64<OVL_ST>(a.block_best + bid, b);
         }
     }
-    if (OVL) ovl_arrive(a.ovl, bid);
+    if (OVL_A) ovl_arrive<WPB, EPI == EPI_HEAD>(a.ovl, bid);
 }
 // ---------------------------------------------------------------- attention (decode)
 // grid = H * nsplit blocks; block (h, s) owns positions [s*tc, (s+1)*tc) of head h.
@@ -577,14 +581,15 @@ __device__ __forceinline__ f4 ld_kv4(const float* base, size_t elem_off) {
     }
     return __builtin_nontemporal_load(reinterpret_cast<const f4*>(base + elem_off));
 }
-template <int D, int WAVES, bool KVH, bool OVL = false>
+template <int D, int WAVES, bool KVH, int OVL = 0>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     constexpr int LPP = D / 4;          // lanes per position
     constexpr int PPW = 64 / LPP;       // positions per wave-instruction
     constexpr int UB = 8;               // wave-instructions per batch (K and V each)
     __shared__ float sm_o[WAVES][D];
     __shared__ float sm_ml[WAVES][2];
-    constexpr bool OVL_LD = OVL && !THK_OVL_INV;
+    constexpr bool OVL_W = (OVL & OVL_WAIT) != 0, OVL_A = (OVL & OVL_ARRIVE) != 0;
+    constexpr bool OVL_LD = OVL_W, OVL_ST = OVL_A;
 
     // prefill: nq > 1 causal queries share one launch; query qi sits at position pos + qi
     const int per_q = a.H * a.nsplit;
@@ -594,7 +599,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPP, li = lane - grp * LPP;
     THK_STAMP(a.trace, bid, 0);
-    if (OVL) ovl_wait<THK_OVL_INV != 0>(a.ovl);
+    if (OVL_W) ovl_wait(a.ovl);
     const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + qi + 1;
     const int E = a.H * D;
     const int t0 = s * a.tc, t1 = min(t0 + a.tc, T);
@@ -607,7 +612,9 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     // wave w takes positions t0 + (it*WAVES + w)*PPW*UB + u*PPW + grp.  Loads are branch-free:
     // positions past the end are clamped to a valid row and masked out of the softmax.
     // (Round 3 tried fetching the first batch BEFORE the device-resident position is known - every row below n_ctx is
-    // allocated - to take the position's round trip off the critical path: 0.6 us per launch SLOWER on MI355X, removed.)
+    // allocated - to take the position's round trip off the critical path: 0.6 us per launch SLOWER on MI355X, removed.
+    // Same outcome under the overlapped dispatch, where the batch was requested before the wait for the predecessor and only
+    // the newest row fetched again afterwards: 2.5265 -> 2.5305 ms per 7B step.  Traffic added to a mat-vec's tail slows the tail.)
     for (int tb = t0 + wave * (PPW * UB); tb < t1; tb += WAVES * PPW * UB) {
         f4 kv[UB], vv[UB];
 #pragma unroll
@@ -661,14 +668,14 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
             L += sm_ml[w][1] * f; od += sm_o[w][d] * f;
         }
         if (a.out) {   // nsplit == 1: finished output, [H*D]
-            st_f1<OVL>(a.out + (size_t)qi * E + h * D + d, od / L);
+            st_f1<OVL_ST>(a.out + (size_t)qi * E + h * D + d, od / L);
         } else {       // split partial: combined by the consumer's prologue (ProAttn) or by attn_combine_kernel
-            st_f1<OVL>(a.part_o + (size_t)(h * a.nsplit + s) * D + d, od);
-            if (d == 0) { st_f1<OVL>(a.part_ml + (h * a.nsplit + s) * 2, M); st_f1<OVL>(a.part_ml + (h * a.nsplit + s) * 2 + 1, L); }
+            st_f1<OVL_ST>(a.part_o + (size_t)(h * a.nsplit + s) * D + d, od);
+            if (d == 0) { st_f1<OVL_ST>(a.part_ml + (h * a.nsplit + s) * 2, M); st_f1<OVL_ST>(a.part_ml + (h * a.nsplit + s) * 2 + 1, L); }
         }
     }
     THK_STAMP(a.trace, bid, 3);
-    if (OVL) ovl_arrive(a.ovl, bid);
+    if (OVL_A) ovl_arrive<WAVES, true>(a.ovl, bid);
 }
 
 // ---------------------------------------------------------------- the step's last launch
@@ -680,14 +687,14 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
 // epoch != NULL: the engine's tag epoch is bumped here, i.e. after the engine launch of this step and before the next.
 // OVL: waits for the head kernel (hence, transitively, for every launch of the step), then zeroes the step's arrival counters;
 // the next step's first packet carries the barrier bit, so nobody is polling them.
-template <bool OVL>
+template <int OVL>
 __device__ __forceinline__ void finish_token_body(const FinishArgs& a) {
     __shared__ unsigned long long sm[kBlock];
     THK_STAMP(a.trace, 0, 0);
-    if (OVL) ovl_wait<false>(a.ovl);
+    if (OVL & OVL_WAIT) ovl_wait(a.ovl);
     unsigned long long b = 0ull;
     for (int i = threadIdx.x; i < a.nblocks; i += kBlock) {
-        const unsigned long long k = OVL ? __hip_atomic_load(a.block_best + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.block_best[i];
+        const unsigned long long k = (OVL & OVL_WAIT) ? __hip_atomic_load(a.block_best + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.block_best[i];
         b = k > b ? k : b;
     }
     sm[threadIdx.x] = b;
@@ -696,7 +703,7 @@ __device__ __forceinline__ void finish_token_body(const FinishArgs& a) {
         if (threadIdx.x < s) { const unsigned long long o = sm[threadIdx.x + s]; if (o > sm[threadIdx.x]) sm[threadIdx.x] = o; }
         __syncthreads();
     }
-    if (OVL) {
+    if (OVL && a.ovl_counters) {       // any overlapped flavour: the step's arrival counters start from zero again
         for (int i = threadIdx.x; i < a.ovl_n_launches * kOvlShards; i += kBlock)
             __hip_atomic_store(a.ovl_counters + (size_t)(i / kOvlShards) * kOvlLaunchWords + (i % kOvlShards) * kOvlShardWords, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -124,14 +124,11 @@ __device__ __forceinline__ void st_u64(unsigned long long* p, unsigned long long
 }
 
 // The dependency protocol of the overlapped dispatch.  Every launch owns kOvlShards arrival counters, 128 bytes apart; a
-// workgroup that has drained its write-through stores adds one to shard (workgroup % kOvlShards).  A successor's workgroup
-// waits - after it has requested its first batch of weights, which depend on nothing - until the shards add up to the
-// predecessor's workgroup count: wave 0 polls (one shard per lane, summed with a butterfly), the other waves sit at the barrier.
+// workgroup that has drained its write-through stores adds its wave count to shard (workgroup % kOvlShards).  A successor's
+// workgroup waits - after it has requested its first batch of weights, which depend on nothing - until the shards add up to the
+// predecessor's wave count: wave 0 polls (one shard per lane, summed with a butterfly), the other waves sit at the barrier.
 // The counters are zeroed by the step's last launch.  A wait is bounded (0.5 s of the 100 MHz clock); the first one that expires
 // sets *err, and every later wait of the chain returns at once, so a broken chain ends in well under a second per step.
-// INV: once the predecessor is done the polling wave drops this CU's L1 and this XCD's clean L2 lines (buffer_inv sc1), so the
-// workgroup may read the predecessor's (written-through) outputs with plain, L2-cacheable loads.
-template <bool INV>
 __device__ __forceinline__ void ovl_wait(const OvlLink& L) {
     if ((threadIdx.x >> 6) == 0 && L.wait) {
         const int lane = threadIdx.x & 63;
@@ -141,23 +138,23 @@ __device__ __forceinline__ void ovl_wait(const OvlLink& L) {
                                            : (lane == kOvlShards ? __hip_atomic_load(L.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 24 : 0u);
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
             if (v >= L.wait_n) break;                                  // all arrived (or the chain is already broken: err << 24)
-            __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_s_sleep(8);                              // ~0.25 us between polls; s_sleep(2) measured 0.4 % slower
             if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
                 if (lane == 0) __hip_atomic_store(L.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 break;
             }
         }
-#if !defined(THK_OVL_INV) || THK_OVL_INV != 2      /* 2 = measurement only: plain loads WITHOUT the invalidate (wrong results possible) */
-        if (INV) asm volatile("buffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
-#endif
     }
     __syncthreads();
 }
+// Counters count WAVES (wait_n = workgroups x waves per workgroup); thread 0 arrives for the whole workgroup behind a barrier.
+// (Every wave arriving for itself, without the barrier, measured 0.2 % slower.)
+template <int WPB, bool BLOCK>
 __device__ __forceinline__ void ovl_arrive(const OvlLink& L, int bid) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every wave: its write-through stores have left
     __syncthreads();
     if (threadIdx.x == 0 && L.done)
-        (void)__hip_atomic_fetch_add(L.done + (bid & (kOvlShards - 1)) * kOvlShardWords, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_add(L.done + (bid & (kOvlShards - 1)) * kOvlShardWords, (unsigned)WPB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace thk

@@ -344,7 +344,7 @@ hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token
 // n_ctx > 0: the position only advances while pos + 1 < n_ctx, so a decode loop that outruns the host-side check
 // (thk_model_decode_step(s) refuse it) can never index the caches or the RoPE table out of bounds.
 // epoch != NULL: the engine's tag epoch is bumped here, i.e. after the engine launch of this step and before the next.
-__global__ __launch_bounds__(kBlock) void finish_token_kernel(const FinishArgs a) { finish_token_body<false>(a); }
+__global__ __launch_bounds__(kBlock) void finish_token_kernel(const FinishArgs a) { finish_token_body<0>(a); }
 hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
                                const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st, unsigned long long* trace,
                                unsigned long long* clock_log) {

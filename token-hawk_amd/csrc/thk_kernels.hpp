@@ -27,7 +27,7 @@ enum { GEMV_EPI_STORE = 0, GEMV_EPI_RESID = 1, GEMV_EPI_ROPE_KV = 2, GEMV_EPI_SW
 constexpr int kOvlShards = 16, kOvlShardWords = 32, kOvlLaunchWords = kOvlShards * kOvlShardWords;   // arrival counters of one launch
 struct OvlLink {
     const unsigned* wait;   // the predecessor's arrival counters; NULL = nothing to wait for (the packet carries the barrier bit)
-    unsigned wait_n;        // the predecessor's workgroup count
+    unsigned wait_n;        // what they add up to when it is done: its workgroups x waves per workgroup
     unsigned* done;         // this launch's arrival counters (NULL: nobody waits for it)
     int n_blocks;           // this launch's workgroup count (gridDim is a hidden argument the private queue does not fill)
     unsigned* err;          // set to 1 by a wait that expired

@@ -229,10 +229,10 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
     const float* xin = sb.hidden_in;
     // overlapped dispatch: while a step program is recorded every launch is linked to its predecessor's arrival counters
     int ovl_k = 0; const unsigned* ovl_prev = nullptr; unsigned ovl_prev_n = 0;
-    auto ovl_link = [&](OvlLink& L, int grid) {
+    auto ovl_link = [&](OvlLink& L, int grid, int waves_per_block = kWaves) {       // arrival counters count waves
         if (!m->ovl_rec) return;
         L.wait = ovl_prev; L.wait_n = ovl_prev_n; L.done = m->ovl_counters + (size_t)ovl_k * kOvlLaunchWords; L.n_blocks = grid; L.err = m->ovl_err;
-        ovl_prev = L.done; ovl_prev_n = (unsigned)grid; ++ovl_k;
+        ovl_prev = L.done; ovl_prev_n = (unsigned)(grid * waves_per_block); ++ovl_k;
     };
     int trace_k = 0;                                     // development timeline (thk_model_step_trace): one [kTraceBlocks][8][4] slab per launch
     auto trace_slab = [&]() -> unsigned long long* { return m->trace_on ? m->trace_buf + (size_t)(trace_k++) * kTraceBlocks * kTraceWords : nullptr; };
@@ -293,7 +293,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.x = m->attn_out; a.part_o = m->part_o; a.part_ml = m->part_ml; a.H = H; a.D = D; a.nsplit = m->nsplit;
             a.resid = xr_in; a.y = m->x;
             t.trace = trace_slab();
-            if (m->skip_kernel != 2) ovl_link(t.ovl, H * m->nsplit);
+            if (m->skip_kernel != 2) ovl_link(t.ovl, H * m->nsplit, m->attn_waves);
             MARK("attn_decode");
             if (m->skip_kernel != 2) HIPCHK(ctx, launch_attn_decode(t, st));
             a.trace = trace_slab();

@@ -20,6 +20,7 @@
 #include "thk_internal.hpp"
 
 #include <dlfcn.h>
+#include <stddef.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
 
@@ -227,14 +228,40 @@ static int build_program(thk_model* m, int seq, OvlQueue* Q) {
     m->ovl_rec = false;
     if (rc != THK_OK) return rc;
     if (rec.overflow || rec.n < 3) return fail(ctx, THK_ERR_STATE, "overlapped dispatch: recording the step failed (%d launches)", rec.n);
+    // Which packets keep the barrier bit (tunable overlap_keep_barrier, a mask over launch kinds: 1 qkv, 2 attention, 4 wo,
+    // 8 w1|w3, 16 w2, 32 lm-head, 64 greedy pick; the step's first packet always does).  A launch behind a barrier packet is the
+    // plain kernel; one whose own packet has no barrier bit waits inside (flavour bit 1); one whose SUCCESSOR has none writes
+    // through and arrives (bit 2).  Fences follow: a barrier packet acquires at agent scope, and whatever runs before a barrier
+    // packet releases at agent scope; between two launches joined by the in-kernel protocol there is no fence at all (measured:
+    // with an acquire on the waiting launch the command processor starts it ~2 us later).  That is safe because after the
+    // barrier packet's invalidate the only plain loads of a waiting kernel are of data nobody writes during the step (weights,
+    // gains, RoPE table, embedding row, position and token); everything an earlier launch of the step wrote it reads with
+    // agent-coherent loads, and every launch has made its outputs visible in memory by its end (written through, or released).
+    const int keep = (int)tun(ctx, "overlap_keep_barrier");
+    std::vector<int> kind(rec.n, 64), barrier(rec.n + 1, 1);
+    for (int i = 0; i < rec.n; ++i) {
+        int nr, u, ns, pro, epi, nsp, pipe;
+        if (!strncmp(store[i].name, "thk_ovl_attn", 12)) kind[i] = 2;
+        else if (sscanf(store[i].name, "thk_ovl_gemv_%d_%d_%d_%d_%d_%d_%d", &nr, &u, &ns, &pro, &epi, &nsp, &pipe) == 7)
+            kind[i] = epi == GEMV_EPI_ROPE_KV ? 1 : epi == GEMV_EPI_SWIGLU ? 8 : epi == GEMV_EPI_HEAD ? 32 : pro == GEMV_PRO_ATTN ? 4 : 16;
+        barrier[i] = (i == 0 || (keep & kind[i])) ? 1 : 0;
+    }
     OvlProgram* P = new OvlProgram();
     std::vector<OvlKernel> ks(rec.n);
     size_t bytes = 0;
     std::vector<size_t> off(rec.n);
     for (int i = 0; i < rec.n; ++i) {
-        const int r = load_kernel(ctx, Q, store[i].name, &ks[i]);
+        const int flavour = (barrier[i] ? 0 : 1) | ((barrier[i + 1] || i == rec.n - 1) ? 0 : 2);
+        char name[96];
+        snprintf(name, sizeof name, "%s_f%d", store[i].name, flavour);
+        const int r = load_kernel(ctx, Q, name, &ks[i]);
         if (r != THK_OK) { delete P; return r; }
-        if ((int)ks[i].kernarg < store[i].arg_bytes) { delete P; return fail(ctx, THK_ERR_STATE, "overlapped dispatch: %s takes %u argument bytes, the host recorded %d", store[i].name, ks[i].kernarg, store[i].arg_bytes); }
+        if ((int)ks[i].kernarg < store[i].arg_bytes) { delete P; return fail(ctx, THK_ERR_STATE, "overlapped dispatch: %s takes %u argument bytes, the host recorded %d", name, ks[i].kernarg, store[i].arg_bytes); }
+        // the recorded link names both neighbours; a side that is ordered by a barrier packet is cut
+        const size_t link_at = kind[i] == 2 ? offsetof(AttnArgs, ovl) : kind[i] == 64 ? offsetof(FinishArgs, ovl) : offsetof(GemvArgs, ovl);
+        OvlLink* L = reinterpret_cast<OvlLink*>(store[i].args + link_at);
+        if (!(flavour & 1)) { L->wait = nullptr; L->wait_n = 0; }
+        if (!(flavour & 2)) L->done = nullptr;
         off[i] = bytes;
         bytes += ((size_t)ks[i].kernarg + 255) / 256 * 256;
     }
@@ -244,12 +271,11 @@ static int build_program(thk_model* m, int seq, OvlQueue* Q) {
     if (hipMemcpy(P->kargs, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { hipFree(P->kargs); delete P; return fail(ctx, THK_ERR_HIP, "overlapped dispatch: uploading the kernel arguments failed"); }
     for (int i = 0; i < rec.n; ++i) {
         P->packets.push_back(make_packet(ks[i], store[i].grid, store[i].block, store[i].lds_dynamic, (char*)P->kargs + off[i]));
-        // the step's first packet waits for everything before it (the previous step's bookkeeping, or the batch gate); the last one
-        // (plain stores of the sequence state) releases at agent scope; nothing in between needs a fence at its end: what crosses a
-        // launch is written through
-        static const bool all_barriers = getenv("THK_OVL_BARRIER") != nullptr;      // development: the overlapped kernels behind ordinary barrier packets
-        static const int acq_inner = getenv("THK_OVL_ACQ") ? atoi(getenv("THK_OVL_ACQ")) : HSA_FENCE_SCOPE_AGENT;     // development: acquire scope of the packets inside a step
-        P->headers.push_back(make_header(i == 0 || all_barriers, (i == 0 || all_barriers) ? HSA_FENCE_SCOPE_AGENT : acq_inner, (i == rec.n - 1 || all_barriers) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE));
+        bool acq = barrier[i] != 0, rel = barrier[i + 1] != 0;
+        static const int fence_cut = getenv("THK_OVL_NOFENCE") ? atoi(getenv("THK_OVL_NOFENCE")) : 0;   // measurement only (results undefined): 1 no fences, 2 no releases, 3 no acquires inside a step
+        if (fence_cut && i != 0) acq = acq && fence_cut == 2;
+        if (fence_cut && i != rec.n - 1) rel = rel && fence_cut == 3;
+        P->headers.push_back(make_header(barrier[i] != 0, acq ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE, rel ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE));
     }
     sb.ovl_prog = P;
     return THK_OK;

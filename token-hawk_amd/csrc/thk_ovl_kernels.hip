@@ -11,26 +11,30 @@
 
 using namespace thk;
 
+#define OVL_GEMV_F(NR, U, NS, PRO, EPI, NSP, PIPE, F)                                                                      \
+    extern "C" __global__ __launch_bounds__(256) void thk_ovl_gemv_##NR##_##U##_##NS##_##PRO##_##EPI##_##NSP##_##PIPE##_f##F(const GemvArgs a) { \
+        gemv_body<NR, U, NS, PRO, EPI, true, NSP, (PIPE) != 0, 4, OVL_QUEUE | F>(a, blockIdx.x, a.ovl.n_blocks);               \
+    }
+// four flavours of every instantiation: f0 behind a barrier packet and followed by one (plain accesses), f1 waits for its
+// predecessor inside, f2 arrives for its successor, f3 both (thk_decode_bodies.hpp: OVL_WAIT = 1, OVL_ARRIVE = 2)
 #define OVL_GEMV(NR, U, NS, PRO, EPI, NSP, PIPE)                                                                            \
-    extern "C" __global__ __launch_bounds__(256) void thk_ovl_gemv_##NR##_##U##_##NS##_##PRO##_##EPI##_##NSP##_##PIPE(const GemvArgs a) { \
-        gemv_body<NR, U, NS, PRO, EPI, true, NSP, (PIPE) != 0, 4, true>(a, blockIdx.x, a.ovl.n_blocks);                    \
+    OVL_GEMV_F(NR, U, NS, PRO, EPI, NSP, PIPE, 0) OVL_GEMV_F(NR, U, NS, PRO, EPI, NSP, PIPE, 1)                                 \
+    OVL_GEMV_F(NR, U, NS, PRO, EPI, NSP, PIPE, 2) OVL_GEMV_F(NR, U, NS, PRO, EPI, NSP, PIPE, 3)
+#define OVL_ATTN_F(D, WAVES, KVH, F)                                                                                        \
+    extern "C" __global__ __launch_bounds__(WAVES * 64) void thk_ovl_attn_##D##_##WAVES##_##KVH##_f##F(const AttnArgs a) {  \
+        attn_body<D, WAVES, (KVH) != 0, OVL_QUEUE | F>(a, blockIdx.x);                                                       \
     }
-#define OVL_ATTN(D, WAVES, KVH)                                                                                             \
-    extern "C" __global__ __launch_bounds__(WAVES * 64) void thk_ovl_attn_##D##_##WAVES##_##KVH(const AttnArgs a) {         \
-        attn_body<D, WAVES, (KVH) != 0, true>(a, blockIdx.x);                                                              \
-    }
+#define OVL_ATTN(D, WAVES, KVH) OVL_ATTN_F(D, WAVES, KVH, 0) OVL_ATTN_F(D, WAVES, KVH, 1) OVL_ATTN_F(D, WAVES, KVH, 2) OVL_ATTN_F(D, WAVES, KVH, 3)
 
 // PRO: 0 copy, 1 RMSNorm, 2 attention combine, 3 RMSNorm of the embedding row; EPI: 1 residual, 2 RoPE + K/V append, 3 SwiGLU, 4 lm-head
 // LLaMA-7B widths (4096 / 11008 columns): thk_ctx.cpp auto_geometry's variants + the neighbours worth sweeping
 OVL_GEMV(2, 8, 8, 1, 2, 0, 1)   OVL_GEMV(2, 8, 8, 3, 2, 0, 1)       // qkv (pipelined row pair), with the embedding fold
-OVL_GEMV(2, 8, 8, 1, 2, 0, 0)   OVL_GEMV(2, 8, 8, 3, 2, 0, 0)       // qkv, batch loop
 OVL_GEMV(1, 8, 8, 2, 1, 4, 1)   OVL_GEMV(1, 8, 8, 2, 1, 2, 1)  OVL_GEMV(1, 8, 8, 2, 1, 8, 1)      // wo, 4 / 2 / 8 attention splits
 OVL_GEMV(2, 8, 8, 1, 3, 0, 1)                                       // w1 | w3
 OVL_GEMV(1, 22, 22, 0, 1, 0, 0) OVL_GEMV(1, 22, 22, 0, 1, 0, 1)     // w2
 OVL_GEMV(1, 8, 8, 1, 4, 0, 1)   OVL_GEMV(2, 8, 8, 1, 4, 0, 0)       // lm-head
 // LLaMA-13B widths (5120 / 13824 columns)
 OVL_GEMV(2, 10, 10, 1, 2, 0, 0) OVL_GEMV(2, 10, 10, 3, 2, 0, 0)     // qkv
-OVL_GEMV(2, 10, 10, 1, 2, 0, 1) OVL_GEMV(2, 10, 10, 3, 2, 0, 1)
 OVL_GEMV(1, 10, 10, 2, 1, 4, 1) OVL_GEMV(1, 10, 10, 2, 1, 2, 1) OVL_GEMV(1, 10, 10, 2, 1, 8, 1)   // wo
 OVL_GEMV(2, 10, 10, 1, 3, 0, 1)                                     // w1 | w3
 OVL_GEMV(1, 27, 27, 0, 1, 0, 1) OVL_GEMV(1, 27, 27, 0, 1, 0, 0)     // w2
@@ -38,7 +42,8 @@ OVL_GEMV(2, 5, 10, 1, 4, 0, 0)  OVL_GEMV(1, 10, 10, 1, 4, 0, 1)     // lm-head
 
 OVL_ATTN(128, 8, 0) OVL_ATTN(128, 4, 0) OVL_ATTN(128, 8, 1) OVL_ATTN(128, 4, 1)
 
-extern "C" __global__ __launch_bounds__(256) void thk_ovl_finish_token(const FinishArgs a) { finish_token_body<true>(a); }
+extern "C" __global__ __launch_bounds__(256) void thk_ovl_finish_token_f0(const FinishArgs a) { finish_token_body<OVL_QUEUE>(a); }
+extern "C" __global__ __launch_bounds__(256) void thk_ovl_finish_token_f1(const FinishArgs a) { finish_token_body<OVL_QUEUE | OVL_WAIT>(a); }
 
 // ---- ordering against the HIP stream (thk_ovl.cpp): words[0] = ticket written by a HIP kernel of the ctx stream, words[32] =
 // batches this queue has completed, words[64] = error word.

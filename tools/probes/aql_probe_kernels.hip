@@ -28,7 +28,8 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 ld_f4_agent(const float* base, unsigned byte_off) {
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 1 << 20, 0x00020000);
     const u4v t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /* sc1 */);
-    return f4{__builtin_bit_cast(float, t.x), __builtin_bit_cast(float, t.y), __builtin_bit_cast(float, t.z), __builtin_bit_cast(float, t.w)};
+    return __builtin_bit_cast(f4, t);     // whole-vector cast: __builtin_bit_cast of ONE element of an ext_vector (t.y ...) reads element 0 with this
+                                          // toolchain, which made the first version of this probe fetch 4 of every 16 bytes (results of 27 Sep, see profiles/)
 }
 
 struct ProbeArgs {
