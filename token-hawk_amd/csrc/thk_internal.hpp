@@ -1,7 +1,9 @@
-// thk_internal.hpp — shared by the three translation units that implement include/thk.h:
-//   thk_ctx.cpp    context, tunables, buffers (TensorBuffer's GPU half, th.cpp:150-229)
-//   thk_ops.cpp    one operator per reference kernel (the 16 cmdbuf_* encoders, th.cpp:617-4351)
-//   thk_model.cpp  model level: th_eval_gpu (th-llama.cpp:464-660) as graph replays / the engine, prefill, pipeline stages
+// thk_internal.hpp — shared by the host-side translation units that implement include/thk.h:
+//   thk_ctx.cpp            context, tunables, buffers (TensorBuffer's GPU half, th.cpp:150-229)
+//   thk_ops.cpp            one operator per reference kernel (the 16 cmdbuf_* encoders, th.cpp:617-4351)
+//   thk_model.cpp          model level: th_eval_gpu (th-llama.cpp:464-660) as hipGraph replays, per-sequence state, pipeline stages
+//   thk_model_prefill.cpp  MFMA prompt prefill; thk_model_engine.cpp  the optional one-launch engine's program
+//   thk_ovl.cpp            the optional overlapped dispatch (private AQL queue); thk_pp.cpp / thk_peer.hip  stage-to-stage transports
 // Internal; not part of the ABI.
 #pragma once
 #include "../../include/thk.h"

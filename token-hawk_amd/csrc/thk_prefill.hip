@@ -179,13 +179,6 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
     };
 
     // ---- software pipeline across chunks --------------------------------------------------------------------------
-    // While the matrix pipe works through chunk g out of REGISTERS (fragment set `cur`), the same instruction stream, between
-    // the MFMAs, (1) waits for chunk g+1's DMA and meets the other waves at the one barrier per chunk, (2) reads chunk g+1's
-    // fragments into the other register set, (3) issues the DMA of chunk g+NST into the stage chunk g just vacated.
-    // The r02 phase trace of the unpipelined loop (profiles/r02_prefill_phase_trace.txt): per chunk 1024 cycles of MFMA but
-    // ~450 of DMA issue (all four waves hit the CU's one address unit together after the barrier), ~250 of exposed
-    // fragment-read latency and ~300 of waitcnt + barrier, none of it overlapped with the matrix pipe (one wave per SIMD).
-    // ---- software pipeline across chunks --------------------------------------------------------------------------
     // While the matrix pipe works through chunk g out of REGISTERS (one fragment set), the same instruction stream, between
     // the MFMAs, (1) waits for chunk g+1's DMA and meets the other waves at the one barrier per chunk, (2) reads chunk g+1's
     // fragments into the other register set, (3) issues the DMA of chunk g+NST into the stage chunk g just vacated.

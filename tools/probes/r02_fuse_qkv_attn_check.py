@@ -1,4 +1,5 @@
-"""Bring-up of the fused qkv+attention launch: tiny parity vs oracle (fuse on/off), 7B greedy agreement and timing."""
+"""Bring-up script of the round-2 fused qkv+attention experiment: runs only with tools/probes/r02_fuse_qkv_attn_experiment.patch applied (its
+tunables fuse_qkv_* do not exist in the library).  Tiny parity vs oracle (fuse on/off), 7B greedy agreement and timing."""
 import sys, os, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
