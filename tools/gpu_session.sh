@@ -18,6 +18,7 @@ for s in "$@"; do
     bench13) timeout 900 python bench.py --model 13b --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_13b.json 2> $O/bench_13b.err; echo "bench13 exit $?"; cut -c1-300 $O/bench_13b.json ;;
     prefill) timeout 600 python tools/bench_prefill.py 7b 128 > $O/prefill.json 2> $O/prefill.err; echo "prefill exit $?"; cat $O/prefill.json ;;
     profprefill) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_prefill" -o r03 -- python "$R/tools/bench_prefill.py" 7b 128 prefill-only > "$R/$O/prof_prefill.json" 2> "$R/$O/prof_prefill.err"); echo "profprefill exit $?"; f=$(find $O/prof_prefill -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/prefill_kernel_stats.csv && head -20 "$f" | cut -c1-200 ;;
+    pmcprefill) for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do t=$(echo $pass | cut -d" " -f1); (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$R/$O/pmc_pf_$t" -o p -- python "$R/tools/bench_prefill.py" 7b 128 prefill-only > /dev/null 2> "$R/$O/pmc_pf_$t.err"); echo "pmc pass $t exit $?"; f=$(find $O/pmc_pf_$t -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python tools/pmc_table.py "$f" gemm_prefill reduce_ ximg attn_prefill > $O/pmc_prefill_$t.csv 2>> "$R/$O/pmc_pf_$t.err" && cat $O/pmc_prefill_$t.csv | cut -c1-400; rm -rf $O/pmc_pf_$t; done ;;
     trace:*) n=$(echo "${s#trace:}" | tr -c 'a-zA-Z0-9_=' '_'); THK_LIB=$R/token-hawk_amd/libthk_trace.so timeout 300 python tools/step_trace.py $(echo "${s#trace:}" | tr '+' ' ') > $O/trace_$n.txt 2> $O/trace_$n.err; echo "trace exit $?"; cat $O/trace_$n.txt; cp gpurun_out/step_trace.json $O/trace_$n.json 2>/dev/null ;;
     profcfg:*) n=$(echo "${s#profcfg:}" | tr -c 'a-zA-Z0-9_=' '_'); (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_$n" -o p -- python "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile $(for t in $(echo "${s#profcfg:}" | tr '+' ' '); do [ "$t" != base ] && echo --tunable $t; done) > "$R/$O/prof_$n.json" 2> "$R/$O/prof_$n.err"); echo "profcfg exit $?"; f=$(find $O/prof_$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/kernel_stats_$n.csv && head -12 "$f" | cut -c1-160 ;;
     sh:*) bash -c "${s#sh:}" ;;
