@@ -3,11 +3,15 @@
 // A HIP stream (and a hipGraph replay of it) sets the AQL barrier bit on every kernel packet: a launch is not even placed on the
 // CUs before its predecessor's last wave has retired, and on MI355X that boundary costs ~1.3 us of idle chip plus the ~1.8 us
 // ramp of the next launch, 162 times per LLaMA-7B token.  Here the same 162 launches are written as AQL packets
-// to a user-mode queue of our own with the barrier bit CLEARED: the command processor places a kernel's workgroups as soon as its
-// predecessor's have all been placed, every wave requests its first batch of weights (they depend on nothing), and the dependency
-// itself is enforced inside the kernels (thk_device.hpp: sharded arrival counters, agent-coherent accesses for everything that
-// crosses a launch; kernels in thk_ovl_kernels.hip -> libthk_ovl.hsaco, loaded with the HSA runtime).  Only the first packet of a
-// step keeps the bit, so a step starts after the previous one has completely finished (its last launch zeroes the counters).
+// to a user-mode queue of our own, and chosen packets (tunable overlap_keep_barrier) go WITHOUT the barrier bit: the command
+// processor may place such a kernel's workgroups while its predecessor still runs, every wave requests its first batch of
+// weights (they depend on nothing), and the dependency itself is enforced inside the kernels (thk_device.hpp: sharded arrival
+// counters, agent-coherent accesses for everything that crosses a launch; kernels in thk_ovl_kernels.hip -> libthk_ovl.hsaco,
+// loaded with the HSA runtime).  A step's first packet always keeps the bit, so a step starts after the previous one has
+// completely finished (its last launch zeroes the counters).
+// MEASURED OUTCOME (profiles/r03_overlap_ab.txt): equal results, not faster than hipGraph replays - the command
+// processor starts a barrier-free successor only in its predecessor's last microseconds and the protocol costs what that buys.
+// The option stays for experiments; the default mask overlaps the two boundaries that gain (wo -> w1|w3, w2 -> qkv).
 //
 // The queue is ordered against the ctx stream with two pairs of tiny kernels: the stream writes a ticket that the batch's first
 // packet waits for, the batch's last packet bumps a counter that a kernel enqueued on the stream waits for.  So
