@@ -31,8 +31,6 @@ void default_tunables(thk_ctx* ctx) {
     ctx->tun["attn_splits"] = 4;          // context splits per head (1,2,4,8)
     ctx->tun["attn_waves"] = 8;           // waves per attention block (4 or 8)
     ctx->tun["fold_embed"] = 1;           // the embedding row is fetched by layer 0's qkv prologue instead of a launch of its own
-    ctx->tun["attn_fork"] = 0;            // decode step: q mat-vec first, then attention over the cache rows of EARLIER steps on a side stream beside the k | v
-                                          // mat-vec (a fork / join in the captured graph); wo's prologue merges the row appended in this step (round-3 experiment)
     ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
     ctx->tun["overlap_dispatch"] = 0;     // thk_model_decode_step(s): the step's launches as AQL packets WITHOUT the barrier bit on a queue of our own,
                                           // dependencies enforced inside the kernels (thk_ovl.cpp); read at every call, so it can be switched between calls
@@ -152,7 +150,6 @@ extern "C" int thk_ctx_destroy(thk_ctx* ctx) {
     ovl_destroy(ctx);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->rope_tab) hipFree(ctx->rope_tab);
-    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return THK_OK;

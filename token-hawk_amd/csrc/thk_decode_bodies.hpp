@@ -154,7 +154,7 @@ struct ProRms {
             for (int k = 0; k < KP; ++k) {
                 const int i = threadIdx.x + k * BT;
                 if ((i << 2) >= C) v[k] = f4{0.f, 0.f, 0.f, 0.f};
-                else if (EMB && bid == 0 && a.x_out) st_f4<COHS>(a.x_out, i << 2, v[k]);
+                else if (EMB && bid == 0) st_f4<COHS>(a.x_out, i << 2, v[k]);
                 ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
             }
             ss = block_sum<WPB>(ss, red);
@@ -173,7 +173,7 @@ struct ProRms {
                 f4 t = {0.f, 0.f, 0.f, 0.f};
                 if ((i << 2) < C) {
                     t = ldx(a, row, i << 2);
-                    if (EMB && bid == 0 && a.x_out) st_f4<COHS>(a.x_out, i << 2, t);
+                    if (EMB && bid == 0) st_f4<COHS>(a.x_out, i << 2, t);
                 }
                 ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
                 *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = t;   // raw copy, normalised below
@@ -207,40 +207,12 @@ __device__ __forceinline__ f4 attn_merge(const float2 (&ml)[NSP], const f4 (&ov)
     }
     return o * (1.0f / L);
 }
-// NEWROW: the partials cover cache rows [0, pos) only (the attention launch ran beside the k | v mat-vec that appends row pos);
-// this prologue adds the newest row itself: score_h = (q_h . k_new_h) * scale for every head (8 threads per head, 16 dims each),
-// then one more "split" (m = score, l = 1, o = v_new) goes into the merge.
-template <int NS, int NSP, int WPB, bool COH, bool NEWROW = false>
+template <int NS, int NSP, int WPB, bool COH>
 struct ProAttn {
     static constexpr int KP = PrologueK<NS, WPB>::value;
     static constexpr int BT = WPB * 64;
     float2 ml[KP][NSP];
     f4 ov[KP][NSP];
-    f4 vn[KP];                                   // NEWROW: the newest V row's elements of this thread
-    __device__ __forceinline__ f4 ld_new4(const GemvArgs& a, const float* base, int e) {     // 4 elements of the newest K or V row (f32 or f16 cache)
-        if (a.kv_f16) {
-            const h4 h = *reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(base) + e);
-            return f4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-        }
-        return ld_f4<COH>(base, e);
-    }
-    // every head's score against the newest row -> sc[h] (LDS); all threads call it; ends with a barrier
-    __device__ __forceinline__ void new_row_scores(const GemvArgs& a, float* sc) {
-        const int pos = *a.pos_ptr;
-        const size_t row = (size_t)pos * a.E * (a.kv_f16 ? 2 : 4);
-        const float* kn = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.kcache) + row);
-        for (int h = threadIdx.x >> 3; h < a.H; h += BT >> 3) {
-            float d = 0.f;
-            const int e0 = h * a.D + (threadIdx.x & 7) * (a.D >> 3);
-            for (int i = 0; i < (a.D >> 3); i += 4) {
-                const f4 q = ld_f4<COH>(a.q, e0 + i), k = ld_new4(a, kn, e0 + i);
-                d += q.x * k.x + q.y * k.y + q.z * k.z + q.w * k.w;
-            }
-            d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
-            if ((threadIdx.x & 7) == 0) sc[h] = d * a.scale;
-        }
-        __syncthreads();
-    }
     __device__ __forceinline__ void load1(const GemvArgs& a, int e, float2 (&m)[NSP], f4 (&o)[NSP]) {
         const int h = e / a.D, d = e - h * a.D;
 #pragma unroll
@@ -251,51 +223,23 @@ struct ProAttn {
     }
     __device__ __forceinline__ void issue(const GemvArgs& a) {
         if (NS == 0) return;
-        const float* vnew = NEWROW ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.vcache) + (size_t)(*a.pos_ptr) * a.E * (a.kv_f16 ? 2 : 4)) : nullptr;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) {
-            const int e = min((int)(threadIdx.x + k * BT) << 2, a.C - 4);
-            load1(a, e, ml[k], ov[k]);
-            if (NEWROW) vn[k] = ld_new4(a, vnew, e);
-        }
+        for (int k = 0; k < KP; ++k) load1(a, min((int)(threadIdx.x + k * BT) << 2, a.C - 4), ml[k], ov[k]);
     }
-    // merge of the NSP splits plus (NEWROW) the newest row: same online-softmax combine, one more term
-    __device__ __forceinline__ f4 merge_new(const float2 (&m)[NSP], const f4 (&o)[NSP], float s_new, f4 v_new) {
-        float M = s_new;
-#pragma unroll
-        for (int s = 0; s < NSP; ++s) M = fmaxf(M, m[s].x);
-        const float en = expf(s_new - M);
-        float L = en; f4 acc = v_new * en;
-#pragma unroll
-        for (int s = 0; s < NSP; ++s) {
-            const float scl = (m[s].x == -INFINITY) ? 0.f : expf(m[s].x - M);
-            L += m[s].y * scl; acc += o[s] * scl;
-        }
-        return acc * (1.0f / L);
-    }
-    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float* red, int ns, int) {
+    __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns, int) {
         const int C = a.C;
-        float* sc = red + 32;                     // NEWROW: one score per head (behind the reduction / head scratch; the launcher sizes LDS for it)
-        if (NEWROW) new_row_scores(a, sc);
         if (NS != 0) {
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
                 const int i = threadIdx.x + k * BT;
-                f4 res;
-                if (NEWROW) res = merge_new(ml[k], ov[k], sc[min(i << 2, C - 4) / a.D], vn[k]);
-                else res = attn_merge<NSP>(ml[k], ov[k]);
+                f4 res = attn_merge<NSP>(ml[k], ov[k]);
                 if ((i << 2) >= C) res = f4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = res;
             }
         } else {
-            const float* vnew = NEWROW ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.vcache) + (size_t)(*a.pos_ptr) * a.E * (a.kv_f16 ? 2 : 4)) : nullptr;
             for (int i = threadIdx.x; i < (ns << 7); i += BT) {
                 f4 res = {0.f, 0.f, 0.f, 0.f};
-                if ((i << 2) < C) {
-                    float2 m[NSP]; f4 o[NSP]; load1(a, i << 2, m, o);
-                    if (NEWROW) res = merge_new(m, o, sc[(i << 2) / a.D], ld_new4(a, vnew, i << 2));
-                    else res = attn_merge<NSP>(m, o);
-                }
+                if ((i << 2) < C) { float2 m[NSP]; f4 o[NSP]; load1(a, i << 2, m, o); res = attn_merge<NSP>(m, o); }
                 *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = res;
             }
         }
@@ -307,10 +251,9 @@ template <int NS, int PRO, int NSP, int WPB, bool COH, bool COHS> struct ProSele
 template <int NS, int NSP, int WPB, bool COH, bool COHS> struct ProSelect<NS, GEMV_PRO_RMS, NSP, WPB, COH, COHS> { typedef ProRms<NS, false, WPB, COH, COHS> type; };
 template <int NS, int NSP, int WPB, bool COH, bool COHS> struct ProSelect<NS, GEMV_PRO_RMS_EMBED, NSP, WPB, COH, COHS> { typedef ProRms<NS, true, WPB, COH, COHS> type; };
 template <int NS, int NSP, int WPB, bool COH, bool COHS> struct ProSelect<NS, GEMV_PRO_ATTN, NSP, WPB, COH, COHS> { typedef ProAttn<NS, (NSP > 0 ? NSP : 1), WPB, COH> type; };
-template <int NS, int NSP, int WPB, bool COH, bool COHS> struct ProSelect<NS, GEMV_PRO_ATTN_NEW, NSP, WPB, COH, COHS> { typedef ProAttn<NS, (NSP > 0 ? NSP : 1), WPB, COH, true> type; };
 
 // ---------------------------------------------------------------- GEMV core
-enum { PRO_COPY = GEMV_PRO_COPY, PRO_RMS = GEMV_PRO_RMS, PRO_ATTN = GEMV_PRO_ATTN, PRO_RMS_EMBED = GEMV_PRO_RMS_EMBED, PRO_ATTN_NEW = GEMV_PRO_ATTN_NEW };
+enum { PRO_COPY = GEMV_PRO_COPY, PRO_RMS = GEMV_PRO_RMS, PRO_ATTN = GEMV_PRO_ATTN, PRO_RMS_EMBED = GEMV_PRO_RMS_EMBED };
 enum { EPI_STORE = GEMV_EPI_STORE, EPI_RESID = GEMV_EPI_RESID, EPI_ROPE_KV = GEMV_EPI_ROPE_KV, EPI_SWIGLU = GEMV_EPI_SWIGLU,
        EPI_HEAD = GEMV_EPI_HEAD };
 
@@ -357,7 +300,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     // row pointers of group g (wave-uniform; independent of the activation vector)
     auto row_ptrs = [&](int g, const h8* (&rp)[NR]) {
         if (EPI == EPI_ROPE_KV) {
-            const int r0 = 2 * (g + a.g0), which = r0 / a.E, rr = r0 - which * a.E;     // g0: a launch may cover only the q rows, or only k | v
+            const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E;
             const uint16_t* base = which == 0 ? a.W[0] : (which == 1 ? a.W[1] : a.W[2]);
             rp[0] = reinterpret_cast<const h8*>(base + (size_t)rr * C);
             rp[1 % NR] = reinterpret_cast<const h8*>(base + (size_t)(rr + 1) * C);
@@ -414,7 +357,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
 #pragma unroll
             for (int r = 0; r < NR; ++r) eo.resid[r] = ld_f1<OVL_LD>(a.resid + min(NR * g + r, a.R - 1));      // wave-uniform address: one request
         } else if (EPI == EPI_ROPE_KV) {
-            const int r0 = 2 * (g + a.g0), which = r0 / a.E, rr = r0 - which * a.E, j = rr % a.D;
+            const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E, j = rr % a.D;
             const float2 t = *reinterpret_cast<const float2*>(a.rope_tab + ((size_t)pos_pipe * (a.D >> 1) + (j >> 1)) * 2);
             eo.cs = t.x; eo.sn = t.y;
         }
@@ -435,7 +378,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         } else if (EPI == EPI_ROPE_KV) {     // K6 th.cpp:1476-1490 + K/V append th-llama.cpp:332-339
             if (lane == 0) {
                 const int pos = PIPE ? pos_pipe : (a.pos_ptr ? *a.pos_ptr : a.pos_val);
-                const int r0 = 2 * (g + a.g0), which = r0 / a.E, rr = r0 - which * a.E;
+                const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E;
                 float y0 = acc[0], y1 = acc[1 % NR];
                 if (which < 2) {
                     const int j = rr % a.D;    // even
@@ -657,7 +600,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     const int grp = lane / LPP, li = lane - grp * LPP;
     THK_STAMP(a.trace, bid, 0);
     if (OVL_W) ovl_wait(a.ovl);
-    const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + qi + 1 - a.excl_newest;   // excl_newest: rows [0, pos) only - the row being appended right now is merged by the consumer (ProAttn NEWROW)
+    const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + qi + 1;
     const int E = a.H * D;
     const int t0 = s * a.tc, t1 = min(t0 + a.tc, T);
 

@@ -42,7 +42,6 @@ struct thk_ctx {
     size_t scratch_bytes = 0;
     float* rope_tab = nullptr;      // operator-API RoPE table
     size_t rope_tab_floats = 0;
-    hipStream_t stream2 = nullptr;  // side stream of the forked decode step (tunable attn_fork): attention over the old cache rows runs beside the k | v mat-vec
     void* ovl = nullptr;            // overlapped dispatch: the private queue and its code object (thk_ovl.cpp), created on first use
 };
 
@@ -106,9 +105,6 @@ struct thk_model {
     int gain_alias = 0;    // measurement aid (tunable measure_gain_alias)
     int skip_kernel = 0;   // measurement aid (tunable measure_skip_kernel): 1 qkv, 2 attention, 3 wo, 4 w13, 5 w2, 6 lm-head are NOT launched
     // persistent loader/consumer engine (thk_engine.hip): one launch per decode step instead of 5 per layer
-    int attn_fork = 0;                   // tunable attn_fork at finalize: q first, then attention over rows [0, pos) on a side stream BESIDE the k | v mat-vec; wo merges row pos
-    int grid_q = 0, grid_kv = 0;
-    std::vector<hipEvent_t> fork_ev;     // two per local layer
     int fold_embed = 1;                  // tunable fold_embed: layer 0's qkv prologue fetches the embedding row (no embed launch)
     int kv_f16 = 0;                      // tunable kv_f16 at finalize: K/V caches stored as binary16 (default 0 = f32, as the reference)
     int engine = 0;                      // resolved at finalize (tunable "engine" and shape eligibility)

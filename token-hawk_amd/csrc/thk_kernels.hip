@@ -45,7 +45,7 @@ __global__ __launch_bounds__(WPB * 64) void gemv_kernel(const GemvArgs a) {
 template <int NR, int U, int NS, int PRO, int EPI, int NSP, bool PIPE, int WPB>
 static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_t st) {
     const int ns = NS ? NS : (((a.C >> 3) + 63) >> 6);
-    const size_t smem = (size_t)ns * 512 * 4 + 128 + (PRO == PRO_ATTN_NEW ? 256 : 0);   // + one score per head for the newest-row merge
+    const size_t smem = (size_t)ns * 512 * 4 + 128;
     (void)nt;   // weights always stream with non-temporal loads (default-policy loads measured 8 % slower)
     if (OvlRecorder* r = ovl_recorder) {       // overlapped dispatch: record, do not launch (the kernel lives in libthk_ovl.hsaco)
         char name[64];
@@ -78,7 +78,7 @@ static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_
 }
 template <int NR, int U, int NS, int PRO, int EPI, bool PIPE, int WPB>
 static hipError_t launch_gemv_w(const GemvArgs& a, int grid, bool nt, hipStream_t st) {
-    if constexpr (PRO == PRO_ATTN || PRO == PRO_ATTN_NEW) {
+    if constexpr (PRO == PRO_ATTN) {
         switch (a.nsplit) {
             case 2: return launch_gemv_k<NR, U, NS, PRO, EPI, 2, PIPE, WPB>(a, grid, nt, st);
             case 4: return launch_gemv_k<NR, U, NS, PRO, EPI, 4, PIPE, WPB>(a, grid, nt, st);
@@ -158,12 +158,11 @@ int gemv_rows_per_group(int C, int epi, int nru) {
 hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, bool nt, hipStream_t st) {
     if (a.C < 256 || a.C % 256 != 0) return hipErrorInvalidValue;
     if (epi == EPI_ROPE_KV && pro == PRO_RMS) return launch_gemv_pe<PRO_RMS, EPI_ROPE_KV>(nru, a, grid, nt, st);
-    if (epi == EPI_ROPE_KV && pro == PRO_RMS_EMBED) return (a.embed && a.tok_ptr) ? launch_gemv_pe<PRO_RMS_EMBED, EPI_ROPE_KV>(nru, a, grid, nt, st) : hipErrorInvalidValue;
+    if (epi == EPI_ROPE_KV && pro == PRO_RMS_EMBED) return (a.embed && a.tok_ptr && a.x_out) ? launch_gemv_pe<PRO_RMS_EMBED, EPI_ROPE_KV>(nru, a, grid, nt, st) : hipErrorInvalidValue;
     if (epi == EPI_SWIGLU && pro == PRO_RMS) return launch_gemv_pe<PRO_RMS, EPI_SWIGLU>(nru, a, grid, nt, st);
     if (epi == EPI_HEAD && pro == PRO_RMS) return launch_gemv_pe<PRO_RMS, EPI_HEAD>(nru, a, grid, nt, st);
     if (epi == EPI_HEAD && pro == PRO_COPY) return launch_gemv_pe<PRO_COPY, EPI_HEAD>(nru, a, grid, nt, st);
     if (epi == EPI_RESID && pro == PRO_ATTN) return launch_gemv_pe<PRO_ATTN, EPI_RESID>(nru, a, grid, nt, st);
-    if (epi == EPI_RESID && pro == PRO_ATTN_NEW) return (a.q && a.pos_ptr && a.kcache && a.vcache && a.H <= 64) ? launch_gemv_pe<PRO_ATTN_NEW, EPI_RESID>(nru, a, grid, nt, st) : hipErrorInvalidValue;
     if (epi == EPI_RESID && pro == PRO_COPY) return launch_gemv_pe<PRO_COPY, EPI_RESID>(nru, a, grid, nt, st);
     if (epi == EPI_STORE && pro == PRO_COPY) return launch_gemv_pe<PRO_COPY, EPI_STORE>(nru, a, grid, nt, st);
     return hipErrorInvalidValue;

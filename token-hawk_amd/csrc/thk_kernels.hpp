@@ -20,7 +20,7 @@ struct SeqState {
 };
 
 // prologue / epilogue selectors of the fused mat-vec
-enum { GEMV_PRO_COPY = 0, GEMV_PRO_RMS = 1, GEMV_PRO_ATTN = 2, GEMV_PRO_RMS_EMBED = 3, GEMV_PRO_ATTN_NEW = 4 };
+enum { GEMV_PRO_COPY = 0, GEMV_PRO_RMS = 1, GEMV_PRO_ATTN = 2, GEMV_PRO_RMS_EMBED = 3 };
 enum { GEMV_EPI_STORE = 0, GEMV_EPI_RESID = 1, GEMV_EPI_ROPE_KV = 2, GEMV_EPI_SWIGLU = 3, GEMV_EPI_HEAD = 4 };
 
 // Overlapped dispatch (thk_ovl.cpp): how a launch finds its predecessor and announces itself (thk_device.hpp, ovl_wait / ovl_arrive).
@@ -49,10 +49,6 @@ struct GemvArgs {
     int kv_f16;             // caches hold binary16 [n_ctx, H, D] (optional; the reference's and the default are f32)
     // PRO_ATTN
     const float* part_o; const float* part_ml; int H; int nsplit;
-    // PRO_ATTN_NEW: the partials cover cache rows [0, pos) only; the prologue merges row pos itself from q (f32 [E]), the row of
-    // kcache / vcache at *pos_ptr (kv_f16 as above) and scale = 1/sqrt(D)
-    const float* q; float scale;
-    int g0;                 // EPI_ROPE_KV: first row group of this launch in the virtual [3E,E] stack (0 = from wq's first row)
     // EPI_HEAD
     int lm_faithful; int q1_split; int q1_cov; unsigned long long* block_best;
     unsigned long long* trace;   // development timeline, [blocks][8 waves][4] (only read by a THK_TRACE build; NULL otherwise)
@@ -67,7 +63,6 @@ struct AttnArgs {
     int H, D, nsplit, tc;      // tc = positions per split
     int waves;                 // waves per block of the stand-alone kernel (4 or 8)
     int nq;                    // causal queries in this launch (prefill); 0/1 = single decode query
-    int excl_newest;           // 1: attend to rows [0, pos) only - row pos is merged by the consumer (GEMV_PRO_ATTN_NEW)
     int kv_f16;                // the caches hold binary16 (kcache / vcache then point to _Float16 data)
     float scale;               // 1/sqrtf(D)
     float* out;                // finished output [H*D] (nsplit == 1); NULL = write split partials

@@ -102,7 +102,6 @@ extern "C" int thk_model_destroy(thk_model* m) {
     hipStreamSynchronize(m->ctx->stream);
     free_working(m);
     hipFree(m->trace_buf);
-    for (hipEvent_t e : m->fork_ev) hipEventDestroy(e);
     hipFree(m->weights_slab);     // every weight pointer of the stage points into it
     delete m;
     return THK_OK;
@@ -268,41 +267,6 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         float* kc = kcache_of(m, sb, i);
         float* vc = vcache_of(m, sb, i);
         const float* xr_in = i == 0 ? xin : m->x;
-        const bool fork = m->attn_fork && !m->ovl_rec && m->nsplit > 1 && m->skip_kernel == 0;
-        if (fork) {   // q first; then attention over the rows of earlier steps on the side stream BESIDE k | v; wo merges the row appended now
-            hipStream_t s2 = ctx->stream2;
-            GemvArgs a{};
-            a.W[0] = L.wq; a.W[1] = L.wk; a.W[2] = L.wv; a.R = E; a.C = E;
-            a.x = xr_in; a.gain = L.attention_norm; a.y = m->q;
-            a.kcache = kc; a.vcache = vc; a.rope_tab = m->rope_tab; a.pos_ptr = &sb.st->pos; a.E = E; a.D = D; a.kv_f16 = m->kv_f16;
-            const bool emb = fold_embed && i == 0;
-            if (emb) { a.embed = m->tok_embeddings; a.tok_ptr = &sb.st->token; a.x_out = m->x; }
-            const int pro = emb ? GEMV_PRO_RMS_EMBED : GEMV_PRO_RMS;
-            GemvArgs aq = a; aq.n_groups = E / 2; aq.g0 = 0; aq.trace = trace_slab();
-            MARK("norm_q_rope");
-            HIPCHK(ctx, launch_gemv(pro, GEMV_EPI_ROPE_KV, m->var_qkv, aq, m->grid_q, nt, st));
-            HIPCHK(ctx, hipEventRecord(m->fork_ev[2 * i], st));
-            HIPCHK(ctx, hipStreamWaitEvent(s2, m->fork_ev[2 * i], 0));
-            AttnArgs t{};
-            t.q = m->q; t.kcache = kc; t.vcache = vc; t.pos_ptr = &sb.st->pos; t.H = H; t.D = D; t.nsplit = m->nsplit; t.tc = m->tc;
-            t.scale = 1.0f / sqrtf((float)D); t.waves = m->attn_waves; t.kv_f16 = m->kv_f16; t.excl_newest = 1;
-            t.out = nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml; t.trace = trace_slab();
-            HIPCHK(ctx, launch_attn_decode(t, s2));
-            HIPCHK(ctx, hipEventRecord(m->fork_ev[2 * i + 1], s2));
-            GemvArgs akv = a; akv.n_groups = E; akv.g0 = E / 2; akv.x_out = nullptr; akv.trace = trace_slab();
-            MARK("norm_kv_rope_append");
-            HIPCHK(ctx, launch_gemv(pro, GEMV_EPI_ROPE_KV, m->var_qkv, akv, m->grid_kv, nt, st));
-            HIPCHK(ctx, hipStreamWaitEvent(st, m->fork_ev[2 * i + 1], 0));
-            GemvArgs w{};
-            w.W[0] = L.wo; w.R = E; w.C = E;
-            const int NR = gemv_rows_per_group(E, GEMV_EPI_RESID, m->var_wo);
-            w.n_groups = (E + NR - 1) / NR;
-            w.part_o = m->part_o; w.part_ml = m->part_ml; w.H = H; w.D = D; w.nsplit = m->nsplit; w.E = E;
-            w.q = m->q; w.kcache = kc; w.vcache = vc; w.pos_ptr = &sb.st->pos; w.scale = t.scale; w.kv_f16 = m->kv_f16;
-            w.resid = xr_in; w.y = m->x; w.trace = trace_slab();
-            MARK("attn_new_row_wo_resid");
-            HIPCHK(ctx, launch_gemv(GEMV_PRO_ATTN_NEW, GEMV_EPI_RESID, m->var_wo, w, m->grid_wo, nt, st));
-        } else {
         {   // rms_norm*gain -> wq,wk,wv -> RoPE -> K/V append   (steps 1-4, th-llama.cpp:299-339)
             GemvArgs a{};
             a.W[0] = L.wq; a.W[1] = L.wk; a.W[2] = L.wv; a.R = E; a.C = E; a.n_groups = 3 * E / 2;
@@ -336,7 +300,6 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             if (m->skip_kernel != 3) ovl_link(a.ovl, m->grid_wo);
             MARK("attn_wo_resid");
             if (m->skip_kernel != 3) HIPCHK(ctx, launch_gemv(m->nsplit == 1 ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, m->var_wo, a, m->grid_wo, nt, st));
-        }
         }
         {   // rms_norm*gain -> w1,w3 -> silu*gate   (steps 12-14, th-llama.cpp:415-438)
             GemvArgs a{};
@@ -450,16 +413,10 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->attn_waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
     m->kv_f16 = tun(ctx, "kv_f16") != 0;
     m->fold_embed = tun(ctx, "fold_embed") != 0;
-    m->attn_fork = tun(ctx, "attn_fork") != 0;
     m->gain_alias = tun(ctx, "measure_gain_alias") != 0;
     m->var_qkv = resolve_variant(ctx, "qkv", (int)E); m->var_wo = resolve_variant(ctx, "wo", (int)E);
     m->var_w13 = resolve_variant(ctx, "w13", (int)E); m->var_w2 = resolve_variant(ctx, "w2", (int)E); m->var_head = resolve_variant(ctx, "head", (int)E);
     m->grid_qkv = grid_for(ctx, "gemv_bpc_qkv", (int)(3 * E / 2), (int)E);
-    m->grid_q = (m->grid_qkv + 2) / 3; m->grid_kv = m->grid_qkv - m->grid_q;
-    if (m->attn_fork) {
-        if (!ctx->stream2) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        while ((int)m->fork_ev.size() < 2 * nl) { hipEvent_t e; HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); m->fork_ev.push_back(e); }
-    }
     m->grid_wo = grid_for(ctx, "gemv_bpc_wo", (int)((E + gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo) - 1) / gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo)), (int)E);
     m->grid_w13 = grid_for(ctx, "gemv_bpc_w13", (int)F, (int)E);
     m->grid_w2 = grid_for(ctx, "gemv_bpc_w2", (int)((E + gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2) - 1) / gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2)), (int)E);

@@ -205,7 +205,6 @@ bool ovl_eligible(const thk_model* m, const char** why) {
     if (!(m->flags & THK_STAGE_EMBED) || !(m->flags & THK_STAGE_HEAD)) w = "a pipeline stage (the overlapped step starts at the embedding and ends with the greedy pick)";
     else if (m->engine) w = "the one-launch engine is on";
     else if (!m->fold_embed) w = "fold_embed = 0";
-    else if (m->attn_fork) w = "attn_fork = 1 (the forked step needs two streams)";
     else if (m->skip_kernel == 1 || m->skip_kernel == 6) w = "measure_skip_kernel drops the step's first or last mat-vec";
     else if (m->nsplit == 1) w = "attn_splits = 1";
     else if (E != 4096 && E != 5120) w = "n_embd is neither 4096 nor 5120 (only the LLaMA-7B/13B widths have overlapped kernel variants)";
