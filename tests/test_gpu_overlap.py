@@ -147,3 +147,26 @@ def test_7b_overlap_hold_position_same_token(thk, ctx):
     assert res[0][0] == res[1][0]
     assert np.abs(res[0][1] - res[1][1]).max() < 1e-5
     m.close()
+
+
+def test_debug_buffer_matches_between_paths(thk, ctx):
+    """thk_model_debug_buffer (development aid): after ONE step from the same state the last layer's q, split partials, SwiGLU
+    vector and the final hidden state are the same on both launch paths, and unknown names are refused."""
+    m = thk.Model(ctx, thk.ModelShape(n_embd=4096, n_head=32, n_layer=1)); m.fill_synthetic(); m.finalize()
+    bufs = {}
+    for mode in (0, 1):
+        ctx.set_tunable("overlap_dispatch", mode)
+        try:
+            m.reset_kv(0); m.seq_set(0, 1, 0)
+            m.decode_step(0, advance=True)
+            bufs[mode] = {n: m.debug_buffer(n) for n in ("q", "part_ml", "part_o", "u", "x")}
+        finally:
+            ctx.set_tunable("overlap_dispatch", 0)
+    assert bufs[0]["q"].size == 4096 and bufs[0]["u"].size == 11008 and bufs[0]["part_o"].size == 32 * 4 * 128
+    for n in bufs[0]:
+        a, b = bufs[0][n], bufs[1][n]
+        fin = np.isfinite(a)                                  # empty splits carry m = -inf
+        assert (np.isfinite(b) == fin).all() and np.abs(a[fin] - b[fin]).max() < 1e-5, n
+    with pytest.raises(thk.ThkError, match="no working buffer"):
+        m.debug_buffer("nope")
+    m.close()
