@@ -45,6 +45,10 @@ def parse():
                    help="prompt: run the 511-token synthetic prompt through the decode path; seeded: (N>1 default off)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-profile", action="store_true")
+    p.add_argument("--no-parity-check", action="store_true",
+                   help="skip `parity_check` (HIP logits vs the oracle on the full-depth model, outside the timed region; rides on the cpu_baseline leg)")
+    p.add_argument("--parity-budget-s", type=float, default=75.0,
+                   help="the n_past = T-1 part of `parity_check` needs the oracle to decode the whole prompt; skipped (and said so) when its measured speed projects past this")
     p.add_argument("--no-extras", action="store_true",
                    help="skip the time-boxed extra measurements taken after the timed region at N=1 (per-step distribution over 200 steps, "
                         "128-token prefill = config C3, 13B decode = config C5); `value`/`config` never depend on them")
@@ -102,9 +106,44 @@ def synthetic_prompt(shape, T, seq):
     return np.concatenate([[1], rng.integers(3, shape.n_vocab, T - 1)]).astype(np.int32)
 
 
-def cpu_baseline(shape_name, T, layers=0):
+def parity_check(model, om, orc, prompt, T, budget_s=75.0):
+    """HIP logits vs the oracle's (fast flavour) on the full-depth model, OUTSIDE the timed region: the first positions of the
+    seeded prompt and, when the oracle's measured speed fits the time budget, n_past = T-1 after the whole (T-1)-token prompt - the
+    position `value` is timed at.  Tolerance: north_star's 1e-3 on logits."""
+    t0 = time.time()
+    early = min(4, T)
+    per, greedy_equal = {}, True
+    model.reset_kv(0); om.reset_kv(0)
+    for i in range(early):
+        lg, _ = model.eval([int(prompt[i])], i)
+        lo, _ = om.eval(int(prompt[i]), i, flags=0)
+        per[str(i)] = float(np.abs(lg - lo).max())
+        greedy_equal = greedy_equal and int(lg.argmax()) == orc.greedy(lo)
+    dt = (time.time() - t0) / early
+    out = {"tolerance": 1e-3, "reference": "oracle fast flavour (CPU restatement of th_eval_gpu, th-llama.cpp:464-660), same seeded weights and prompt"}
+    if T - 1 >= early and (T - 1 - early) * dt * 0.9 < budget_s:        # the early evals carry the logits head; cache-fill evals do not
+        if T - 1 > early:
+            model.eval(prompt[early:T - 1], early, want_logits=False)
+            for i in range(early, T - 1):
+                om.eval(int(prompt[i]), i, want_logits=False, flags=0)
+        lg, _ = model.eval([int(prompt[T - 1])], T - 1)
+        lo, _ = om.eval(int(prompt[T - 1]), T - 1, flags=0)
+        per[str(T - 1)] = float(np.abs(lg - lo).max())
+        greedy_equal = greedy_equal and int(lg.argmax()) == orc.greedy(lo)
+        out["logit_abs_max_at_last"] = round(float(np.abs(lo).max()), 3)
+    else:
+        out["note"] = f"n_past={T - 1} skipped: the oracle needs ~{(T - 1 - early) * dt:.0f}s for the prompt on this host (budget {budget_s:.0f}s); tests/test_gpu_full_depth.py covers it"
+    out.update({"positions": [int(k) for k in per], "max_abs_logit_diff": float(f"{max(per.values()):.3e}"),
+                "per_position": {k: float(f"{v:.3e}") for k, v in per.items()}, "greedy_equal": bool(greedy_equal),
+                "pass": bool(max(per.values()) < 1e-3 and greedy_equal), "wall_s": round(time.time() - t0, 1)})
+    return out
+
+
+def cpu_baseline(shape_name, T, layers=0, parity=None):
     """Oracle fast flavour (AVX2/F16C + OpenMP) on this box's host cores: the FULL model for 16 decode steps at context T
-    when host RAM allows, otherwise a 4-layer sample scaled to the layer count and labelled so."""
+    when host RAM allows, otherwise a 4-layer sample scaled to the layer count and labelled so.
+    parity: optional callable(oracle_model, oracle_module) -> dict, run on the FULL oracle model before the timing (the
+    bench line's `parity_check`); returns (cpu_baseline dict, parity dict | None)."""
     from oracle import oracle as orc
     oshape = {"7b": orc.LLAMA_7B, "13b": orc.LLAMA_13B, "tiny": orc.TINY}[shape_name]
     E, Fd, V = oshape.n_embd, oshape.n_ff, oshape.n_vocab
@@ -121,6 +160,13 @@ def cpu_baseline(shape_name, T, layers=0):
     orc.set_num_threads(orc.usable_cpus())          # all usable host cores (affinity mask / cgroup quota aware)
     m = orc.OracleModel(sample_shape)
     m.fill_synthetic()
+    par = None
+    if parity is not None:
+        try:
+            par = parity(m, orc) if full else {"skipped": f"host RAM {avail / 2**30:.0f} GiB cannot hold the oracle's full model"}
+        except Exception as e:
+            par = {"error": str(e)}
+    t0 = time.time()
     steps = 16 if full else 3
     m.time_decode(min(T, oshape.n_ctx) - 1, n_sample, 1)                       # touch pages
     tl, th = m.time_decode(min(T, oshape.n_ctx) - 1, n_sample, steps)
@@ -135,7 +181,7 @@ def cpu_baseline(shape_name, T, layers=0):
             f"(host RAM {avail / 2**30:.0f} GiB < model)")
     return {"value": round(1.0 / per_tok, 3), "unit": "tokens/s", "cores": orc.num_threads(), "kind": "port",
             "sample": f"{what}; oracle fast flavour (AVX2+F16C, OpenMP) on all usable host cores; llama.cpp unavailable; "
-                      f"cpu='{cpu_model}'; setup+run {time.time() - t0:.1f}s"}
+                      f"cpu='{cpu_model}'; run {time.time() - t0:.1f}s"}, par
 
 
 def kernel_profile(model, shape, T, n_steps=6):
@@ -623,7 +669,12 @@ def main():
 
         if rank == 0 and N == 1 and not args.no_cpu_baseline:
             try:
-                result["cpu_baseline"] = cpu_baseline(args.model, T, args.cpu_baseline_layers)
+                par_fn = None
+                if not PIPE and not args.no_parity_check:
+                    par_fn = lambda om, orc: parity_check(model, om, orc, prompts[:, 0], T, args.parity_budget_s)   # noqa: E731
+                result["cpu_baseline"], par = cpu_baseline(args.model, T, args.cpu_baseline_layers, par_fn)
+                if par is not None:
+                    result["parity_check"] = par
             except Exception as e:   # the baseline is a report item; never let it kill the GPU number
                 result["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
         if rank == 0:
