@@ -56,9 +56,16 @@ def parse():
     p.add_argument("--lmhead", default="correct", choices=["correct", "faithful"])
     p.add_argument("--force-pipeline", action="store_true",
                    help="run the N>1 code path (process group, HipStage, ring driver with a self send/recv) even with one rank; plumbing check")
-    p.add_argument("--transport", default="native", choices=["torch", "native", "peer"],
-                   help="N>1 hidden-state hand-off: torch.distributed P2P ops (backend nccl = RCCL), libthk's thk_pp_* (RCCL directly, default) or "
-                        "thk_peer_* (no library: stores into the next stage's IPC-mapped mailbox + flag; opt-in, never exercised across xGMI)")
+    p.add_argument("--transport", default="auto", choices=["auto", "torch", "native", "peer"],
+                   help="N>1 hidden-state hand-off: libthk's thk_pp_* (RCCL directly), thk_peer_* (no library: stores into the next stage's "
+                        "IPC-mapped fine-grained mailbox + flag) or torch.distributed P2P ops (backend nccl = RCCL).  auto (default) tries "
+                        "native -> peer -> torch and keeps the first one that sets up on EVERY rank and passes the hand-off pattern check; "
+                        "a named transport is tried alone (the run fails if it does not validate)")
+    p.add_argument("--balance", action="store_true",
+                   help="N>1: size the stages with pipeline.balanced_layer_split() from the byte-based stage cost model (the lm-head rank may carry "
+                        "fewer layers) instead of the uniform 32/16/8/4 split BASELINE.md names; the line reports both splits and their bounds either way")
+    p.add_argument("--watchdog-s", type=float, default=900.0,
+                   help="N>1: a rank whose warm-up + timed region + drain does not finish in this many seconds reports and exits 3 (a dead peer must not hang the node)")
     p.add_argument("--kv", default="f32", choices=["f32", "f16"],
                    help="KV-cache storage: f32 as the reference (default, the headline configuration) or the optional binary16 cache (s_kv = 2 in bytes/token)")
     p.add_argument("--cpu-baseline-layers", type=int, default=0,
@@ -273,6 +280,89 @@ def extra_decode_13b(thk, ctx, T, stream, torch, steps=100, warmup=20):
         m.close()
 
 
+def stage_cost_model_us(shape, T):
+    """(one layer, final norm + lm-head + pick) in microseconds from the algorithmic bytes: every weight-streaming launch costs
+    bytes / 6.8 TB/s + ~3.1 us of ramp and boundary; 5 launches per layer, 1 for the head."""
+    E, F, V = shape.n_embd, shape.n_ff, shape.n_vocab
+    layer = ((4 * E * E + 3 * E * F) * 2 + 2 * T * E * 4) / 6.8e12 * 1e6 + 5 * 3.1
+    head = (V * E * 2) / 6.8e12 * 1e6 + 3.1
+    return layer, head
+
+
+def choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, log_lines):
+    """Set up and VALIDATE the hand-off transport on every rank together: `auto` walks native (thk_pp_*, RCCL) -> peer (thk_peer_*,
+    IPC mailboxes) -> torch (torch.distributed P2P ops) and keeps the first one that sets up everywhere and passes
+    PipelineDriver.validate_handoff(); a named transport is tried alone.  Returns the HandoffReport (args.transport = the choice)
+    or None.  Every decision is all-reduced (MIN) so the ranks never disagree; the reasons go to log_lines."""
+    import ctypes as C
+    order = ["native", "peer", "torch"] if args.transport == "auto" else [args.transport]
+
+    def agree(ok):
+        flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
+
+    def teardown():
+        if getattr(stage, "pp", None) is not None:
+            ctx.lib.thk_pp_destroy(stage.pp)
+        stage.pp = None
+        if getattr(stage, "peer", None) is not None:
+            ctx.lib.thk_peer_destroy(stage.peer)
+        stage.peer = None
+
+    for kind in order:
+        why, ok = "", True
+        try:
+            if kind == "native":
+                uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    buf = C.create_string_buffer(128)
+                    if ctx.lib.thk_pp_get_unique_id(buf) != 0:
+                        ok, why = False, "thk_pp_get_unique_id failed (librccl not loadable?)"
+                    else:
+                        uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
+                dist.broadcast(uid, 0)
+                if agree(ok):                         # agree BEFORE the collective ncclCommInitRank inside thk_pp_create
+                    torch.cuda.synchronize(dev)
+                    stage.attach_native_transport(rank, N, bytes(uid.cpu().numpy().tobytes()))
+                else:
+                    ok = False
+            elif kind == "peer":
+                handles = [None] * N
+                try:
+                    mine = stage.attach_peer_transport(S)
+                except Exception as e:
+                    mine, ok, why = None, False, f"thk_peer_create/export: {e}"
+                dist.all_gather_object(handles, mine)
+                if all(h is not None for h in handles):
+                    stage.connect_peer(handles[(rank + 1) % N] if N > 1 else None)
+                    kind_mem = int(ctx.lib.thk_peer_memory_kind(stage.peer))
+                    if kind_mem == 0 and N > 1:
+                        ok, why = False, "the mailbox could only be allocated coarse-grained: not safe across GPUs"
+                else:
+                    ok = False
+        except Exception as e:
+            ok, why = False, f"{type(e).__name__}: {e}"
+        if not agree(ok):
+            log_lines.append(f"{kind}: set-up failed on some rank" + (f" (rank {rank}: {why})" if why else ""))
+            teardown()
+            continue
+        try:
+            rep = drv.validate_handoff(reps=16, sync=lambda: torch.cuda.synchronize(dev))
+            if getattr(stage, "peer", None) is not None:
+                stage.peer_check()
+            ok, why = rep.ok, "; ".join(rep.errors[:2])
+        except Exception as e:
+            rep, ok, why = None, False, f"{type(e).__name__}: {e}"
+        if agree(ok):
+            log_lines.append(f"{kind}: validated ({rep.checked} payloads per rank, {rep.handoff_us:.1f} us per bare hand-off on rank {rank})")
+            args.transport = kind
+            return rep
+        log_lines.append(f"{kind}: hand-off check failed on some rank" + (f" (rank {rank}: {why})" if why else ""))
+        teardown()
+    return None
+
+
 SKIP_IDS = {"norm_qkv_rope_kv": 1, "attn_decode": 2, "attn_wo_resid": 3, "norm_w13_swiglu": 4, "w2_resid": 5, "norm_lmhead": 6}
 
 
@@ -441,47 +531,21 @@ def main():
             model.finalize()
             stage = None
         else:
-            stage = HipStage(thk, ctx, shape, rank, N, S, dev)
+            from token_hawk_amd.pipeline import balanced_layer_split, split_efficiency_bound
+            t_layer_us, t_head_us = stage_cost_model_us(shape, T)
+            uniform = [layer_range(shape.n_layer, r, N) for r in range(N)]
+            balanced = balanced_layer_split(shape.n_layer, N, t_layer_us, t_head_us)
+            split = balanced if args.balance else uniform
+            stage = HipStage(thk, ctx, shape, rank, N, S, dev, layers=split[rank])
             model = stage.model
-            if args.transport == "peer":
-                # mailbox transport: every rank exports its mailbox (64-byte hipIpc handle), opens its successor's
-                handles = [None] * N
-                dist.all_gather_object(handles, stage.attach_peer_transport(S))
-                stage.connect_peer(handles[(rank + 1) % N] if N > 1 else None)
-                dist.barrier()
-            if args.transport == "native":
-                # libthk's own RCCL path (measured ~15 us per hand-off vs ~190 us through torch P2P ops); every rank
-                # must agree, so success is all-reduced and the torch transport is the fallback.
-                import ctypes as C
-                uid = torch.zeros(128, dtype=torch.uint8, device=dev)
-                ok = 1
-                try:
-                    if rank == 0:
-                        buf = C.create_string_buffer(128)
-                        if ctx.lib.thk_pp_get_unique_id(buf) != 0:
-                            raise RuntimeError("thk_pp_get_unique_id failed")
-                        uid.copy_(torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8))
-                except Exception as e:
-                    log(f"[bench r{rank}] native transport unavailable: {e}"); ok = 0
-                dist.broadcast(uid, 0)
-                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # agree BEFORE the collective ncclCommInitRank inside thk_pp_create
-                ok = int(flag.item())
-                torch.cuda.synchronize(dev)
-                if ok:
-                    try:
-                        stage.attach_native_transport(rank, N, bytes(uid.cpu().numpy().tobytes()))
-                    except Exception as e:
-                        log(f"[bench r{rank}] thk_pp_create failed: {e}"); ok = 0
-                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 0:
-                    if getattr(stage, "pp", None) is not None:
-                        ctx.lib.thk_pp_destroy(stage.pp)
-                    stage.pp = None
-                    args.transport = "torch"
-                    log(f"[bench r{rank}] falling back to the torch.distributed transport")
-        l0, l1 = layer_range(shape.n_layer, rank, N)
+            drv = PipelineDriver(stage, rank, N, S, force_ring=(N == 1))
+            transport_log = []
+            handoff = choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, transport_log)
+            if handoff is None:
+                if rank == 0:
+                    log("[bench] ERROR: no transport passed the hand-off check: " + "; ".join(transport_log))
+                sys.exit(4)
+        l0, l1 = (stage.l0, stage.l1) if PIPE else (0, shape.n_layer)
         ctx.sync()
         log(f"[bench r{rank}] {info['name']} cus={info['n_cu']} layers [{l0},{l1}) model ready in {time.time() - t_setup:.1f}s")
 
@@ -494,7 +558,6 @@ def main():
             model.seq_set(0, int(prompts[T - 1, 0]), T - 1)
             drv = None
         else:
-            drv = PipelineDriver(stage, rank, N, S, force_ring=(N == 1))
             for s in range(S):
                 stage.set_seq(s, int(prompts[0, s]), 0)
             if T > 1:
@@ -511,6 +574,9 @@ def main():
             else:
                 drv.steady(k, advance=False)                  # ring kept full: k * S micro-steps, one item per rank in each
 
+        from token_hawk_amd.pipeline import Watchdog
+        dog = Watchdog(args.watchdog_s if PIPE else 0, f"rank {rank}: warm-up + {args.steps} timed steps + drain")
+        dog.__enter__()
         if PIPE:
             drv.prime(advance=False)                          # N - 1 fill micro-steps, outside the warm-up and the timed region
 
@@ -540,6 +606,7 @@ def main():
             torch.cuda.synchronize(dev)
             if getattr(stage, "peer", None) is not None:
                 stage.peer_check()                            # a bounded hand-off wait that gave up would have produced garbage
+        dog.__exit__(None, None, None)
         dist_ms = None
         if rank == 0 and N == 1 and not PIPE and not args.no_extras:
             # straight after the timed region, before anything allocates or frees device memory: a freed 13.5 GB model (the
@@ -599,6 +666,29 @@ def main():
                 # the lm-head, rank 0 the embedding fetch) bounds the ring
                 result["ideal_efficiency_bound"] = round(sum(stage_ms) / (N * max(stage_ms)), 4)
             result["timed_region"] = "steady ring: prime() before the warm-up, steps * S micro-steps timed, drain() after (no fill/drain inside)"
+            # the hand-off, validated before anything was timed: known patterns through every (sequence, kind) slot of the chosen
+            # transport on every boundary, then bare ring hand-offs timed with no compute between them
+            hmax = torch.tensor([handoff.handoff_us], device=dev, dtype=torch.float64)
+            allh = [torch.zeros_like(hmax) for _ in range(N)]
+            dist.all_gather(allh, hmax)
+            result["handoff"] = {"validated": True, "payloads_checked_per_rank": handoff.checked, "handoff_us": round(max(float(t.item()) for t in allh), 2),
+                                 "handoff_us_per_rank": [round(float(t.item()), 2) for t in allh],
+                                 "method": "pattern round trip on every boundary and sequence slot (2 rounds), then 16 x S bare ring hand-offs per rank, host clock around stream-ordered enqueue + one sync",
+                                 "transport_log": transport_log}
+            result["config"]["transport"] = args.transport
+            result["layer_split"] = {"used": [list(x) for x in split], "uniform": [list(x) for x in uniform], "balanced": [list(x) for x in balanced],
+                                     "cost_model_us": {"layer": round(t_layer_us, 2), "lm_head": round(t_head_us, 2),
+                                                       "basis": "algorithmic bytes / 6.8 TB/s + 3.1 us per launch (DESIGN.md 4.6)"},
+                                     "bound_uniform": round(split_efficiency_bound(uniform, t_layer_us, t_head_us), 4),
+                                     "bound_balanced": round(split_efficiency_bound(balanced, t_layer_us, t_head_us), 4)}
+            if stage_ms and N > 1:
+                # the same question asked of the measurement: per-layer and lm-head cost from the stages just timed
+                nl = [b - a for a, b in split]
+                tl = float(np.median([stage_ms[r] / nl[r] for r in range(N - 1)]))
+                th = max(0.0, stage_ms[-1] - nl[-1] * tl)
+                mb = balanced_layer_split(shape.n_layer, N, tl, th)
+                result["layer_split"]["measured"] = {"layer_ms": round(tl, 4), "lm_head_ms": round(th, 4), "balanced": [list(x) for x in mb],
+                                                     "bound_if_rebalanced": round(split_efficiency_bound(mb, tl, th), 4)}
         if rank == 0:
             gen, ngen, pos = (model.seq_get(0) if not PIPE else ([], 0, 0))
             if not PIPE:

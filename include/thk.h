@@ -243,13 +243,8 @@ int thk_model_prepare_steps(thk_model* m, int32_t seq, int32_t n_steps);
 /* 1 when the finalized model runs a decode step as ONE persistent loader/consumer launch (thk_engine.hip;
  * tunable "engine" = 1, default 0, shape permitting), 0 when it runs 5 fused launches per layer. */
 int thk_model_uses_engine(const thk_model* m);
-/* 1 when thk_model_decode_step(s) of this model currently take the overlapped dispatch (tunable "overlap_dispatch" = 1, read at
- * every call): the step's launches go to a user-mode queue of libthk's own as AQL packets WITHOUT the barrier bit, each kernel
- * waits for its predecessor inside (thk_ovl.cpp).  Same results, same stream-ordered meaning of the calls; only for whole models
- * (embedding .. lm-head) of the LLaMA-7B/13B widths - any other model makes the decode calls fail while the tunable is set. */
-int thk_model_uses_overlap(const thk_model* m);
 /* Development aid: copy out one of the working buffers the last decode step left behind ("x" final hidden state, "q", "u",
- * "part_o", "part_ml": the LAST layer's), to compare two launch paths stage by stage on a one-layer model. */
+ * "part_o", "part_ml": the LAST layer's), to compare two launch configurations stage by stage on a one-layer model. */
 int thk_model_debug_buffer(thk_model* m, const char* name, float* out, int64_t cap, int64_t* n_out);
 /* Development aid (tunable engine_trace=1 before finalize): the last step's per-workgroup, per-op s_memtime stamps,
  * [n_cu][n_ops][8] 64-bit words (slot meaning in thk_engine.hip). */
@@ -277,9 +272,10 @@ int64_t thk_model_bytes_per_token(const thk_model* m, int32_t T);
 /* Time the last `n` kernels of interest: enables per-kernel hipEvent timing of one
  * decode step outside graph replay; fills names/ms arrays (diagnostics for bench.py). */
 int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_entries, char (*names)[48], float* ms, int32_t* n_out);
-/* Development aid; needs a library built with -DTHK_TRACE (libthk_trace.so), THK_ERR_STATE otherwise.  Runs one eager decode
- * step in which every wave of every launch stamps the 100 MHz s_memrealtime counter at four points: kernel entry |
- * activation vector staged | first weight batch consumed | done.  out = [n_kernels][blocks_per_kernel][8 waves][4] u64, 0 = not
+/* Development aid; needs a library built with -DTHK_TRACE (libthk_trace.so), THK_ERR_STATE otherwise.  Runs TWO hold-position
+ * decode steps as one replayed graph (ONE eager step with use_graph = 0) in which every wave of every launch stamps the 100 MHz
+ * s_memrealtime counter at four points: kernel entry | activation vector staged | first weight batch consumed | done; the stamps
+ * of the LAST step are returned.  The sequence does not advance.  out = [n_kernels][blocks_per_kernel][8 waves][4] u64, 0 = not
  * stamped; names in thk_model_profile_step order.  No reference counterpart (the reference times whole passes, th-llama.cpp:640-655). */
 int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long long* out, int64_t cap_words, int32_t max_names, char (*names)[48],
                          int32_t* n_kernels, int32_t* blocks_per_kernel);
@@ -317,12 +313,17 @@ int thk_pp_recv_token(thk_pp* pp, thk_model* m, int32_t seq, int peer);
 typedef struct thk_peer thk_peer;
 #define THK_PEER_HANDLE_BYTES 64
 enum { THK_PEER_HIDDEN = 0, THK_PEER_TOKEN = 1 };
+/* how the mailbox was allocated: uncached / fine-grained device memory is visible to a polling kernel while ANOTHER GPU writes it;
+ * coarse-grained (plain hipMalloc: the fallback when the runtime cannot allocate or IPC-export the others) only guarantees that
+ * at dispatch boundaries, i.e. it is safe for rings inside one GPU only */
+enum { THK_PEER_MEM_COARSE = 0, THK_PEER_MEM_UNCACHED = 1, THK_PEER_MEM_FINEGRAINED = 2 };
 int thk_peer_create(thk_ctx* ctx, thk_model* stage, int32_t n_seq, thk_peer** out);
 int thk_peer_export(thk_peer* p, void* handle_out64);
 int thk_peer_connect(thk_peer* p, const void* next_handle64);
 int thk_peer_send(thk_peer* p, int32_t seq, int kind);   /* kind: THK_PEER_HIDDEN (thk_model_hidden_out) | THK_PEER_TOKEN (thk_model_token_dev) */
 int thk_peer_recv(thk_peer* p, int32_t seq, int kind);   /* into thk_model_hidden_in | thk_model_token_dev */
-int thk_peer_check(thk_peer* p);                         /* THK_ERR_STATE if a wait timed out since the last check */
+int thk_peer_check(thk_peer* p);                         /* THK_ERR_STATE once a wait has timed out: sticky - send / recv refuse from then on, destroy and recreate */
+int thk_peer_memory_kind(const thk_peer* p);             /* THK_PEER_MEM_* of this stage's mailbox */
 int thk_peer_destroy(thk_peer* p);
 
 /* Tuning knobs (integers, by name) so the bench can sweep launch geometry without

@@ -56,10 +56,17 @@ def test_tiny_model_every_token_vs_oracle(thk, orc, ctx, splits, use_graph):
     m.close()
 
 
-@pytest.mark.parametrize("tunables", [{"attn_waves": 4}, {"attn_waves": 4, "attn_splits": 8}, {"fold_embed": 0}, {"fold_embed": 0, "use_graph": 0}])
+R03_STEP = {"attn_vsplit": 1, "attn_tc_dyn": 0, "fold_finish": 0, "attn_splits": 4}     # the launch geometry of round 3's step
+
+
+@pytest.mark.parametrize("tunables", [{"attn_waves": 4}, {"attn_waves": 4, "attn_splits": 8}, {"fold_embed": 0}, {"fold_embed": 0, "use_graph": 0},
+                                      {"attn_vsplit": 1}, {"attn_tc_dyn": 0}, {"attn_vsplit": 1, "attn_tc_dyn": 0, "attn_waves": 4},
+                                      {"fold_finish": 0}, {"fold_finish": 0, "use_graph": 0}, {"fold_finish": 1, "use_graph": 0}, R03_STEP])
 def test_optional_paths_vs_oracle(thk, orc, ctx, tunables):
     """The off-by-default options stay correct: 4-wave attention blocks, the stand-alone embedding launch (default: the row is
-    fetched by layer 0's qkv prologue)."""
+    fetched by layer 0's qkv prologue), one attention workgroup per (head, split) (default: a pair that halves the V columns),
+    splits over the cache capacity (default: over the live context), the greedy pick as a launch of its own (default: folded into
+    the lm-head launch's last workgroup)."""
     m, om = make_pair(thk, orc, ctx, "TINY", tunables=tunables)
     rng = np.random.default_rng(5)
     toks = [1] + rng.integers(3, 2048, 30).tolist()
@@ -135,6 +142,39 @@ def test_multi_step_graph_matches_single_steps(thk, orc, ctx):
     a.decode_steps(3, 0, advance=True)           # fewer than one multi-step graph
     assert a.seq_get(0)[2] == 30
     a.close(); b.close()
+
+
+def test_multi_step_graph_cache_is_bounded(thk, ctx):
+    """A sequence keeps at most 6 multi-step graphs (least recently used evicted): many distinct step counts neither leak
+    graphs nor change results."""
+    a = thk.Model(ctx, thk.TINY); a.fill_synthetic(); a.finalize()
+    b = thk.Model(ctx, thk.TINY); b.fill_synthetic(); b.finalize()
+    a.seq_set(0, 1, 0); b.seq_set(0, 1, 0)
+    total = 0
+    for n in (2, 3, 4, 5, 6, 7, 8, 9, 3, 2, 9):          # 8 distinct counts > the cache's 6 slots; 3, 2 and 9 come round again
+        a.decode_steps(n, 0, advance=True); total += n
+    for _ in range(total):
+        b.decode_step(0, advance=True)
+    ga, na, pa = a.seq_get(0); gb, nb, pb = b.seq_get(0)
+    assert na == nb == total and pa == pb == total and ga.tolist() == gb.tolist()
+    a.close(); b.close()
+
+
+def test_folded_greedy_pick_over_many_steps_and_sequences(thk, orc, ctx):
+    """The lm-head launch's last workgroup finishes the token (ticket counter zeroed for the next launch): 60 consecutive steps on
+    two interleaved sequences give the tokens of the stand-alone finish_token launch, in graph replay and eagerly."""
+    out = {}
+    for fold in (1, 0):
+        for graph in (1, 0):
+            m, om = make_pair(thk, orc, ctx, "TINY", n_seq=2, tunables={"fold_finish": fold, "use_graph": graph})
+            om.close()
+            m.seq_set(0, 1, 0); m.seq_set(1, 9, 0)
+            for k in range(6):
+                m.decode_steps(5, 0, advance=True); m.decode_steps(5, 1, advance=True)
+            out[(fold, graph)] = (m.seq_get(0)[0].tolist(), m.seq_get(1)[0].tolist())
+            assert len(out[(fold, graph)][0]) == 30
+            m.close()
+    assert out[(1, 1)] == out[(0, 1)] == out[(1, 0)] == out[(0, 0)]
 
 
 def test_device_step_clock(thk, ctx):
@@ -627,6 +667,59 @@ def test_7b_full_model_prefill_128_vs_token_by_token(thk, ctx):
     assert np.isfinite(lp).all()
     assert np.abs(lp - ld).max() < LOGIT_TOL and int(lp.argmax()) == int(ld.argmax())
     assert np.abs(la_next - lb_next).max() < LOGIT_TOL
+
+
+def test_7b_round4_step_equals_round3_step(thk, ctx):
+    """Full 7B, real geometry: the round-4 step (paired attention workgroups that halve the V columns, splits over the live
+    context, greedy pick folded into the lm-head launch, kernel arguments preloaded) against round 3's launch geometry (one
+    workgroup per (head, split), splits over n_ctx, finish_token launch).  The default model free-runs 24 greedy tokens on the
+    device; the round-3 geometry is teacher-forced with them: logits equal to summation-order noise at every position, the same
+    pick wherever the top-2 margin is not itself noise; the same at the last cache slot."""
+    shape = thk.LLAMA_7B
+    rng = np.random.default_rng(4)
+    prompt = np.concatenate([[1], rng.integers(3, shape.n_vocab, 40)]).astype(np.int32)
+    P = len(prompt)
+
+    def build(tun):
+        old = {k: ctx.get_tunable(k) for k in tun}
+        for k, v in tun.items():
+            ctx.set_tunable(k, v)
+        try:
+            m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+        finally:
+            for k, v in old.items():
+                ctx.set_tunable(k, v)
+        return m
+    a = build({})
+    la, _ = a.eval(prompt, 0)
+    first = int(la.argmax())
+    a.seq_set(0, first, P)
+    a.decode_steps(24, 0, advance=True)
+    gen = a.seq_get(0)[0].tolist()
+    la_end = a.read_logits(0)                         # logits of the 24th free-running step
+    a.seq_set(0, 5, 511)
+    a.decode_steps(1, 0, advance=False)
+    la_last, tok_last = a.read_logits(0), a.seq_get(0)[0].tolist()
+    a.close()
+    b = build(R03_STEP)
+    lb, _ = b.eval(prompt, 0)
+    assert np.abs(la - lb).max() < 1e-4 and int(lb.argmax()) == first
+    toks = [first] + gen
+    worst = 0.0
+    for i in range(24):
+        lb, _ = b.eval([toks[i]], P + i)
+        top2 = np.sort(lb)[-2:]
+        if top2[1] - top2[0] > 1e-3:
+            assert int(lb.argmax()) == gen[i], (i, int(lb.argmax()), gen[i])
+    worst = float(np.abs(lb - la_end).max())
+    assert worst < 2e-4, worst
+    b.seq_set(0, 5, 511)
+    b.decode_steps(1, 0, advance=False)
+    lb_last = b.read_logits(0)
+    assert np.abs(la_last - lb_last).max() < 2e-4
+    top2 = np.sort(lb_last)[-2:]
+    assert top2[1] - top2[0] < 1e-3 or b.seq_get(0)[0].tolist() == tok_last
+    b.close()
 
 
 def test_13b_full_model_properties(thk, ctx):

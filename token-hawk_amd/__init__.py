@@ -368,10 +368,6 @@ class Model:
         self.ctx.check(self.ctx.lib.thk_model_debug_buffer(self.h, name.encode(), out.ctypes.data, out.size, C.byref(n)), "thk_model_debug_buffer")
         return out[:n.value].copy()
 
-    def uses_overlap(self) -> bool:
-        """True when decode_step(s) currently take the overlapped dispatch (tunable overlap_dispatch = 1; thk_ovl.cpp)."""
-        return bool(self.ctx.lib.thk_model_uses_overlap(self.h))
-
     def seq_get(self, seq: int = 0, cap: int = 4096):
         out = np.empty(cap, np.int32)
         n, pos = C.c_int32(), C.c_int32()

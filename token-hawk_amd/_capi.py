@@ -80,7 +80,6 @@ SIGNATURES = {
     "thk_model_decode_steps": (C.c_int, [vp, i32, i32, C.c_int]),
     "thk_model_prepare_steps": (C.c_int, [vp, i32, i32]),
     "thk_model_uses_engine": (C.c_int, [vp]),
-    "thk_model_uses_overlap": (C.c_int, [vp]),
     "thk_model_debug_buffer": (C.c_int, [vp, C.c_char_p, vp, i64, C.POINTER(i64)]),
     "thk_model_engine_trace": (C.c_int, [vp, vp, i64, C.POINTER(i32), C.POINTER(i32)]),
     "thk_model_hidden_in": (vp, [vp, i32]),
@@ -115,6 +114,7 @@ SIGNATURES = {
     "thk_peer_send": (C.c_int, [vp, i32, C.c_int]),
     "thk_peer_recv": (C.c_int, [vp, i32, C.c_int]),
     "thk_peer_check": (C.c_int, [vp]),
+    "thk_peer_memory_kind": (C.c_int, [vp]),
     "thk_peer_destroy": (C.c_int, [vp]),
     "thk_set_tunable": (C.c_int, [vp, C.c_char_p, i64]),
     "thk_get_tunable": (C.c_int, [vp, C.c_char_p, C.POINTER(i64)]),

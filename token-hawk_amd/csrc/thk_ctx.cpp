@@ -28,14 +28,13 @@ void default_tunables(thk_ctx* ctx) {
         ctx->tun[std::string("gemv_bpc_") + k] = -1;
         ctx->tun[std::string("gemv_variant_") + k] = -1;   // (rows/iteration, slots/batch) variant, see gemv_variant()
     }
-    ctx->tun["attn_splits"] = 4;          // context splits per head (1,2,4,8)
+    ctx->tun["attn_splits"] = 0;          // context splits per head: 0 = auto (4; 8 when n_ctx > 1024), or 1, 2, 4, 8
+    ctx->tun["attn_vsplit"] = 2;          // workgroups per (head, split): 2 = the pair shares the split's K rows and halves its V columns (256 workgroups for 7B)
+    ctx->tun["attn_tc_dyn"] = 1;          // 1 = the splits partition the live context T (tc computed on the device), 0 = the cache capacity n_ctx
+    ctx->tun["fold_finish"] = 1;          // the lm-head launch's last workgroup reduces the arg-max keys and finishes the token (no launch of its own)
     ctx->tun["attn_waves"] = 8;           // waves per attention block (4 or 8)
     ctx->tun["fold_embed"] = 1;           // the embedding row is fetched by layer 0's qkv prologue instead of a launch of its own
     ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
-    ctx->tun["overlap_dispatch"] = 0;     // thk_model_decode_step(s): the step's launches as AQL packets WITHOUT the barrier bit on a queue of our own,
-                                          // dependencies enforced inside the kernels (thk_ovl.cpp); read at every call, so it can be switched between calls
-    ctx->tun["overlap_keep_barrier"] = 118;// overlapped dispatch: launch kinds whose packets KEEP the barrier bit (1 qkv, 2 attention, 4 wo, 8 w1|w3, 16 w2,
-                                          // 32 lm-head, 64 greedy pick); read when a sequence's step program is built (first overlapped call after finalize)
     ctx->tun["measure_skip_kernel"] = 0;  // bench.py: marginal cost of one kernel = step time with minus without it (results are garbage then);
                                           // refused unless the process runs with THK_MEASURE_HOOKS=1 (never in a product)
     ctx->tun["measure_gain_alias"] = 0;   // measurement only (THK_MEASURE_HOOKS=1): the RMS prologues read the activation vector in place of the gain vector
@@ -147,7 +146,6 @@ extern "C" int thk_ctx_destroy(thk_ctx* ctx) {
     if (!ctx) return THK_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    ovl_destroy(ctx);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->rope_tab) hipFree(ctx->rope_tab);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -157,7 +155,7 @@ extern "C" int thk_ctx_destroy(thk_ctx* ctx) {
 extern "C" int thk_sync(thk_ctx* ctx) {
     if (!ctx) return THK_ERR_INVALID;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return ovl_check_error_ctx(ctx);
+    return THK_OK;
 }
 extern "C" const char* thk_last_error(thk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 extern "C" void* thk_ctx_stream(thk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }

@@ -1,9 +1,6 @@
-// thk_decode_bodies.hpp — device bodies of the decode step's kernels (fused mat-vec with its prologues / epilogues, attention,
-// greedy pick), shared by the two ways they are launched:
-//   thk_kernels.hip      the HIP kernels (stream launches, hipGraph replays): OVL = 0
-//   thk_ovl_kernels.hip  the kernels of the overlapped dispatch (thk_ovl.cpp: a private user-mode queue on which chosen packets
-//                        carry no barrier bit): OVL flavours add the in-kernel dependency protocol and agent-coherent accesses
-// Internal; device code only.
+// thk_decode_bodies.hpp — device bodies of the decode step's kernels: the fused mat-vec with its prologues / epilogues (the lm-head
+// flavour also finishes the token), attention, the stand-alone greedy pick.  Launched by thk_kernels.hip (stream launches, hipGraph
+// replays).  Internal; device code only.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -11,16 +8,6 @@
 #include "thk_device.hpp"
 
 namespace thk {
-
-// Flavours of a kernel of the overlapped dispatch (template argument OVL; 0 = the stream-ordered kernel):
-//   OVL_WAIT    its packet carries no barrier bit: it waits for its predecessor inside and reads earlier launches' outputs coherently
-//   OVL_ARRIVE  its successor's packet carries no barrier bit: it writes through and arrives on its counters
-//   OVL_QUEUE   launched from the private queue at all (no gridDim builtin) - set on every kernel of thk_ovl_kernels.hip
-enum { OVL_WAIT = 1, OVL_ARRIVE = 2, OVL_QUEUE = 4 };
-// A waiting kernel reads what earlier launches of the step wrote with agent-coherent loads (sc1: served from the memory side,
-// never from this XCD's L2).  Measured alternatives on MI355X, 7B step: invalidating L1 / L2 once per workgroup after the wait
-// (buffer_inv sc1) and loading plainly 2.81 ms against 2.55 ms; plain loads without any invalidate (wrong, an upper bound for
-// cacheable loads) 2.505 ms against 2.517 ms - the coherent loads are not what the protocol costs.
 
 // Development timeline (libthk_trace.so only, built with -DTHK_TRACE; tools/step_trace.py): every wave stamps the 100 MHz
 // s_memrealtime counter at up to four points of its kernel into [workgroup][wave (8)][4].  Scalar instructions only (the stamp
@@ -42,6 +29,9 @@ __device__ __forceinline__ void thk_stamp(unsigned long long* tr, int bid, int s
 #else
 #define THK_STAMP(tr, bid, slot) do { } while (0)
 #endif
+
+template <int NT, bool AGENT>
+__device__ __forceinline__ void finish_token_reduce(const FinishArgs& a, unsigned long long* keys, int nkeys, unsigned long long* sm);
 
 template <int WPB = kWaves>
 __device__ __forceinline__ float block_sum(float v, float* red /* >= WPB floats of LDS */) {
@@ -90,7 +80,7 @@ __device__ __forceinline__ int xs_store_index(int i, int ns) {
 template <int NS, int WPB> struct PrologueK { static constexpr int value = NS ? (NS * 128 + WPB * 64 - 1) / (WPB * 64) : 1; };
 
 // plain copy (th.cpp K1 with no fused producer)
-template <int NS, int WPB, bool COH>
+template <int NS, int WPB>
 struct ProCopy {
     static constexpr int KP = PrologueK<NS, WPB>::value;
     static constexpr int BT = WPB * 64;
@@ -98,7 +88,7 @@ struct ProCopy {
     __device__ __forceinline__ void issue(const GemvArgs& a) {
         if (NS == 0) return;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) v[k] = ld_f4<COH>(a.x, min((int)(threadIdx.x + k * BT) << 2, a.C - 4));
+        for (int k = 0; k < KP; ++k) v[k] = *reinterpret_cast<const f4*>(a.x + min((int)(threadIdx.x + k * BT) << 2, a.C - 4));
     }
     __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns, int) {
         const int C = a.C;
@@ -112,7 +102,7 @@ struct ProCopy {
         } else {
             for (int i = threadIdx.x; i < (ns << 7); i += BT) {
                 f4 o = {0.f, 0.f, 0.f, 0.f};
-                if ((i << 2) < C) o = ld_f4<COH>(a.x, i << 2);
+                if ((i << 2) < C) o = *reinterpret_cast<const f4*>(a.x + (i << 2));
                 *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = o;
             }
         }
@@ -124,7 +114,7 @@ struct ProCopy {
 // EMB: the input vector is the embedding row of the sequence's current token (loader :185-195, th-llama.cpp:577-584: x =
 // f32(table[token,:])), fetched here instead of by a launch of its own; block 0 also writes the f32 row to a.x_out, which
 // the layer's residual add reads two launches later.
-template <int NS, bool EMB, int WPB, bool COH, bool COHS>
+template <int NS, bool EMB, int WPB>
 struct ProRms {
     static constexpr int KP = PrologueK<NS, WPB>::value;
     static constexpr int BT = WPB * 64;
@@ -134,7 +124,7 @@ struct ProRms {
             const h4 h = *reinterpret_cast<const h4*>(row + ic);
             return f4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
         }
-        return ld_f4<COH>(a.x, ic);
+        return *reinterpret_cast<const f4*>(a.x + ic);
     }
     __device__ __forceinline__ void issue(const GemvArgs& a) {
         if (NS == 0) return;
@@ -154,7 +144,7 @@ struct ProRms {
             for (int k = 0; k < KP; ++k) {
                 const int i = threadIdx.x + k * BT;
                 if ((i << 2) >= C) v[k] = f4{0.f, 0.f, 0.f, 0.f};
-                else if (EMB && bid == 0) st_f4<COHS>(a.x_out, i << 2, v[k]);
+                else if (EMB && bid == 0) *reinterpret_cast<f4*>(a.x_out + (i << 2)) = v[k];
                 ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
             }
             ss = block_sum<WPB>(ss, red);
@@ -173,7 +163,7 @@ struct ProRms {
                 f4 t = {0.f, 0.f, 0.f, 0.f};
                 if ((i << 2) < C) {
                     t = ldx(a, row, i << 2);
-                    if (EMB && bid == 0) st_f4<COHS>(a.x_out, i << 2, t);
+                    if (EMB && bid == 0) *reinterpret_cast<f4*>(a.x_out + (i << 2)) = t;
                 }
                 ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
                 *reinterpret_cast<f4*>(xs + xs_index(i << 2, ns)) = t;   // raw copy, normalised below
@@ -207,7 +197,7 @@ __device__ __forceinline__ f4 attn_merge(const float2 (&ml)[NSP], const f4 (&ov)
     }
     return o * (1.0f / L);
 }
-template <int NS, int NSP, int WPB, bool COH>
+template <int NS, int NSP, int WPB>
 struct ProAttn {
     static constexpr int KP = PrologueK<NS, WPB>::value;
     static constexpr int BT = WPB * 64;
@@ -217,8 +207,8 @@ struct ProAttn {
         const int h = e / a.D, d = e - h * a.D;
 #pragma unroll
         for (int s = 0; s < NSP; ++s) {
-            m[s] = ld_f2<COH>(a.part_ml, (h * NSP + s) * 2);
-            o[s] = ld_f4<COH>(a.part_o, (h * NSP + s) * a.D + d);
+            m[s] = *reinterpret_cast<const float2*>(a.part_ml + (h * NSP + s) * 2);
+            o[s] = *reinterpret_cast<const f4*>(a.part_o + (h * NSP + s) * a.D + d);
         }
     }
     __device__ __forceinline__ void issue(const GemvArgs& a) {
@@ -246,11 +236,10 @@ struct ProAttn {
         __syncthreads();
     }
 };
-// COH: loads of the predecessor's outputs are agent-coherent; COHS: stores are written through (overlapped dispatch)
-template <int NS, int PRO, int NSP, int WPB, bool COH, bool COHS> struct ProSelect { typedef ProCopy<NS, WPB, COH> type; };
-template <int NS, int NSP, int WPB, bool COH, bool COHS> struct ProSelect<NS, GEMV_PRO_RMS, NSP, WPB, COH, COHS> { typedef ProRms<NS, false, WPB, COH, COHS> type; };
-template <int NS, int NSP, int WPB, bool COH, bool COHS> struct ProSelect<NS, GEMV_PRO_RMS_EMBED, NSP, WPB, COH, COHS> { typedef ProRms<NS, true, WPB, COH, COHS> type; };
-template <int NS, int NSP, int WPB, bool COH, bool COHS> struct ProSelect<NS, GEMV_PRO_ATTN, NSP, WPB, COH, COHS> { typedef ProAttn<NS, (NSP > 0 ? NSP : 1), WPB, COH> type; };
+template <int NS, int PRO, int NSP, int WPB> struct ProSelect { typedef ProCopy<NS, WPB> type; };
+template <int NS, int NSP, int WPB> struct ProSelect<NS, GEMV_PRO_RMS, NSP, WPB> { typedef ProRms<NS, false, WPB> type; };
+template <int NS, int NSP, int WPB> struct ProSelect<NS, GEMV_PRO_RMS_EMBED, NSP, WPB> { typedef ProRms<NS, true, WPB> type; };
+template <int NS, int NSP, int WPB> struct ProSelect<NS, GEMV_PRO_ATTN, NSP, WPB> { typedef ProAttn<NS, (NSP > 0 ? NSP : 1), WPB> type; };
 
 // ---------------------------------------------------------------- GEMV core
 enum { PRO_COPY = GEMV_PRO_COPY, PRO_RMS = GEMV_PRO_RMS, PRO_ATTN = GEMV_PRO_ATTN, PRO_RMS_EMBED = GEMV_PRO_RMS_EMBED };
@@ -272,16 +261,10 @@ __device__ __forceinline__ h8 ldw(const h8* p) {
 // U = slots per load batch (NS % U == 0 when NS != 0): NR*U 16-byte loads per lane are issued
 // back to back with no intervening branch or wait.
 // bid / nblk: this block's index and the number of blocks working on the op (== blockIdx.x / gridDim.x).
-// OVL: the launch belongs to the overlapped dispatch (thk_ovl.cpp) - the activation vector, residuals and every output are
-// accessed agent-coherently, the workgroup waits for its predecessor AFTER requesting its first weight batch and arrives on its
-// own counters at the end (thk_device.hpp).
-template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool PIPE, int WPB = kWaves, int OVL = 0>
+template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool PIPE, int WPB = kWaves>
 __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, const int nblk) {
     static_assert(!PIPE || (NS != 0 && U == NS), "the pipelined loop keeps one whole row group in flight");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool OVL_W = (OVL & OVL_WAIT) != 0, OVL_A = (OVL & OVL_ARRIVE) != 0;
-    constexpr bool OVL_LD = OVL_W;         // loads of earlier launches' outputs are coherent themselves
-    constexpr bool OVL_ST = OVL_A;       // outputs are written through
     const int C = a.C;
     const int nvec = C >> 3;                                  // 16-byte vectors per row
     const int ns = NS ? NS : ((nvec + 63) >> 6);
@@ -355,7 +338,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     auto epi_fetch = [&](int g, EpiOps& eo) {
         if (EPI == EPI_RESID) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r) eo.resid[r] = ld_f1<OVL_LD>(a.resid + min(NR * g + r, a.R - 1));      // wave-uniform address: one request
+            for (int r = 0; r < NR; ++r) eo.resid[r] = a.resid[min(NR * g + r, a.R - 1)];      // wave-uniform address: one request
         } else if (EPI == EPI_ROPE_KV) {
             const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E, j = rr % a.D;
             const float2 t = *reinterpret_cast<const float2*>(a.rope_tab + ((size_t)pos_pipe * (a.D >> 1) + (j >> 1)) * 2);
@@ -368,12 +351,12 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         if (EPI == EPI_STORE) {
             if (lane == 0) {
 #pragma unroll
-                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) st_f1<OVL_ST>(a.y + NR * g + r, acc[r]);
+                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) a.y[NR * g + r] = acc[r];
             }
         } else if (EPI == EPI_RESID) {       // K11 th.cpp:2136-2147: c = a + b
             if (lane == 0) {
 #pragma unroll
-                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) st_f1<OVL_ST>(a.y + NR * g + r, (eo ? eo->resid[r] : ld_f1<OVL_LD>(a.resid + NR * g + r)) + acc[r]);
+                for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) a.y[NR * g + r] = (eo ? eo->resid[r] : a.resid[NR * g + r]) + acc[r];
             }
         } else if (EPI == EPI_ROPE_KV) {     // K6 th.cpp:1476-1490 + K/V append th-llama.cpp:332-339
             if (lane == 0) {
@@ -389,14 +372,14 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
                 }
                 if (which != 0 && a.kv_f16) {     // optional f16 cache: RNE rounding at the append (v_cvt_f16_f32)
                     _Float16* dh = reinterpret_cast<_Float16*>(which == 1 ? a.kcache : a.vcache) + (size_t)pos * a.E;
-                    st_h1<OVL_ST>(dh + rr, (_Float16)y0); st_h1<OVL_ST>(dh + rr + 1, (_Float16)y1);
+                    dh[rr] = (_Float16)y0; dh[rr + 1] = (_Float16)y1;
                 } else {
                     float* dst = which == 0 ? a.y : (which == 1 ? a.kcache + (size_t)pos * a.E : a.vcache + (size_t)pos * a.E);
-                    st_f1<OVL_ST>(dst + rr, y0); st_f1<OVL_ST>(dst + rr + 1, y1);
+                    dst[rr] = y0; dst[rr + 1] = y1;
                 }
             }
         } else if (EPI == EPI_SWIGLU) {      // K12 th.cpp:2706-2707, K13 :2512-2524
-            if (lane == 0) { const float u1 = acc[0]; st_f1<OVL_ST>(a.y + g, (u1 / (1.0f + expf(-u1))) * acc[1 % NR]); }
+            if (lane == 0) { const float u1 = acc[0]; a.y[g] = (u1 / (1.0f + expf(-u1))) * acc[1 % NR]; }
         } else {                              // EPI_HEAD: K3 th.cpp:3926-3943 (+Q1 switch)
             if (lane == 0) {
 #pragma unroll
@@ -405,7 +388,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
                     if (row < a.R) {
                         const bool covered = !a.lm_faithful || (row % a.q1_split) < a.q1_cov;
                         const float v = covered ? acc[r] + acc_hi[r] : acc[r];
-                        st_f1<OVL_ST>(a.y + row, v);
+                        a.y[row] = v;
                         const unsigned long long k = argmax_key(v, (unsigned)row);
                         best = k > best ? k : best;
                     }
@@ -422,15 +405,11 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     const h8* rp0[NR];
     h8 w0[NR][U];
     row_ptrs(has_first ? g : a.n_groups - 1, rp0);   // idle waves (more waves than groups) load a valid row:
-    typename ProSelect<NS, PRO, NSP, WPB, OVL_LD, OVL_ST>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
-    if (!OVL_W) pro.issue(a);
+    typename ProSelect<NS, PRO, NSP, WPB>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
+    pro.issue(a);
     __builtin_amdgcn_sched_barrier(0);
     load_batch(rp0, 0, w0);
     __builtin_amdgcn_sched_barrier(0);
-    if (OVL_W) {     // the weights are on their way; now the predecessor has to be done before its outputs are touched
-        ovl_wait(a.ovl);
-        pro.issue(a);
-    }
     pro.finish(a, xs, red, ns, bid);
     THK_STAMP(a.trace, bid, 1);
 
@@ -549,83 +528,107 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         if (threadIdx.x == 0) {
             unsigned long long b = wb[0];
             for (int w = 1; w < WPB; ++w) b = wb[w] > b ? wb[w] : b;
-            st_u64<OVL_ST>(a.block_best + bid, b);
+            // folded pick: the key crosses to another XCD inside this launch, so it is written through; nobody waits for it here
+            if (a.fin.folded) st_agent_u64(a.block_best + bid, b); else a.block_best[bid] = b;
+        }
+        // The greedy pick folded into this launch (round 4).  The workgroup with the HIGHEST index - dispatched last on its XCD,
+        // so it never holds a slot some not-yet-dispatched workgroup of its XCD needs - waits until every key slot is non-zero (a
+        // key is never 0 and the slots are zeroed again below), reduces them and finishes the token.  The other workgroups pay one
+        // fire-and-forget store: a first version in which every workgroup waited for its store's acknowledgement and then drew a
+        // ticket with a returning atomic lengthened the launch by 8 us (two memory round trips per workgroup on 1.6 generations of
+        // workgroups) - more than the finish_token launch and its boundary (4.3 + 2.0 us) cost.
+        if (a.fin.folded && bid == nblk - 1) {
+            __syncthreads();                     // wave 0's key store is issued; xs (the activation vector) is dead from here on
+            finish_token_reduce<WPB * 64, true>(a.fin, a.block_best, nblk, reinterpret_cast<unsigned long long*>(xs));
         }
     }
-    if (OVL_A) ovl_arrive<WPB, EPI == EPI_HEAD>(a.ovl, bid);
 }
 // ---------------------------------------------------------------- attention (decode)
-// grid = H * nsplit blocks; block (h, s) owns positions [s*tc, (s+1)*tc) of head h.
-// A position's head slice is D contiguous floats; D/4 lanes x float4 cover it, so a
-// wave-instruction fetches PPW = 64/(D/4) positions.  Each wave runs an online
-// softmax over its positions, the four waves are merged through LDS, and the block
-// writes (m, l, o[D]) for the split (or the normalised output when nsplit == 1).
-// Scores: S = (q.k) * 1/sqrt(D) scaled after the sum (th.cpp:527-529, th-llama.cpp:518);
-// softmax K10 th.cpp:1901-1957.
-// WAVES waves per block share one (head, split): more waves = fewer positions per wave, so every
-// wave needs a single load batch (one HBM round trip) at T = 512 with 4 splits.
+// grid = H * nsplit * VS blocks; block (h, s, vh) owns positions [s*tc, (s+1)*tc) of head h and, when VS == 2, half vh of the
+// head's V columns.
+// A position's head slice is D contiguous floats; D/4 lanes x float4 cover it, so a wave-instruction fetches PPW = 64/(D/4)
+// positions of K.  Each wave runs an online softmax over its positions, the waves are merged through LDS, and the block writes
+// (m, l, o[D/VS]) for the split (or the normalised output when nsplit == 1).
+// Scores: S = (q.k) * 1/sqrt(D) scaled after the sum (th.cpp:527-529, th-llama.cpp:518); softmax K10 th.cpp:1901-1957.
+// WAVES waves per block share one (head, split): more waves = fewer positions per wave, so every wave needs a single load batch
+// (one HBM round trip) at T = 512 with 4 splits.
+//
+// VS == 2 (round 4): 7B has H * nsplit = 128 (head, split) pairs and the chip has 256 CUs; a CU that pulls a split's 128 KB alone
+// is what bounds the launch.  Doubling the splits doubles the partials every wo workgroup reads (measured -2 %).
+// Instead TWO workgroups share a (head, split): both read its K slice and compute the same scores (bit-identical: same
+// instructions on the same data), each takes half of the V columns and writes half of o with the identical (m, l) - 96 KB per CU
+// on 256 CUs and the consumer's prologue (ProAttn) reads exactly what it read before.  The pair is workgroups b and b + 8 of a
+// group of 16: workgroup i runs on XCD i % 8, so the pair shares an L2 and the second K read is an L2 hit (or merges with the
+// first in flight).  V lanes: D/(4 VS) lanes cover a position's half slice, PPW * VS positions per wave-instruction, UB / VS
+// instructions.  The position a lane takes in V instruction u' is the one its own K lane group handled in K instruction
+// VS*u' + (its V lane group & 1), so the softmax weight is already in the lane's registers (a select, no shuffle).
+//
+// tc_dyn (round 4): tc follows the LIVE context, tc = ceil(T / nsplit) rounded up to the wave batch (PPW * UB positions), computed
+// here from the device-resident position - every (head, split) has work at every T >= nsplit * PPW * UB instead of the splits
+// partitioning the cache capacity n_ctx (at T << n_ctx all but the first would exit empty).
 // one position's 4-element slice for this lane: f32 cache (16 bytes) or f16 cache (8 bytes, widened by v_cvt_f32_f16)
-template <bool KVH, bool COH>
+template <bool KVH>
 __device__ __forceinline__ f4 ld_kv4(const float* base, size_t elem_off) {
-    if (COH) {        // sc1 | nt: the row the predecessor has just appended must come from the memory side; nothing here is re-read
-        if (KVH) {
-            const u2v t = __builtin_amdgcn_raw_buffer_load_b64(coh_rsrc(base), (int)(elem_off * 2), 0, kAuxSc1 | kAuxNt);
-            const h4 h = __builtin_bit_cast(h4, t);
-            return f4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
-        }
-        return ld_f4<true, kAuxSc1 | kAuxNt>(base, (int)elem_off);
-    }
     if (KVH) {
         const h4 h = __builtin_nontemporal_load(reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(base) + elem_off));
         return f4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
     }
     return __builtin_nontemporal_load(reinterpret_cast<const f4*>(base + elem_off));
 }
-template <int D, int WAVES, bool KVH, int OVL = 0>
+template <int D, int WAVES, bool KVH, int VS = 1>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
-    constexpr int LPP = D / 4;          // lanes per position
-    constexpr int PPW = 64 / LPP;       // positions per wave-instruction
-    constexpr int UB = 8;               // wave-instructions per batch (K and V each)
-    __shared__ float sm_o[WAVES][D];
+    constexpr int LPP = D / 4;          // lanes per position (K)
+    constexpr int PPW = 64 / LPP;       // positions per wave-instruction (K)
+    constexpr int UB = 8;               // K wave-instructions per batch
+    constexpr int DV = D / VS;          // V columns of this block
+    constexpr int LPV = DV / 4, PPV = 64 / LPV, UBV = UB / VS;   // the same three for V
+    static_assert(VS == 1 || VS == 2, "V columns are whole or halved");
+    __shared__ float sm_o[WAVES][DV];
     __shared__ float sm_ml[WAVES][2];
-    constexpr bool OVL_W = (OVL & OVL_WAIT) != 0, OVL_A = (OVL & OVL_ARRIVE) != 0;
-    constexpr bool OVL_LD = OVL_W, OVL_ST = OVL_A;
 
     // prefill: nq > 1 causal queries share one launch; query qi sits at position pos + qi
-    const int per_q = a.H * a.nsplit;
+    const int hs = a.H * a.nsplit;
+    const int per_q = hs * VS;
     const int qi = a.nq > 1 ? bid / per_q : 0;
-    const int hb = bid - qi * per_q;
+    const int r = bid - qi * per_q;
+    int hb = r, vh = 0;
+    if (VS == 2) {
+        if ((hs & 7) == 0) { vh = (r >> 3) & 1; hb = ((r >> 4) << 3) | (r & 7); }   // the pair = workgroups b, b + 8: same XCD
+        else { vh = r & 1; hb = r >> 1; }
+    }
     const int h = hb / a.nsplit, s = hb - h * a.nsplit;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPP, li = lane - grp * LPP;
+    const int grv = lane / LPV, lv = lane - grv * LPV;          // VS == 2: grp == grv >> 1
+    const int sel = (VS == 2) ? (grv & 1) : 0;
     THK_STAMP(a.trace, bid, 0);
-    if (OVL_W) ovl_wait(a.ovl);
     const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + qi + 1;
     const int E = a.H * D;
-    const int t0 = s * a.tc, t1 = min(t0 + a.tc, T);
+    int tc = a.tc;
+    if (a.tc_dyn) tc = (((T + a.nsplit - 1) / a.nsplit + PPW * UB - 1) / (PPW * UB)) * (PPW * UB);
+    const int t0 = s * tc, t1 = min(t0 + tc, T);
 
-    const f4 q = ld_f4<OVL_LD>(a.q, qi * E + h * D + li * 4);
-    const size_t hoff = (size_t)(h * D + li * 4);      // element offset of this lane's slice inside a cache row
+    const f4 q = *reinterpret_cast<const f4*>(a.q + qi * E + h * D + li * 4);
+    const size_t koff = (size_t)(h * D + li * 4);               // element offset of this lane's K slice inside a cache row
+    const size_t voff = (size_t)(h * D + vh * DV + lv * 4);     // ... and of its V slice
 
     float m = -INFINITY, l = 0.f;
     f4 o = {0.f, 0.f, 0.f, 0.f};
     // wave w takes positions t0 + (it*WAVES + w)*PPW*UB + u*PPW + grp.  Loads are branch-free:
     // positions past the end are clamped to a valid row and masked out of the softmax.
     // (Round 3 tried fetching the first batch BEFORE the device-resident position is known - every row below n_ctx is
-    // allocated - to take the position's round trip off the critical path: 0.6 us per launch SLOWER on MI355X, removed.
-    // Same outcome under the overlapped dispatch, where the batch was requested before the wait for the predecessor and only
-    // the newest row fetched again afterwards: 2.5265 -> 2.5305 ms per 7B step.  Traffic added to a mat-vec's tail slows the tail.)
+    // allocated - to take the position's round trip off the critical path: 0.6 us per launch SLOWER on MI355X, removed.)
     for (int tb = t0 + wave * (PPW * UB); tb < t1; tb += WAVES * PPW * UB) {
-        f4 kv[UB], vv[UB];
+        f4 kv[UB], vv[UBV];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int t = min(tb + u * PPW + grp, t1 - 1);
-            kv[u] = ld_kv4<KVH, OVL_LD>(a.kcache, (size_t)t * E + hoff);
+            kv[u] = ld_kv4<KVH>(a.kcache, (size_t)t * E + koff);
         }
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int t = min(tb + u * PPW + grp, t1 - 1);
-            vv[u] = ld_kv4<KVH, OVL_LD>(a.vcache, (size_t)t * E + hoff);
+        for (int u = 0; u < UBV; ++u) {
+            const int t = min(tb + (VS * u + sel) * PPW + grp, t1 - 1);
+            vv[u] = ld_kv4<KVH>(a.vcache, (size_t)t * E + voff);
         }
         __builtin_amdgcn_sched_barrier(0);
         float sc[UB];
@@ -642,22 +645,32 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
         const float mn = fmaxf(m, bm);
         const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
         l *= alpha; o *= alpha;
+        float p[UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const float p = expf(sc[u] - mn);   // exp(-inf) == 0 for masked positions
-            l += p; o += vv[u] * p;
+        for (int u = 0; u < UB; ++u) { p[u] = expf(sc[u] - mn); l += p[u]; }   // exp(-inf) == 0 for masked positions
+        // VS == 2: the lane's V position of instruction u is K position 2u + sel.  Blended with a bit mask, not with `sel ? a : b`:
+        // the compiler turns a select of two array elements into ONE dynamically indexed access and then moves the whole array
+        // into LDS (18 KB per workgroup, attention 6x slower - measured, round 4).
+        const unsigned selm = 0u - (unsigned)sel;
+#pragma unroll
+        for (int u = 0; u < UBV; ++u) {
+            float pv = p[u % UB];
+            if (VS == 2) pv = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, p[(2 * u + 1) % UB]) & selm) | (__builtin_bit_cast(unsigned, p[(2 * u) % UB]) & ~selm));
+            o += vv[u] * pv;
         }
         m = mn;
         THK_STAMP(a.trace, bid, 1);
     }
-    // merge the PPW lane groups of the wave (same m): sum l and o across groups
-    if (PPW >= 2) { l += __shfl_xor(l, LPP); o.x += __shfl_xor(o.x, LPP); o.y += __shfl_xor(o.y, LPP); o.z += __shfl_xor(o.z, LPP); o.w += __shfl_xor(o.w, LPP); }
-    if (PPW >= 4) { l += __shfl_xor(l, 2 * LPP); o.x += __shfl_xor(o.x, 2 * LPP); o.y += __shfl_xor(o.y, 2 * LPP); o.z += __shfl_xor(o.z, 2 * LPP); o.w += __shfl_xor(o.w, 2 * LPP); }
-    if (lane < LPP) *reinterpret_cast<f4*>(&sm_o[wave][lane * 4]) = o;
+    // merge the lane groups of the wave (same m): l over the PPW K groups, o over the PPV V groups
+#pragma unroll
+    for (int off = LPP; off < 64; off <<= 1) l += __shfl_xor(l, off);
+#pragma unroll
+    for (int off = LPV; off < 64; off <<= 1) { o.x += __shfl_xor(o.x, off); o.y += __shfl_xor(o.y, off); o.z += __shfl_xor(o.z, off); o.w += __shfl_xor(o.w, off); }
+    if (lane < LPV) *reinterpret_cast<f4*>(&sm_o[wave][lane * 4]) = o;
     if (lane == 0) { sm_ml[wave][0] = m; sm_ml[wave][1] = l; }
     __syncthreads();
     THK_STAMP(a.trace, bid, 2);
-    if (threadIdx.x < D) {
+    if (threadIdx.x < DV) {
         const int d = threadIdx.x;
         float M = -INFINITY;
         for (int w = 0; w < WAVES; ++w) M = fmaxf(M, sm_ml[w][0]);
@@ -668,44 +681,48 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
             L += sm_ml[w][1] * f; od += sm_o[w][d] * f;
         }
         if (a.out) {   // nsplit == 1: finished output, [H*D]
-            st_f1<OVL_ST>(a.out + (size_t)qi * E + h * D + d, od / L);
+            a.out[(size_t)qi * E + h * D + vh * DV + d] = od / L;
         } else {       // split partial: combined by the consumer's prologue (ProAttn) or by attn_combine_kernel
-            st_f1<OVL_ST>(a.part_o + (size_t)(h * a.nsplit + s) * D + d, od);
-            if (d == 0) { st_f1<OVL_ST>(a.part_ml + (h * a.nsplit + s) * 2, M); st_f1<OVL_ST>(a.part_ml + (h * a.nsplit + s) * 2 + 1, L); }
+            a.part_o[(size_t)(h * a.nsplit + s) * D + vh * DV + d] = od;
+            if (d == 0 && vh == 0) { a.part_ml[(h * a.nsplit + s) * 2] = M; a.part_ml[(h * a.nsplit + s) * 2 + 1] = L; }
         }
     }
     THK_STAMP(a.trace, bid, 3);
-    if (OVL_A) ovl_arrive<WAVES, true>(a.ovl, bid);
 }
 
-// ---------------------------------------------------------------- the step's last launch
-// Greedy pick + sequence bookkeeping after the head kernel: reduce the per-block
-// best keys, write the token (first max wins, th-llama.cpp:826-838), log it,
-// advance the position when asked.
+// ---------------------------------------------------------------- finishing a token
+// Greedy pick + sequence bookkeeping once every workgroup of the head kernel has written its best key: reduce the keys, write the
+// token (first max wins, th-llama.cpp:826-838), log it, advance the position when asked.  Runs as the tail of the lm-head launch's
+// highest-numbered workgroup (gemv_body, EPI_HEAD with fin.folded; AGENT = the keys come from other XCDs inside the same launch,
+// so every slot is polled until it is non-zero and zeroed again) or as a launch of its own (finish_token_kernel: engine path,
+// tunable fold_finish = 0).
 // n_ctx > 0: the position only advances while pos + 1 < n_ctx, so a decode loop that outruns the host-side check
 // (thk_model_decode_step(s) refuse it) can never index the caches or the RoPE table out of bounds.
 // epoch != NULL: the engine's tag epoch is bumped here, i.e. after the engine launch of this step and before the next.
-// OVL: waits for the head kernel (hence, transitively, for every launch of the step), then zeroes the step's arrival counters;
-// the next step's first packet carries the barrier bit, so nobody is polling them.
-template <int OVL>
-__device__ __forceinline__ void finish_token_body(const FinishArgs& a) {
-    __shared__ unsigned long long sm[kBlock];
-    THK_STAMP(a.trace, 0, 0);
-    if (OVL & OVL_WAIT) ovl_wait(a.ovl);
+template <int NT, bool AGENT>
+__device__ __forceinline__ void finish_token_reduce(const FinishArgs& a, unsigned long long* keys, int nkeys, unsigned long long* sm /* NT u64 of LDS */) {
     unsigned long long b = 0ull;
-    for (int i = threadIdx.x; i < a.nblocks; i += kBlock) {
-        const unsigned long long k = (OVL & OVL_WAIT) ? __hip_atomic_load(a.block_best + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : a.block_best[i];
+    bool late = false;
+    const unsigned long long t0 = AGENT ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    for (int i = threadIdx.x; i < nkeys; i += NT) {
+        unsigned long long k;
+        if (AGENT) {       // written by other workgroups of THIS launch: read from the memory side until it is there (bounded: 1 s of the 100 MHz clock)
+            while ((k = ld_agent_u64(keys + i)) == 0ull) {
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 100000000ull) { late = true; break; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            st_agent_u64(keys + i, 0ull);                // the slot is empty again for the next step's launch
+        } else {
+            k = keys[i];
+        }
         b = k > b ? k : b;
     }
+    if (AGENT && late && a.st) a.st->pad = 1;            // a workgroup of this launch never delivered: reported by thk_model_seq_get / seq_last_token
     sm[threadIdx.x] = b;
     __syncthreads();
-    for (int s = kBlock / 2; s > 0; s >>= 1) {
+    for (int s = NT / 2; s > 0; s >>= 1) {
         if (threadIdx.x < s) { const unsigned long long o = sm[threadIdx.x + s]; if (o > sm[threadIdx.x]) sm[threadIdx.x] = o; }
         __syncthreads();
-    }
-    if (OVL && a.ovl_counters) {       // any overlapped flavour: the step's arrival counters start from zero again
-        for (int i = threadIdx.x; i < a.ovl_n_launches * kOvlShards; i += kBlock)
-            __hip_atomic_store(a.ovl_counters + (size_t)(i / kOvlShards) * kOvlLaunchWords + (i % kOvlShards) * kOvlShardWords, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (threadIdx.x == 0) {
         SeqState* st = a.st;
@@ -722,6 +739,11 @@ __device__ __forceinline__ void finish_token_body(const FinishArgs& a) {
         }
         if (a.epoch) *a.epoch += 1u;
     }
+}
+__device__ __forceinline__ void finish_token_body(const FinishArgs& a) {
+    __shared__ unsigned long long sm[kBlock];
+    THK_STAMP(a.trace, 0, 0);
+    finish_token_reduce<kBlock, false>(a, const_cast<unsigned long long*>(a.block_best), a.nblocks, sm);
     THK_STAMP(a.trace, 0, 3);
 }
 

@@ -3,7 +3,7 @@
 //   thk_ops.cpp            one operator per reference kernel (the 16 cmdbuf_* encoders, th.cpp:617-4351)
 //   thk_model.cpp          model level: th_eval_gpu (th-llama.cpp:464-660) as hipGraph replays, per-sequence state, pipeline stages
 //   thk_model_prefill.cpp  MFMA prompt prefill; thk_model_engine.cpp  the optional one-launch engine's program
-//   thk_ovl.cpp            the optional overlapped dispatch (private AQL queue); thk_pp.cpp / thk_peer.hip  stage-to-stage transports
+//   thk_pp.cpp / thk_peer.hip  stage-to-stage transports
 // Internal; not part of the ABI.
 #pragma once
 #include "../../include/thk.h"
@@ -42,7 +42,6 @@ struct thk_ctx {
     size_t scratch_bytes = 0;
     float* rope_tab = nullptr;      // operator-API RoPE table
     size_t rope_tab_floats = 0;
-    void* ovl = nullptr;            // overlapped dispatch: the private queue and its code object (thk_ovl.cpp), created on first use
 };
 
 struct LayerW {
@@ -63,13 +62,14 @@ struct SeqBuf {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     std::map<int, std::pair<hipGraph_t, hipGraphExec_t>> multi;     // n decode steps (2 <= n <= kMaxGraphSteps) in ONE graph (thk_model_prepare_steps / first use)
+    std::map<int, unsigned long long> multi_used; unsigned long long multi_clock = 0;   // last use per n: at most kMaxMultiGraphs are kept (LRU)
     int pos_host = 0;                // position the NEXT step evaluates (every change goes through this API, so the host knows it exactly)
     EngOp* eng_ops = nullptr;        // device: this sequence's engine program (cache / hidden-state pointers differ per sequence)
     int eng_n_ops = 0;
-    void* ovl_prog = nullptr;        // overlapped dispatch: this sequence's step as AQL packets + device-resident kernel arguments (thk_ovl.cpp)
 };
 
 static const int kGenLogCap = 4096;
+static const int kMaxMultiGraphs = 6;     // multi-step graphs kept per sequence (n * ~161 kernel nodes each); the least recently used one is evicted
 static const int kMaxGraphSteps = 32;     // longest multi-step graph; a request of n steps replays floor(n / 32) of these and ONE graph of the remainder
 
 struct thk_model {
@@ -88,7 +88,8 @@ struct thk_model {
     std::vector<SeqBuf> seqs;
     // working buffers shared by all sequences (steps run back to back on one stream)
     float *x = nullptr, *q = nullptr, *u = nullptr, *attn_out = nullptr, *part_o = nullptr, *part_ml = nullptr;
-    unsigned long long* block_best = nullptr;
+    unsigned long long* block_best = nullptr;       // arg-max key per lm-head workgroup of the decode step
+    unsigned long long* block_best_aux = nullptr;   // the same for head launches outside the step (prefill)
     float* rope_tab = nullptr;        // [n_ctx][D/2][2]
     // launch geometry resolved at finalize
     int nsplit = 4, tc = 128, nt = 1, use_graph = 1;
@@ -114,10 +115,9 @@ struct thk_model {
     unsigned long long* eng_trace = nullptr;   // development timeline (tunable engine_trace), [n_cu][n_ops][8]
     unsigned long long* trace_buf = nullptr;   // development timeline of the launch path (thk_model_step_trace, THK_TRACE builds)
     bool trace_on = false;
-    // overlapped dispatch (thk_ovl.cpp)
-    unsigned* ovl_counters = nullptr;    // device: kOvlLaunchWords arrival-counter words per launch of a step
-    unsigned* ovl_err = nullptr;         // device: the queue's error word
-    bool ovl_rec = false;                // enqueue_step is recording a step program: link every launch to its predecessor
+    int fold_finish = 1;                 // tunable fold_finish: the lm-head launch's last workgroup picks the greedy token (no finish_token launch)
+    int attn_vsplit = 2;                 // tunable attn_vsplit: workgroups per (head, split) of the attention launch, each taking 1/vsplit of the V columns
+    int attn_tc_dyn = 1;                 // tunable attn_tc_dyn: the context splits partition the LIVE context (computed on the device), not the cache capacity
 };
 
 // ---------------------------------------------------------------- model internals shared by thk_model*.cpp
@@ -135,15 +135,6 @@ int set_seq_state(thk_model* m, int seq, int token, int pos, bool reset_gen);   
 bool engine_plan(thk_model* m);                                                 // thk_model_engine.cpp
 int engine_build_program(thk_model* m, SeqBuf& sb);
 int check_engine_error(thk_model* m);
-// overlapped dispatch (thk_ovl.cpp)
-int enqueue_step_recorded(thk_model* m, int seq);      // thk_model.cpp: enqueue_step with thk::ovl_recorder set (nothing is launched)
-bool ovl_eligible(const thk_model* m, const char** why);
-int ovl_decode_steps(thk_model* m, int seq, int n_steps);
-int ovl_check_error(thk_model* m);
-int ovl_check_error_ctx(thk_ctx* ctx);
-void ovl_free_seq(SeqBuf& sb);
-void ovl_destroy(thk_ctx* ctx);
-
 // ---------------------------------------------------------------- helpers (thk_ctx.cpp)
 int fail(thk_ctx* ctx, int code, const char* fmt, ...);
 #define HIPCHK(ctx, call)                                                                                  \

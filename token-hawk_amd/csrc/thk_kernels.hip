@@ -28,18 +28,21 @@
 
 namespace thk {
 
-thread_local OvlRecorder* ovl_recorder = nullptr;
-void OvlRecorder::add(const char* name, int grid, int block, int lds_dynamic, const void* args, int arg_bytes) {
-    if (n >= cap || arg_bytes > (int)sizeof(v[0].args)) { overflow = true; return; }
-    Launch& l = v[n++];
-    snprintf(l.name, sizeof l.name, "%s", name);
-    l.grid = grid; l.block = block; l.lds_dynamic = lds_dynamic; l.arg_bytes = arg_bytes;
-    memcpy(l.args, args, arg_bytes);
-}
-
+// Kernel-argument preload (round 4).  A wave's first instructions used to be s_load_dword of its kernel arguments - a scalar-cache
+// miss that goes to L2 and, for the first waves on every XCD, to memory - and nothing, not even the first weight request, could be
+// issued before it returned: part of every launch's ~1.8 us ramp, 161 times per token.  gfx950 can deliver the first 14 dwords of
+// the kernarg segment in SGPRs at wave launch (hipcc -mllvm -amdgpu-kernarg-preload-count=14, .amdhsa_user_sgpr_kernarg_preload_length;
+// the code object keeps a fall-back prologue for firmware without the feature).  Only EXPLICIT scalar arguments are preloaded, not
+// the members of a by-value struct, so everything the code needs before its first `s_waitcnt lgkmcnt` - the weight bases, the
+// activation and gain vectors, the column / group / row counts and the grid size (gridDim.x is an implicit argument at the END of
+// the segment) - travels as leading scalars and the rest of the argument block follows as the struct it always was.
 template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool PIPE, int WPB>
-__global__ __launch_bounds__(WPB * 64) void gemv_kernel(const GemvArgs a) {
-    gemv_body<NR, U, NS, PRO, EPI, NT, NSP, PIPE, WPB>(a, blockIdx.x, gridDim.x);
+__global__ __launch_bounds__(WPB * 64) void gemv_kernel(const uint16_t* W0, const uint16_t* W1, const uint16_t* W2, const float* x, const float* gain,
+                                                        int C, int n_groups, int R_or_E, int nblk, const GemvArgs a) {
+    GemvArgs b = a;
+    b.W[0] = W0; b.W[1] = W1; b.W[2] = W2; b.x = x; b.gain = gain; b.C = C; b.n_groups = n_groups;
+    if (EPI == EPI_ROPE_KV) b.E = R_or_E; else b.R = R_or_E;
+    gemv_body<NR, U, NS, PRO, EPI, NT, NSP, PIPE, WPB>(b, blockIdx.x, nblk);
 }
 
 template <int NR, int U, int NS, int PRO, int EPI, int NSP, bool PIPE, int WPB>
@@ -47,13 +50,6 @@ static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_
     const int ns = NS ? NS : (((a.C >> 3) + 63) >> 6);
     const size_t smem = (size_t)ns * 512 * 4 + 128;
     (void)nt;   // weights always stream with non-temporal loads (default-policy loads measured 8 % slower)
-    if (OvlRecorder* r = ovl_recorder) {       // overlapped dispatch: record, do not launch (the kernel lives in libthk_ovl.hsaco)
-        char name[64];
-        snprintf(name, sizeof name, "thk_ovl_gemv_%d_%d_%d_%d_%d_%d_%d", NR, U, NS, PRO, EPI, NSP, (int)PIPE);
-        if (WPB != kWaves || NS == 0) return hipErrorInvalidValue;
-        r->add(name, grid, WPB * 64, (int)smem, &a, sizeof a);
-        return hipSuccess;
-    }
     auto kn = gemv_kernel<NR, U, NS, PRO, EPI, true, NSP, PIPE, WPB>;
     static size_t attr_set[kMaxDevices] = {};   // per instantiation AND per device; first call happens outside graph capture
     if (smem > 48 * 1024) {
@@ -73,7 +69,7 @@ static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kn), WPB * 64, smem);
         fprintf(stderr, "[thk] gemv<NR=%d,U=%d,NS=%d,PRO=%d,EPI=%d,PIPE=%d,WPB=%d> grid=%d smem=%zu: %d blocks/CU (occupancy API)\n", NR, U, NS, PRO, EPI, (int)PIPE, WPB, grid, smem, nb);
     }
-    hipLaunchKernelGGL(kn, dim3(grid), dim3(WPB * 64), smem, st, a);
+    hipLaunchKernelGGL(kn, dim3(grid), dim3(WPB * 64), smem, st, a.W[0], a.W[1], a.W[2], a.x, a.gain, a.C, a.n_groups, EPI == EPI_ROPE_KV ? a.E : a.R, grid, a);
     return hipGetLastError();
 }
 template <int NR, int U, int NS, int PRO, int EPI, bool PIPE, int WPB>
@@ -169,34 +165,35 @@ hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, b
 }
 
 
-template <int D, int WAVES, bool KVH>
-__global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(const AttnArgs a) {
-    attn_body<D, WAVES, KVH>(a, blockIdx.x);
+// leading scalars: preloaded into SGPRs at wave launch (see gemv_kernel) - the position, q and the cache rows are what the chain
+// of dependent loads starts from
+template <int D, int WAVES, bool KVH, int VS>
+__global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(const int32_t* pos_ptr, const float* q, const float* kcache, const float* vcache,
+                                                                 int pos_val, int H, int nsplit, int tc, int tc_dyn, int nq, const AttnArgs a) {
+    AttnArgs b = a;
+    b.pos_ptr = pos_ptr; b.q = q; b.kcache = kcache; b.vcache = vcache; b.pos_val = pos_val; b.H = H; b.nsplit = nsplit; b.tc = tc; b.tc_dyn = tc_dyn; b.nq = nq;
+    attn_body<D, WAVES, KVH, VS>(b, blockIdx.x);
 }
 
+template <int D, int WAVES>
+static void launch_attn_dw(const AttnArgs& a, int grid, hipStream_t st) {
+    const bool v2 = a.vsplit == 2;
+#define THK_ATTN_GO(kvh, vs) hipLaunchKernelGGL((attn_decode_kernel<D, WAVES, kvh, vs>), dim3(grid), dim3(WAVES * 64), 0, st, a.pos_ptr, a.q, a.kcache, a.vcache, \
+                                                a.pos_val, a.H, a.nsplit, a.tc, a.tc_dyn, a.nq, a)
+    if (a.kv_f16) { if (v2) THK_ATTN_GO(true, 2); else THK_ATTN_GO(true, 1); }
+    else { if (v2) THK_ATTN_GO(false, 2); else THK_ATTN_GO(false, 1); }
+#undef THK_ATTN_GO
+}
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
-    const int grid = a.H * a.nsplit * (a.nq > 1 ? a.nq : 1);
+    if (a.vsplit != 1 && a.vsplit != 2) return hipErrorInvalidValue;
+    const int grid = a.H * a.nsplit * a.vsplit * (a.nq > 1 ? a.nq : 1);
     const bool w8 = a.waves == 8;
-    if (OvlRecorder* r = ovl_recorder) {
-        char name[64];
-        snprintf(name, sizeof name, "thk_ovl_attn_%d_%d_%d", a.D, w8 ? 8 : 4, a.kv_f16 ? 1 : 0);
-        if (a.nq > 1) return hipErrorInvalidValue;
-        r->add(name, grid, w8 ? 512 : 256, 0, &a, sizeof a);
-        return hipSuccess;
-    }
-#define THK_ATTN(d)                                                                                           \
-    case d:                                                                                                   \
-        if (a.kv_f16) {                                                                                        \
-            if (w8) hipLaunchKernelGGL((attn_decode_kernel<d, 8, true>), dim3(grid), dim3(512), 0, st, a);    \
-            else hipLaunchKernelGGL((attn_decode_kernel<d, 4, true>), dim3(grid), dim3(256), 0, st, a);       \
-        } else if (w8) hipLaunchKernelGGL((attn_decode_kernel<d, 8, false>), dim3(grid), dim3(512), 0, st, a); \
-        else hipLaunchKernelGGL((attn_decode_kernel<d, 4, false>), dim3(grid), dim3(256), 0, st, a);          \
-        break;
     switch (a.D) {
-        THK_ATTN(64) THK_ATTN(128) THK_ATTN(256)
+        case 64: if (w8) launch_attn_dw<64, 8>(a, grid, st); else launch_attn_dw<64, 4>(a, grid, st); break;
+        case 128: if (w8) launch_attn_dw<128, 8>(a, grid, st); else launch_attn_dw<128, 4>(a, grid, st); break;
+        case 256: if (w8) launch_attn_dw<256, 8>(a, grid, st); else launch_attn_dw<256, 4>(a, grid, st); break;
         default: return hipErrorInvalidValue;
     }
-#undef THK_ATTN
     return hipGetLastError();
 }
 
@@ -344,7 +341,7 @@ hipError_t launch_embed(const uint16_t* table, const SeqState* st_dev, int token
 // n_ctx > 0: the position only advances while pos + 1 < n_ctx, so a decode loop that outruns the host-side check
 // (thk_model_decode_step(s) refuse it) can never index the caches or the RoPE table out of bounds.
 // epoch != NULL: the engine's tag epoch is bumped here, i.e. after the engine launch of this step and before the next.
-__global__ __launch_bounds__(kBlock) void finish_token_kernel(const FinishArgs a) { finish_token_body<0>(a); }
+__global__ __launch_bounds__(kBlock) void finish_token_kernel(const FinishArgs a) { finish_token_body(a); }
 hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks, SeqState* st_dev, int32_t* gen_log, int log_cap,
                                const int* advance_ptr, int32_t* id_out, int n_ctx, unsigned* epoch, hipStream_t st, unsigned long long* trace,
                                unsigned long long* clock_log) {
@@ -354,7 +351,6 @@ hipError_t launch_finish_token(const unsigned long long* block_best, int nblocks
     return launch_finish_token_args(a, st);
 }
 hipError_t launch_finish_token_args(const FinishArgs& a, hipStream_t st) {
-    if (OvlRecorder* r = ovl_recorder) { r->add("thk_ovl_finish_token", 1, kBlock, 0, &a, sizeof a); return hipSuccess; }
     hipLaunchKernelGGL(finish_token_kernel, dim3(1), dim3(kBlock), 0, st, a);
     return hipGetLastError();
 }

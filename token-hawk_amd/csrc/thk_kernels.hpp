@@ -16,21 +16,21 @@ struct SeqState {
     int32_t pos;     // n_past of the token being evaluated (T = pos + 1)
     int32_t token;   // current input token id / greedy result of the last step
     int32_t n_gen;   // tokens appended to the log so far
-    int32_t pad;
+    int32_t pad;     // error word: 1 = the folded greedy pick gave up waiting for an arg-max key (reported by thk_model_seq_get)
 };
 
 // prologue / epilogue selectors of the fused mat-vec
 enum { GEMV_PRO_COPY = 0, GEMV_PRO_RMS = 1, GEMV_PRO_ATTN = 2, GEMV_PRO_RMS_EMBED = 3 };
 enum { GEMV_EPI_STORE = 0, GEMV_EPI_RESID = 1, GEMV_EPI_ROPE_KV = 2, GEMV_EPI_SWIGLU = 3, GEMV_EPI_HEAD = 4 };
 
-// Overlapped dispatch (thk_ovl.cpp): how a launch finds its predecessor and announces itself (thk_device.hpp, ovl_wait / ovl_arrive).
-constexpr int kOvlShards = 16, kOvlShardWords = 32, kOvlLaunchWords = kOvlShards * kOvlShardWords;   // arrival counters of one launch
-struct OvlLink {
-    const unsigned* wait;   // the predecessor's arrival counters; NULL = nothing to wait for (the packet carries the barrier bit)
-    unsigned wait_n;        // what they add up to when it is done: its workgroups x waves per workgroup
-    unsigned* done;         // this launch's arrival counters (NULL: nobody waits for it)
-    int n_blocks;           // this launch's workgroup count (gridDim is a hidden argument the private queue does not fill)
-    unsigned* err;          // set to 1 by a wait that expired
+// the greedy pick + sequence bookkeeping that ends a decode step (finish_token_reduce, thk_decode_bodies.hpp): arguments of the
+// stand-alone launch, and - with `folded` set - of the lm-head launch whose highest-numbered workgroup does the same work itself
+struct FinishArgs {
+    const unsigned long long* block_best; int nblocks;     // stand-alone launch only (the lm-head launch reads its own GemvArgs::block_best)
+    SeqState* st; int32_t* gen_log; int log_cap;
+    const int* advance_ptr; int32_t* id_out; int n_ctx; unsigned* epoch;
+    unsigned long long* trace; unsigned long long* clock_log;
+    int folded;                // lm-head launch only: 1 = this launch finishes the token itself (its key slots must be zero when it starts)
 };
 
 struct GemvArgs {
@@ -51,8 +51,8 @@ struct GemvArgs {
     const float* part_o; const float* part_ml; int H; int nsplit;
     // EPI_HEAD
     int lm_faithful; int q1_split; int q1_cov; unsigned long long* block_best;
+    FinishArgs fin;              // EPI_HEAD: fin.folded folds the greedy pick into this launch
     unsigned long long* trace;   // development timeline, [blocks][8 waves][4] (only read by a THK_TRACE build; NULL otherwise)
-    OvlLink ovl;                 // overlapped dispatch only
 };
 
 struct AttnArgs {
@@ -60,7 +60,9 @@ struct AttnArgs {
     const float* kcache;       // [n_ctx, H, D] f32
     const float* vcache;
     const int32_t* pos_ptr; int pos_val;   // T = pos + 1
-    int H, D, nsplit, tc;      // tc = positions per split
+    int H, D, nsplit, tc;      // tc = positions per split ...
+    int tc_dyn;                // ... or 1: tc = ceil(T / nsplit) rounded up to the wave batch, computed on the device from the live position
+    int vsplit;                // 1 | 2: workgroups per (head, split), each taking 1/vsplit of the V columns (attn_body)
     int waves;                 // waves per block of the stand-alone kernel (4 or 8)
     int nq;                    // causal queries in this launch (prefill); 0/1 = single decode query
     int kv_f16;                // the caches hold binary16 (kcache / vcache then point to _Float16 data)
@@ -69,27 +71,7 @@ struct AttnArgs {
     float* part_o;             // [H, nsplit, D]
     float* part_ml;            // [H, nsplit, 2]
     unsigned long long* trace; // development timeline, [blocks][8 waves][4] (only read by a THK_TRACE build; NULL otherwise)
-    OvlLink ovl;               // overlapped dispatch only
 };
-
-// the step's last launch (greedy pick + sequence bookkeeping), as one argument block
-struct FinishArgs {
-    const unsigned long long* block_best; int nblocks;
-    SeqState* st; int32_t* gen_log; int log_cap;
-    const int* advance_ptr; int32_t* id_out; int n_ctx; unsigned* epoch;
-    unsigned long long* trace; unsigned long long* clock_log;
-    OvlLink ovl;               // overlapped dispatch only ...
-    unsigned* ovl_counters; int ovl_n_launches;   // ... where this launch also zeroes every arrival counter of the step
-};
-
-// Recording instead of launching: while ovl_recorder is set (thk_ovl.cpp builds a sequence's step program), launch_gemv,
-// launch_attn_decode and launch_finish_token_args append {kernel name in libthk_ovl.hsaco, geometry, argument block} to it.
-struct OvlRecorder {
-    struct Launch { char name[64]; int grid, block, lds_dynamic; unsigned char args[384]; int arg_bytes; };
-    Launch* v; int n, cap; bool overflow;
-    void add(const char* name, int grid, int block, int lds_dynamic, const void* args, int arg_bytes);
-};
-extern thread_local OvlRecorder* ovl_recorder;
 
 // nru (0..7) selects the (rows per wave iteration, slots per load batch) variant for the column class of C;
 // see gemv_variant() in thk_kernels.hip.  Row groups = ceil(rows / gemv_rows_per_group).

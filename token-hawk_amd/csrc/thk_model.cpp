@@ -78,8 +78,8 @@ static void free_seq(SeqBuf& s) {
     if (s.exec) hipGraphExecDestroy(s.exec);
     if (s.graph) hipGraphDestroy(s.graph);
     for (auto& g : s.multi) { if (g.second.second) hipGraphExecDestroy(g.second.second); if (g.second.first) hipGraphDestroy(g.second.first); }
+    s.multi.clear(); s.multi_used.clear();
     hipFree(s.eng_ops);
-    ovl_free_seq(s);
     hipFree(s.kv);            // st, gen_log, hidden_in/out, logits, advance live in the model's arena
     s = SeqBuf();
 }
@@ -90,9 +90,8 @@ static void free_working(thk_model* m) {
     m->arena_chunks.clear(); m->arena_off = m->arena_cap = 0;
     hipFree(m->prefill_ws); hipFree(m->prefill_pk); m->prefill_pk = nullptr; m->prefill_pk_bytes = 0; m->pk_w.clear(); m->pk_tiles[0] = 0; m->pk_failed = false;
     m->eng_trace = nullptr;
-    hipFree(m->ovl_counters); m->ovl_counters = nullptr;
     m->eng_gran = nullptr; m->eng_words = nullptr; m->engine = 0;
-    m->x = m->q = m->u = m->attn_out = m->part_o = m->part_ml = nullptr; m->block_best = nullptr; m->rope_tab = nullptr;
+    m->x = m->q = m->u = m->attn_out = m->part_o = m->part_ml = nullptr; m->block_best = m->block_best_aux = nullptr; m->rope_tab = nullptr;
     m->prefill_ws = nullptr; m->prefill_ws_bytes = 0;
     m->finalized = false;
 }
@@ -227,13 +226,6 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
     const bool nt = m->nt != 0;
     const int nl = m->l1 - m->l0;
     const float* xin = sb.hidden_in;
-    // overlapped dispatch: while a step program is recorded every launch is linked to its predecessor's arrival counters
-    int ovl_k = 0; const unsigned* ovl_prev = nullptr; unsigned ovl_prev_n = 0;
-    auto ovl_link = [&](OvlLink& L, int grid, int waves_per_block = kWaves) {       // arrival counters count waves
-        if (!m->ovl_rec) return;
-        L.wait = ovl_prev; L.wait_n = ovl_prev_n; L.done = m->ovl_counters + (size_t)ovl_k * kOvlLaunchWords; L.n_blocks = grid; L.err = m->ovl_err;
-        ovl_prev = L.done; ovl_prev_n = (unsigned)(grid * waves_per_block); ++ovl_k;
-    };
     int trace_k = 0;                                     // development timeline (thk_model_step_trace): one [kTraceBlocks][8][4] slab per launch
     auto trace_slab = [&]() -> unsigned long long* { return m->trace_on ? m->trace_buf + (size_t)(trace_k++) * kTraceBlocks * kTraceWords : nullptr; };
     const bool fold_embed = (m->flags & THK_STAGE_EMBED) && m->fold_embed && !m->engine && nl > 0 && m->skip_kernel != 1;
@@ -276,7 +268,6 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             if (emb) { a.embed = m->tok_embeddings; a.tok_ptr = &sb.st->token; a.x_out = m->x; }
             if (m->gain_alias && !emb) a.gain = a.x;
             a.trace = trace_slab();
-            if (m->skip_kernel != 1) ovl_link(a.ovl, m->grid_qkv);
             MARK("norm_qkv_rope_kv");
             if (m->skip_kernel != 1) HIPCHK(ctx, launch_gemv(emb ? GEMV_PRO_RMS_EMBED : GEMV_PRO_RMS, GEMV_EPI_ROPE_KV, m->var_qkv, a, m->grid_qkv, nt, st));
         }
@@ -284,6 +275,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             // split combine -> wo -> + residual (steps 10-11, th-llama.cpp:401-413)
             AttnArgs t{};
             t.q = m->q; t.kcache = kc; t.vcache = vc; t.pos_ptr = &sb.st->pos; t.H = H; t.D = D; t.nsplit = m->nsplit; t.tc = m->tc;
+            t.tc_dyn = m->attn_tc_dyn; t.vsplit = m->attn_vsplit;
             t.scale = 1.0f / sqrtf((float)D); t.waves = m->attn_waves; t.kv_f16 = m->kv_f16;
             t.out = m->nsplit == 1 ? m->attn_out : nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml;
             GemvArgs a{};
@@ -293,11 +285,9 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.x = m->attn_out; a.part_o = m->part_o; a.part_ml = m->part_ml; a.H = H; a.D = D; a.nsplit = m->nsplit;
             a.resid = xr_in; a.y = m->x;
             t.trace = trace_slab();
-            if (m->skip_kernel != 2) ovl_link(t.ovl, H * m->nsplit, m->attn_waves);
             MARK("attn_decode");
             if (m->skip_kernel != 2) HIPCHK(ctx, launch_attn_decode(t, st));
             a.trace = trace_slab();
-            if (m->skip_kernel != 3) ovl_link(a.ovl, m->grid_wo);
             MARK("attn_wo_resid");
             if (m->skip_kernel != 3) HIPCHK(ctx, launch_gemv(m->nsplit == 1 ? GEMV_PRO_COPY : GEMV_PRO_ATTN, GEMV_EPI_RESID, m->var_wo, a, m->grid_wo, nt, st));
         }
@@ -307,7 +297,6 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.x = m->x; a.gain = L.ffn_norm; a.y = m->u;
             if (m->gain_alias) a.gain = a.x;
             a.trace = trace_slab();
-            if (m->skip_kernel != 4) ovl_link(a.ovl, m->grid_w13);
             MARK("norm_w13_swiglu");
             if (m->skip_kernel != 4) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_SWIGLU, m->var_w13, a, m->grid_w13, nt, st));
         }
@@ -319,7 +308,6 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.x = m->u; a.resid = m->x;
             a.y = (i == nl - 1 && !(m->flags & THK_STAGE_HEAD)) ? sb.hidden_out : m->x;
             a.trace = trace_slab();
-            if (m->skip_kernel != 5) ovl_link(a.ovl, m->grid_w2);
             MARK("w2_resid");
             if (m->skip_kernel != 5) HIPCHK(ctx, launch_gemv(GEMV_PRO_COPY, GEMV_EPI_RESID, m->var_w2, a, m->grid_w2, nt, st));
         }
@@ -333,20 +321,18 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         a.lm_faithful = m->lm_mode == THK_LMHEAD_FAITHFUL; q1_constants(V, &a.q1_split, &a.q1_cov);
         a.block_best = m->block_best;
         a.trace = trace_slab();
-        if (m->skip_kernel != 6) ovl_link(a.ovl, m->grid_head);
+        FinishArgs f{};
+        f.block_best = m->block_best; f.nblocks = m->grid_head; f.st = sb.st; f.gen_log = sb.gen_log; f.log_cap = kGenLogCap; f.advance_ptr = sb.advance;
+        f.n_ctx = T; f.clock_log = sb.clock_log;
+        const bool fold = m->fold_finish && m->skip_kernel != 6;
+        if (fold) { a.fin = f; a.fin.folded = 1; }      // the launch's highest-numbered workgroup picks the token itself (key slots are zero between launches)
         MARK("norm_lmhead");
         if (m->skip_kernel != 6) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, nt, st));
-        MARK("finish_token");
-        if (m->skip_kernel != 6) {
-            FinishArgs f{};
-            f.block_best = m->block_best; f.nblocks = m->grid_head; f.st = sb.st; f.gen_log = sb.gen_log; f.log_cap = kGenLogCap; f.advance_ptr = sb.advance;
-            f.n_ctx = T; f.trace = trace_slab(); f.clock_log = sb.clock_log;
-            ovl_link(f.ovl, 1);
-            f.ovl.done = nullptr;                       // nobody waits for the step's last launch: the next step's first packet carries the barrier bit
-            f.ovl_counters = m->ovl_counters; f.ovl_n_launches = ovl_k;
-            HIPCHK(ctx, launch_finish_token_args(f, st));
+        if (!fold) {
+            MARK("finish_token");
+            if (m->skip_kernel != 6) { f.trace = trace_slab(); HIPCHK(ctx, launch_finish_token_args(f, st)); }
+            else HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, T, nullptr, st));       // no arg-max keys were written: keep the token
         }
-        else HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, T, nullptr, st));       // no arg-max keys were written: keep the token
     } else {
         MARK("advance_pos");
         HIPCHK(ctx, launch_advance_pos(sb.st, sb.advance, T, nullptr, st));
@@ -355,22 +341,8 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
     return THK_OK;
 }
 
-int enqueue_step_recorded(thk_model* m, int seq) { return enqueue_step(m, seq, nullptr); }
-// launch names of a step in order, nothing launched (the recorder swallows the launches)
-static int enqueue_step_names(thk_model* m, int seq, StepProf* p) {
-    std::vector<OvlRecorder::Launch> store(5 * (m->l1 - m->l0) + 8);
-    OvlRecorder rec{store.data(), 0, (int)store.size(), false};
-    const bool on = m->trace_on;
-    m->trace_on = false;
-    ovl_recorder = &rec;
-    const int rc = enqueue_step(m, seq, p);
-    ovl_recorder = nullptr;
-    m->trace_on = on;
-    return rc;
-}
-
 __global__ void set_seq_state_kernel(SeqState* st, int token, int pos, int reset_gen) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { st->token = token; st->pos = pos; if (reset_gen) st->n_gen = 0; }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { st->token = token; st->pos = pos; if (reset_gen) { st->n_gen = 0; st->pad = 0; } }
 }
 __global__ void set_seq_token_kernel(SeqState* st, int token) {
     if (threadIdx.x == 0 && blockIdx.x == 0) st->token = token;
@@ -405,7 +377,8 @@ extern "C" int thk_model_finalize(thk_model* m) {
     const int nl = m->l1 - m->l0;
     // launch geometry
     m->nsplit = (int)tun(ctx, "attn_splits");
-    REQUIRE(ctx, valid_splits(m->nsplit), "attn_splits must be 1, 2, 4 or 8");
+    if (m->nsplit == 0) m->nsplit = T > 1024 ? 8 : 4;       // auto: 4 context splits per head (x 2 workgroups per split), 8 for long caches
+    REQUIRE(ctx, valid_splits(m->nsplit), "attn_splits must be 0 (auto), 1, 2, 4 or 8");
     m->tc = (int)((T + m->nsplit - 1) / m->nsplit);
     m->nt = true;
     m->use_graph = tun(ctx, "use_graph") != 0;
@@ -413,6 +386,9 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->attn_waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
     m->kv_f16 = tun(ctx, "kv_f16") != 0;
     m->fold_embed = tun(ctx, "fold_embed") != 0;
+    m->fold_finish = tun(ctx, "fold_finish") != 0;
+    m->attn_vsplit = tun(ctx, "attn_vsplit") == 1 ? 1 : 2;
+    m->attn_tc_dyn = tun(ctx, "attn_tc_dyn") != 0;
     m->gain_alias = tun(ctx, "measure_gain_alias") != 0;
     m->var_qkv = resolve_variant(ctx, "qkv", (int)E); m->var_wo = resolve_variant(ctx, "wo", (int)E);
     m->var_w13 = resolve_variant(ctx, "w13", (int)E); m->var_w2 = resolve_variant(ctx, "w2", (int)E); m->var_head = resolve_variant(ctx, "head", (int)E);
@@ -432,7 +408,12 @@ extern "C" int thk_model_finalize(thk_model* m) {
     } while (0)
     ALLOCZ(m->x, E * 4); ALLOCZ(m->q, E * 4); ALLOCZ(m->u, F * 4); ALLOCZ(m->attn_out, E * 4);
     ALLOCZ(m->part_o, H * kMaxSplit * D * 4); ALLOCZ(m->part_ml, H * kMaxSplit * 2 * 4);
-    ALLOCZ(m->block_best, (size_t)std::max(m->grid_head > 0 ? m->grid_head : 1, ctx->n_cu) * 8 + 4096);
+    {   // arg-max key slots, twice: [0] the decode step's (all zero between launches when the pick is folded into the lm-head launch),
+        // [1] for head launches outside the step (prefill), whose keys nobody consumes
+        const size_t slots = (size_t)std::max(m->grid_head > 0 ? m->grid_head : 1, ctx->n_cu) + 512;
+        ALLOCZ(m->block_best, slots * 8 * 2);
+        m->block_best_aux = m->block_best + slots;
+    }
     ALLOCZ(m->rope_tab, T * (D / 2) * 2 * 4);
     {
         std::vector<float> tab;
@@ -557,7 +538,7 @@ static int check_room(thk_model* m, int seq, int n_steps, int advance) {
 static int ensure_multi_graph(thk_model* m, int seq, int n) {
     thk_ctx* ctx = m->ctx;
     SeqBuf& sb = m->seqs[seq];
-    if (sb.multi.count(n)) return THK_OK;
+    if (sb.multi.count(n)) { sb.multi_used[n] = ++sb.multi_clock; return THK_OK; }
     int rc = THK_OK;
     hipGraph_t g = nullptr; hipGraphExec_t x = nullptr;
     HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
@@ -567,7 +548,15 @@ static int ensure_multi_graph(thk_model* m, int seq, int n) {
     if (e != hipSuccess) return fail(ctx, THK_ERR_HIP, "hipStreamEndCapture (%d-step graph): %s", n, hipGetErrorString(e));
     e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
     if (e != hipSuccess) { hipGraphDestroy(g); return fail(ctx, THK_ERR_HIP, "hipGraphInstantiate (%d-step graph): %s", n, hipGetErrorString(e)); }
+    // a sequence keeps at most kMaxMultiGraphs step counts (n * ~161 nodes each): the least recently replayed one makes room
+    if ((int)sb.multi.size() >= kMaxMultiGraphs) {
+        auto victim = sb.multi.begin();
+        for (auto it = sb.multi.begin(); it != sb.multi.end(); ++it) if (sb.multi_used[it->first] < sb.multi_used[victim->first]) victim = it;
+        hipGraphExecDestroy(victim->second.second); hipGraphDestroy(victim->second.first);
+        sb.multi_used.erase(victim->first); sb.multi.erase(victim);
+    }
     sb.multi[n] = {g, x};
+    sb.multi_used[n] = ++sb.multi_clock;
     return THK_OK;
 }
 extern "C" int thk_model_decode_step(thk_model* m, int32_t seq, int advance) {
@@ -578,7 +567,7 @@ extern "C" int thk_model_decode_step(thk_model* m, int32_t seq, int advance) {
     if (rc != THK_OK) return rc;
     rc = set_advance(m, seq, advance);
     if (rc != THK_OK) return rc;
-    rc = tun(m->ctx, "overlap_dispatch") != 0 ? ovl_decode_steps(m, seq, 1) : run_step(m, seq);
+    rc = run_step(m, seq);
     if (rc == THK_OK && advance) m->seqs[seq].pos_host += 1;
     return rc;
 }
@@ -604,11 +593,6 @@ extern "C" int thk_model_decode_steps(thk_model* m, int32_t seq, int32_t n_steps
     rc = set_advance(m, seq, advance);
     if (rc != THK_OK) return rc;
     SeqBuf& sb = m->seqs[seq];
-    if (tun(ctx, "overlap_dispatch") != 0) {           // the same launches as AQL packets without the barrier bit (thk_ovl.cpp)
-        rc = ovl_decode_steps(m, seq, n_steps);
-        if (rc == THK_OK && advance) sb.pos_host += n_steps;
-        return rc;
-    }
     int left = n_steps;
     if (m->use_graph) {
         while (left >= 2) {                          // 20 = one 20-step graph; 200 = 6 x 32 + 8
@@ -643,6 +627,7 @@ extern "C" int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out,
     }
     if (n_out) *n_out = h.n_gen;
     if (pos_out) *pos_out = h.pos;
+    if (h.pad != 0) return fail(ctx, THK_ERR_STATE, "sequence %d: the lm-head launch's folded greedy pick gave up waiting for an arg-max key (a workgroup of the launch never delivered); tokens from that step on are not trustworthy", seq);
     return check_engine_error(m);
 }
 
@@ -689,13 +674,16 @@ extern "C" int thk_model_seq_last_token(thk_model* m, int32_t seq, int32_t* toke
     thk_ctx* ctx = m->ctx;
     REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemcpyAsync(token_out, &m->seqs[seq].st->token, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SeqState h{};
+    HIPCHK(ctx, hipMemcpyAsync(&h, m->seqs[seq].st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *token_out = h.token;
+    if (h.pad != 0) return fail(ctx, THK_ERR_STATE, "sequence %d: the folded greedy pick gave up waiting for an arg-max key", seq);
     return check_engine_error(m);
 }
 
 // Development aid: the working buffers a decode step leaves behind (the LAST layer's q, split partials and u, the final hidden
-// state), so that two launch paths can be compared stage by stage on a one-layer model (tools/dev/ovl_debug.py).
+// state), so that two launch configurations can be compared stage by stage on a one-layer model.
 extern "C" int thk_model_debug_buffer(thk_model* m, const char* name, float* out, int64_t cap, int64_t* n_out) {
     if (!m || !name || !out || !n_out) return THK_ERR_INVALID;
     thk_ctx* ctx = m->ctx;
@@ -749,9 +737,12 @@ extern "C" int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_ent
     return rc;
 }
 
-// Development aid (libthk_trace.so, tools/step_trace.py): one eager decode step with every wave of every launch stamping
-// the 100 MHz s_memrealtime counter at four points (kernel entry | activation vector staged | first weight batch consumed |
-// done); returns [n_kernels][kTraceBlocks][8 waves][4] u64 (0 = not stamped) and the launch names in thk_model_profile_step order.
+// Development aid (libthk_trace.so, tools/step_trace.py): decode steps with every wave of every launch stamping the 100 MHz
+// s_memrealtime counter at four points (kernel entry | activation vector staged | first weight batch consumed | done).  With
+// graphs on (the default) TWO hold-position steps are captured into one graph and replayed, and the SECOND one's stamps are
+// returned (the first absorbs the replay's start-up); with use_graph = 0 it is one eager step.  The traced steps never advance the
+// sequence (the advance flag is forced to 0 and restored), so the host's position mirror stays exact.  Returns
+// [n_kernels][kTraceBlocks][8 waves][4] u64 (0 = not stamped) and the launch names in thk_model_profile_step order.
 extern "C" int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long long* out, int64_t cap_words, int32_t max_names, char (*names)[48],
                                     int32_t* n_kernels, int32_t* blocks_per_kernel) {
     if (!m || !out || !n_kernels || !blocks_per_kernel) return THK_ERR_INVALID;
@@ -759,23 +750,18 @@ extern "C" int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long lon
     REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
     if (!trace_compiled()) return fail(ctx, THK_ERR_STATE, "this libthk was built without -DTHK_TRACE (build libthk_trace.so: __graft_entry__.build_libthk(trace=True))");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = check_room(m, seq, 1, 0);
+    if (rc != THK_OK) return rc;
     const size_t max_k = 6 * (size_t)(m->l1 - m->l0) + 8;
     const size_t words = max_k * kTraceBlocks * kTraceWords;
     if (!m->trace_buf) HIPCHK(ctx, hipMalloc((void**)&m->trace_buf, words * 8));
     HIPCHK(ctx, hipMemsetAsync(m->trace_buf, 0, words * 8, ctx->stream));
+    const int advance_before = m->seqs[seq].advance_host;
+    if ((rc = set_advance(m, seq, 0)) != THK_OK) return rc;
     StepProf p;
     p.names_only = true;
     m->trace_on = true;
-    int rc = THK_OK;
-    if (tun(ctx, "overlap_dispatch") != 0) {   // the overlapped dispatch: a step program recorded with the trace slabs, two steps (the second one's stamps remain)
-        SeqBuf& sb = m->seqs[seq];
-        ovl_free_seq(sb);
-        rc = enqueue_step_names(m, seq, &p);
-        if (rc == THK_OK) rc = ovl_decode_steps(m, seq, 2);
-        m->trace_on = false;
-        if (rc == THK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "sync failed while tracing");
-        ovl_free_seq(sb);                       // the next ordinary call records a program without stamps
-    } else if (m->use_graph) {      // the timeline of a step as it is normally run: a replayed graph (two steps, the SECOND one is recorded)
+    if (m->use_graph) {      // the timeline of a step as it is normally run: a replayed graph (two steps, the SECOND one is recorded)
         hipGraph_t g = nullptr; hipGraphExec_t x = nullptr;
         HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
         m->trace_on = false;
@@ -796,6 +782,7 @@ extern "C" int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long lon
         if (rc == THK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "sync failed while tracing");
     }
     for (auto ev : p.events) hipEventDestroy(ev);
+    if (advance_before >= 0) { const int rc2 = set_advance(m, seq, advance_before); if (rc == THK_OK) rc = rc2; }
     if (rc != THK_OK) return rc;
     const size_t nk = p.names.size();
     REQUIRE(ctx, nk <= max_k && (int64_t)(nk * kTraceBlocks * kTraceWords) <= cap_words, "step trace needs %zu words", nk * kTraceBlocks * kTraceWords);
@@ -804,4 +791,3 @@ extern "C" int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long lon
     *n_kernels = (int)nk; *blocks_per_kernel = kTraceBlocks;
     return THK_OK;
 }
-

@@ -96,7 +96,6 @@ extern "C" int thk_model_engine_trace(thk_model* m, unsigned long long* out, int
 }
 // Bounded in-launch waits raise a device-side error word instead of hanging; surface it.
 int check_engine_error(thk_model* m) {
-    { const int rc = ovl_check_error(m); if (rc != THK_OK) return rc; }
     if (m->engine && m->eng_words) {
         unsigned e = 0;
         HIPCHK(m->ctx, hipMemcpyAsync(&e, m->eng_words + 32, 4, hipMemcpyDeviceToHost, m->ctx->stream));

@@ -193,7 +193,7 @@ extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* token
         a.n_groups = (V + NR - 1) / NR;
         a.x = b.X + (size_t)(last - 1) * E; a.gain = m->norm; a.y = sb.logits;
         a.lm_faithful = m->lm_mode == THK_LMHEAD_FAITHFUL; q1_constants(V, &a.q1_split, &a.q1_cov);
-        a.block_best = m->block_best;
+        a.block_best = m->block_best_aux;      // not the decode step's slots: those stay zero between launches (folded greedy pick)
         HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, m->nt != 0, st));
         HIPCHK(ctx, hipMemcpyAsync(m->x, b.X + (size_t)(last - 1) * E, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
     }

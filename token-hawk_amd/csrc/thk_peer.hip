@@ -17,7 +17,14 @@
 //   * Flow control is the ring itself: a stage produces item i + S for a sequence only after the token/hidden of item i has
 //     travelled through every other stage, so a mailbox slot is never overwritten before it was read (S = N sequences in flight).
 //   * Every wait is bounded (~2 s on the 100 MHz counter): a missing peer raises an error word (thk_peer_check) instead of
-//     hanging the GPU.
+//     hanging the GPU.  A time-out is STICKY: the flag sequence of that (sequence, kind) is out of step from then on, so every
+//     later wait returns at once without touching its destination, thk_peer_check keeps reporting the failure and
+//     thk_peer_send / thk_peer_recv refuse - the peer has to be destroyed and recreated (round 4; round 3 cleared the word and let
+//     later hand-offs pair with stale flags).
+//   * The mailbox is FINE-GRAINED device memory (hipExtMallocWithFlags: uncached, else fine-grained): another GPU writes it while
+//     this GPU's kernel polls it, and HIP only guarantees cross-agent visibility of ordinary (coarse-grained) allocations at
+//     dispatch boundaries.  If neither flavour can be allocated AND exported over IPC the mailbox falls back to hipMalloc and
+//     thk_peer_memory_kind says so (then only same-GPU rings are safe - what tests/test_gpu_pipeline.py runs).
 // Reference: none - the reference is single-device.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -55,8 +62,8 @@ __global__ __launch_bounds__(256) void peer_wait_kernel(const u64* slot, int n_w
     if (threadIdx.x == 0) {
         const u64 want = *received + 1;
         const u64 t0 = __builtin_amdgcn_s_memrealtime();
-        int good = 1;
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+        int good = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;     // an earlier time-out: the chain is broken, do not wait again
+        while (good && __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
             __builtin_amdgcn_s_sleep(16);
             if (__builtin_amdgcn_s_memrealtime() - t0 > kTimeoutTicks) { good = 0; break; }
         }
@@ -79,6 +86,8 @@ struct thk_peer {
     thk_model* model = nullptr;
     int n_seq = 1, hidden_words = 0;
     u64* box = nullptr;          // own mailbox (device)
+    int box_kind = 0;            // THK_PEER_MEM_*: how it was allocated
+    bool failed = false;         // a hand-off wait timed out (sticky)
     size_t box_words = 0;
     u64* next_box = nullptr;     // the next stage's mailbox as mapped into this process
     bool next_is_ipc = false;
@@ -104,7 +113,18 @@ extern "C" int thk_peer_create(thk_ctx* ctx, thk_model* stage, int32_t n_seq, th
     p->ctx = ctx; p->model = stage; p->n_seq = n_seq; p->hidden_words = (E / 2 + kLine - 1) / kLine * kLine;
     p->box_words = p->flag_off(n_seq, 0);
     hipStream_t st = (hipStream_t)thk_ctx_stream(ctx);
-    hipError_t e = hipMalloc((void**)&p->box, p->box_words * 8);          // its own allocation: the IPC handle covers exactly the mailbox
+    // its own allocation (the IPC handle covers exactly the mailbox), fine-grained if the runtime can allocate AND export that
+    hipError_t e = hipErrorUnknown;
+    const struct { unsigned flag; int kind; } tries[] = {{hipDeviceMallocUncached, THK_PEER_MEM_UNCACHED}, {hipDeviceMallocFinegrained, THK_PEER_MEM_FINEGRAINED}};
+    for (const auto& t : tries) {
+        void* q = nullptr;
+        if (hipExtMallocWithFlags(&q, p->box_words * 8, t.flag) != hipSuccess) { (void)hipGetLastError(); continue; }
+        hipIpcMemHandle_t h;
+        if (hipIpcGetMemHandle(&h, q) != hipSuccess) { (void)hipGetLastError(); hipFree(q); continue; }
+        p->box = (u64*)q; p->box_kind = t.kind; e = hipSuccess;
+        break;
+    }
+    if (!p->box) { e = hipMalloc((void**)&p->box, p->box_words * 8); p->box_kind = THK_PEER_MEM_COARSE; }
     if (e == hipSuccess) e = hipMalloc((void**)&p->counters, ((size_t)n_seq * 4 + 2) * 8);
     if (e == hipSuccess) e = hipMemsetAsync(p->box, 0, p->box_words * 8, st);
     if (e == hipSuccess) e = hipMemsetAsync(p->counters, 0, ((size_t)n_seq * 4 + 2) * 8, st);
@@ -114,6 +134,7 @@ extern "C" int thk_peer_create(thk_ctx* ctx, thk_model* stage, int32_t n_seq, th
     *out = p;
     return THK_OK;
 }
+extern "C" int thk_peer_memory_kind(const thk_peer* p) { return p ? p->box_kind : THK_ERR_INVALID; }
 extern "C" int thk_peer_export(thk_peer* p, void* handle_out64) {
     if (!p || !handle_out64) return THK_ERR_INVALID;
     static_assert(sizeof(hipIpcMemHandle_t) == THK_PEER_HANDLE_BYTES, "hipIpcMemHandle_t size");
@@ -138,6 +159,7 @@ extern "C" int thk_peer_connect(thk_peer* p, const void* next_handle64) {
 static int peer_io(thk_peer* p, int32_t seq, int kind, bool send) {
     if (!p || seq < 0 || seq >= p->n_seq || (kind != THK_PEER_HIDDEN && kind != THK_PEER_TOKEN)) return THK_ERR_INVALID;
     if (!p->next_box) return thk::ctx_fail(p->ctx, THK_ERR_STATE, "thk_peer: thk_peer_connect first");
+    if (p->failed) return thk::ctx_fail(p->ctx, THK_ERR_STATE, "thk_peer: a hand-off timed out earlier; the flag sequence is out of step - destroy this peer and create a new one");
     hipStream_t st = (hipStream_t)thk_ctx_stream(p->ctx);
     const int words = kind == THK_PEER_HIDDEN ? thk_model_n_embd(p->model) / 2 : 0;
     const size_t off = kind == THK_PEER_HIDDEN ? p->hidden_off(seq) : p->token_off(seq);
@@ -161,9 +183,9 @@ extern "C" int thk_peer_check(thk_peer* p) {
     unsigned e = 0;
     PEERCHK(p->ctx, hipMemcpyAsync(&e, p->err, 4, hipMemcpyDeviceToHost, st));
     PEERCHK(p->ctx, hipStreamSynchronize(st));
-    if (e) {
-        PEERCHK(p->ctx, hipMemsetAsync(p->err, 0, 4, st));
-        return thk::ctx_fail(p->ctx, THK_ERR_STATE, "thk_peer: a hand-off wait timed out (the previous stage never delivered)");
+    if (e || p->failed) {
+        p->failed = true;          // sticky: the device word stays set, so waits already enqueued return at once
+        return thk::ctx_fail(p->ctx, THK_ERR_STATE, "thk_peer: a hand-off wait timed out (the previous stage never delivered); the peer is unusable from here on");
     }
     return THK_OK;
 }

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
             }                                                                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
             if (i < SYNC_AT) {                                                                                         \
-                _Pragma("unroll") for (int k = LT + i * LH / SYNC_AT; k < LT + (i + 1) * LH / SYNC_AT; ++k)            \
+                _Pragma("unroll") for (int k = LT + i * LH / (SYNC_AT > 0 ? SYNC_AT : 1); k < LT + (i + 1) * LH / (SYNC_AT > 0 ? SYNC_AT : 1); ++k)            \
                     v3_issue_one<MT, NF, PK>(k, pend_more, ximg, scratch, pend_sb, pend_xs, pend_w, pend_row0, R, C, wave);     \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
             }                                                                                                          \

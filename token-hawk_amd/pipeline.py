@@ -17,17 +17,95 @@ test_pipeline_gloo.py supplies an oracle-backed stage); the product stage is Hip
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
+import os
+import sys
+import threading
+import time
+from dataclasses import dataclass, field
 
 import torch
 import torch.distributed as dist
 
 
 def layer_range(n_layer: int, rank: int, world: int):
-    """Contiguous split of the layers; the first n_layer % world ranks take one extra."""
+    """Contiguous split of the layers; the first n_layer % world ranks take one extra (32/16/8/4 per GPU)."""
     base, extra = divmod(n_layer, world)
     l0 = rank * base + min(rank, extra)
     return l0, l0 + base + (1 if rank < extra else 0)
+
+
+def stage_cost(n_layers: int, first: bool, last: bool, t_layer: float, t_head: float, t_embed: float = 0.0) -> float:
+    """Cost model of one stage: its layers, plus the embedding fetch on the first and final norm + lm-head + pick on the last."""
+    return n_layers * t_layer + (t_embed if first else 0.0) + (t_head if last else 0.0)
+
+
+def balanced_layer_split(n_layer: int, world: int, t_layer: float, t_head: float, t_embed: float = 0.0):
+    """Contiguous layer counts per rank that minimise the slowest stage under stage_cost() - the ring runs at the pace of its
+    slowest stage, and the last rank also carries the lm-head.  Exact (dynamic programme over (rank, layers used)); every rank
+    keeps at least one layer; among the optimal splits the one closest to uniform wins, so the BASELINE split is returned
+    whenever it is already optimal (LLaMA-7B: the lm-head costs 0.6 of a layer, so 4/4/.../4 is optimal at N = 8 - moving a
+    layer off the last rank makes another rank slower than the head ever was).  Returns [(l0, l1)] * world."""
+    assert 1 <= world <= n_layer
+    INF = float("inf")
+    uni = [b - a for a, b in (layer_range(n_layer, r, world) for r in range(world))]
+    # best[r][k] = (max cost, distance from uniform) of ranks r.. when k layers remain for them
+    best = [[(INF, INF)] * (n_layer + 1) for _ in range(world + 1)]
+    pick = [[0] * (n_layer + 1) for _ in range(world + 1)]
+    best[world][0] = (0.0, 0)
+    for r in range(world - 1, -1, -1):
+        for k in range(world - r, n_layer + 1):
+            for n in range(1, k - (world - r - 1) + 1):
+                rest = best[r + 1][k - n]
+                if rest[0] == INF:
+                    continue
+                c = (max(stage_cost(n, r == 0, r == world - 1, t_layer, t_head, t_embed), rest[0]), abs(n - uni[r]) + rest[1])
+                if c[0] < best[r][k][0] - 1e-12 or (abs(c[0] - best[r][k][0]) <= 1e-12 and c[1] < best[r][k][1]):
+                    best[r][k] = c; pick[r][k] = n
+    out, k, l0 = [], n_layer, 0
+    for r in range(world):
+        n = pick[r][k]
+        out.append((l0, l0 + n)); l0 += n; k -= n
+    return out
+
+
+def split_efficiency_bound(split, t_layer: float, t_head: float, t_embed: float = 0.0) -> float:
+    """Sum of the stage costs / (N x the slowest): what a zero-cost hand-off could reach relative to N perfectly balanced stages."""
+    N = len(split)
+    c = [stage_cost(b - a, r == 0, r == N - 1, t_layer, t_head, t_embed) for r, (a, b) in enumerate(split)]
+    return sum(c) / (N * max(c))
+
+
+class Watchdog:
+    """`with Watchdog(seconds, what):` - if the body has not finished in time the process reports and exits with code 3.  The
+    ring's device-side waits are stream-ordered (RCCL) or bounded on the device (thk_peer); what can still block for ever is the
+    HOST waiting on a stream behind a hand-off whose peer died.  A hung rank would hang the node's other ranks and the driver with
+    it; a dead one is an error the launcher reports."""
+
+    def __init__(self, seconds: float, what: str, on_expire=None):
+        self.seconds, self.what, self.on_expire = seconds, what, on_expire
+        self._t = None
+
+    def _fire(self):
+        print(f"[pipeline watchdog] '{self.what}' did not finish within {self.seconds:.0f} s: a peer is gone or a hand-off is stuck; exiting (3)",
+              file=sys.stderr, flush=True)
+        if self.on_expire is not None:
+            try:
+                self.on_expire()
+            except Exception:
+                pass
+        os._exit(3)
+
+    def __enter__(self):
+        if self.seconds and self.seconds > 0:
+            self._t = threading.Timer(self.seconds, self._fire)
+            self._t.daemon = True
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        if self._t is not None:
+            self._t.cancel()
+        return False
 
 
 class _CudaView:
@@ -40,8 +118,9 @@ class _CudaView:
 class HipStage:
     """One pipeline stage on one MI355X, backed by thk_model_* (libthk.so)."""
 
-    def __init__(self, thk, ctx, shape, rank: int, world: int, n_seq: int, device: torch.device):
-        l0, l1 = layer_range(shape.n_layer, rank, world)
+    def __init__(self, thk, ctx, shape, rank: int, world: int, n_seq: int, device: torch.device, layers=None):
+        l0, l1 = layers if layers is not None else layer_range(shape.n_layer, rank, world)      # layers: an uneven split (balanced_layer_split)
+        self.l0, self.l1 = l0, l1
         flags = (thk.THK_STAGE_EMBED if rank == 0 else 0) | (thk.THK_STAGE_HEAD if rank == world - 1 else 0)
         self.model = thk.Model(ctx, shape, l0, l1, flags=flags, n_seq=n_seq)
         self.model.fill_synthetic()
@@ -115,6 +194,15 @@ class HipStage:
 class PipelineResult:
     items: int          # work items this rank processed
     micro_steps: int
+    topped_up: int = 0  # drain(): extra items issued so that every sequence ends on the same step
+
+
+@dataclass
+class HandoffReport:
+    ok: bool
+    checked: int                      # payloads this rank verified
+    handoff_us: float                 # average time of one ring hand-off (all ranks sending and receiving at once), no compute
+    errors: list = field(default_factory=list)
 
 
 class PipelineDriver:
@@ -141,43 +229,86 @@ class PipelineDriver:
     def ring(self) -> bool:
         return self.world > 1 or self.force_ring
 
+    def _xfer(self, send_seq, recv_seq):
+        """One grouped hand-off on the stage's transport: send this stage's output of sequence send_seq (hidden state, or the token
+        from the last stage) to the next rank, receive the input of sequence recv_seq from the previous one (None = nothing)."""
+        st = self.stage
+        skind, rkind = ("token" if st.is_last else "hidden"), ("token" if st.is_first else "hidden")
+        if send_seq is None and recv_seq is None:
+            return
+        if getattr(st, "peer", None) is not None:        # mailbox transport (thk_peer_*): stores into the next stage's memory, no library
+            st.peer_exchange([(skind, send_seq)] if send_seq is not None else [], [(rkind, recv_seq)] if recv_seq is not None else [])
+            return
+        if getattr(st, "pp", None) is not None:          # native RCCL transport (thk_pp_*), same schedule
+            st.native_exchange([(skind, send_seq, self.next)] if send_seq is not None else [], [(rkind, recv_seq, self.prev)] if recv_seq is not None else [])
+            return
+        ops = []
+        if send_seq is not None:                         # the token feeds item i_done + S on rank 0
+            ops.append(dist.P2POp(dist.isend, st.token[send_seq] if st.is_last else st.hidden_out[send_seq], self.next))
+        if recv_seq is not None:
+            ops.append(dist.P2POp(dist.irecv, st.token[recv_seq] if st.is_first else st.hidden_in[recv_seq], self.prev))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()                                     # stream-ordered for NCCL; blocking (bounded by the group's timeout) for gloo
+
     def _exchange(self, j: int, lo: int, hi):
         """Grouped P2P after micro-step j: send item (j - rank)'s output, receive the input of item (j + 1 - rank).
         Only items in [lo, hi) exist (hi = None: no upper bound, the ring is kept full)."""
-        st, r, N, S = self.stage, self.rank, self.world, self.S
+        r, N, S = self.rank, self.world, self.S
         live = (lambda i: lo <= i and (hi is None or i < hi))
         i_done = j - r                                   # item this rank just finished
         i_prev = j - ((r - 1) % N)                       # item the previous rank just finished
-        if getattr(st, "peer", None) is not None:        # mailbox transport (thk_peer_*): stores into the next stage's memory, no library
-            sends = [("token" if st.is_last else "hidden", i_done % S)] if live(i_done) else []
-            recvs = [("token" if st.is_first else "hidden", i_prev % S)] if live(i_prev) else []
-            if sends or recvs:
-                st.peer_exchange(sends, recvs)
-            return
-        if getattr(st, "pp", None) is not None:          # native RCCL transport (thk_pp_*), same schedule
-            sends, recvs = [], []
-            if live(i_done):
-                sends.append(("token" if st.is_last else "hidden", i_done % S, self.next))
-            if live(i_prev):
-                recvs.append(("token" if st.is_first else "hidden", i_prev % S, self.prev))
-            if sends or recvs:
-                st.native_exchange(sends, recvs)
-            return
-        ops = []
-        if live(i_done):
-            s = i_done % S
-            if not st.is_last:
-                ops.append(dist.P2POp(dist.isend, st.hidden_out[s], self.next))
-            else:                                        # the token feeds item i_done + S on rank 0
-                ops.append(dist.P2POp(dist.isend, st.token[s], self.next))
-        if live(i_prev):
-            if not st.is_first:
-                ops.append(dist.P2POp(dist.irecv, st.hidden_in[i_prev % S], self.prev))
-            else:
-                ops.append(dist.P2POp(dist.irecv, st.token[i_prev % S], self.prev))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()                                 # stream-ordered for NCCL; blocking for gloo
+        self._xfer(i_done % S if live(i_done) else None, i_prev % S if live(i_prev) else None)
+
+    def validate_handoff(self, reps: int = 16, sync=None) -> HandoffReport:
+        """Before anything is timed: every rank writes a known pattern into each sequence's output slot (hidden state, or token on
+        the last stage), the ring hands all of them over on the transport in use, and every receiver checks what arrived against the
+        pattern its predecessor must have written.  Then `reps` bare hand-offs per sequence are timed (every rank sends and receives in
+        each, as in a steady micro-step) -> handoff_us.  Clobbers hidden_in / token: call it before the sequences are set up.
+        sync: callable that waits for the device (None: CPU stage).  All ranks must call it together."""
+        st, r, N, S = self.stage, self.rank, self.world, self.S
+        if not self.ring:
+            return HandoffReport(True, 0, 0.0)
+        E = st.hidden_out[0].numel()
+
+        def pattern(rank, s, rep):                       # exactly representable f32 values, different for every (rank, sequence, element, round)
+            base = torch.arange(E, dtype=torch.float32)
+            return (base * 0.5 + float(1000 * rank + 10 * s + rep)) * (-1.0 if (rank + s) % 2 else 1.0)
+
+        def token_code(rank, s, rep):
+            return 7 + 100 * rank + 10 * s + rep
+
+        errors, checked = [], 0
+        for rep in range(2):                             # twice: the second round proves nothing stale from the first is read
+            for s in range(S):
+                if st.is_last:
+                    st.token[s].copy_(torch.tensor([token_code(r, s, rep)], dtype=torch.int32))
+                else:
+                    st.hidden_out[s].copy_(pattern(r, s, rep))
+            for s in range(S):
+                self._xfer(s, s)
+            if sync is not None:
+                sync()
+            for s in range(S):
+                if st.is_first:
+                    got, want = int(st.token[s].cpu()[0]), token_code(self.prev, s, rep)
+                    if got != want:
+                        errors.append(f"rank {r} seq {s} round {rep}: token {got} != {want} from rank {self.prev}")
+                else:
+                    got, want = st.hidden_in[s].cpu(), pattern(self.prev, s, rep)
+                    if not torch.equal(got, want):
+                        bad = int((got != want).sum())
+                        errors.append(f"rank {r} seq {s} round {rep}: {bad} of {E} hidden-state words differ from rank {self.prev}'s pattern")
+                checked += 1
+        if sync is not None:
+            sync()
+        t0 = time.perf_counter()
+        for k in range(reps):
+            for s in range(S):
+                self._xfer(s, s)
+        if sync is not None:
+            sync()
+        us = (time.perf_counter() - t0) / max(1, reps * S) * 1e6
+        return HandoffReport(not errors, checked, us, errors)
 
     def _micro(self, n_micro: int, lo: int, hi, advance: bool, forced_tokens=None) -> int:
         """n_micro global micro-steps from self.j on; returns the number of items this rank processed."""
@@ -236,15 +367,20 @@ class PipelineDriver:
             return PipelineResult(total, total)
         return PipelineResult(self._micro(total, self.base, None, advance), total)
 
-    def drain(self, advance: bool) -> PipelineResult:
-        """Let the items already issued by rank 0 leave the last stage (N - 1 micro-steps); the ring is empty afterwards."""
+    def drain(self, advance: bool, align: bool = True) -> PipelineResult:
+        """Let the items already issued by rank 0 leave the last stage; the ring is empty afterwards.  prime() issued N - 1 items
+        beyond whole steps, so with align (default) rank 0 first issues the S - (N - 1) % S items that complete the step: every
+        sequence then ends the same number of tokens ahead and the ring is back on a step boundary (run(forced_tokens=...) needs
+        one).  align=False keeps round 3's behaviour (sequences 0..N-2 end one token ahead of the rest)."""
         assert self.primed
         self.primed = False
         if not self.ring:
             return PipelineResult(0, 0)
-        n = self.world - 1
         hi = self.j                                       # rank 0 has issued items [base, j)
+        top = (-(hi - self.base)) % self.S if align else 0
+        hi += top
+        n = top + self.world - 1
         done = self._micro(n, self.base, hi, advance)
         self.base = hi
         self.j = hi
-        return PipelineResult(done, n)
+        return PipelineResult(done, n, top)
