@@ -191,8 +191,10 @@ def cpu_baseline(shape_name, T, layers=0, parity=None):
                       f"cpu='{cpu_model}'; run {time.time() - t0:.1f}s"}, par
 
 
-def kernel_profile(model, shape, T, n_steps=6):
-    """Per-kernel average duration (HIP events on the libthk stream, eager launches)."""
+def kernel_profile(model, shape, T, n_steps=6, kv_bytes=4):
+    """Per-kernel average duration of EAGER launches (HIP events on the libthk stream between un-graphed launches: each figure
+    carries the ~2-3 us dispatch gap a graph replay does not pay; the graph-replay cost of the dominant kernel is measured
+    separately as a marginal cost, see `roofline`).  Every field is therefore prefixed eager_."""
     agg = {}
     for _ in range(n_steps):
         for name, ms in model.profile_step(0):
@@ -201,9 +203,8 @@ def kernel_profile(model, shape, T, n_steps=6):
     E, F, V = shape.n_embd, shape.n_ff, shape.n_vocab
     alg = {   # algorithmic bytes per launch
         "norm_qkv_rope_kv": 3 * E * E * 2 + 2 * E * 4 + 2 * E * 4,
-        "attn_decode": 2 * T * E * 4,
+        "attn_decode": 2 * T * E * kv_bytes,
         "attn_wo_resid": E * E * 2,
-        "attn_wo_fused": 2 * T * E * 4 + E * E * 2,
         "norm_w13_swiglu": 2 * E * F * 2 + E * 4,
         "w2_resid": E * F * 2,
         "norm_lmhead": V * E * 2 + E * 4,
@@ -211,9 +212,9 @@ def kernel_profile(model, shape, T, n_steps=6):
     out = {}
     for name, (tot, n) in agg.items():
         avg_ms = tot / n
-        out[name] = {"avg_us": round(avg_ms * 1e3, 2), "launches_per_step": n // n_steps,
+        out[name] = {"eager_avg_us": round(avg_ms * 1e3, 2), "launches_per_step": n // n_steps,
                      "alg_bytes": alg.get(name, 0),
-                     "gbs": round(alg.get(name, 0) / (avg_ms * 1e-3) / 1e9, 1) if name in alg and avg_ms > 0 else None}
+                     "eager_gbs": round(alg.get(name, 0) / (avg_ms * 1e-3) / 1e9, 1) if name in alg and avg_ms > 0 else None}
     return out
 
 
@@ -251,6 +252,44 @@ def extra_prefill_128(thk, model, shape, ctx):
             "ms_min": round(min(ts) * 1e3, 3), "tok_s": round(M / t, 1), "tflops": round(flops / t / 1e12, 2), "mfma_peak_tflops_f16_dense": 2500,
             "frac_of_mfma_peak": round(flops / t / 2.5e15, 4), "weight_pass_hbm_ms": round(shape.weight_bytes() / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
             "first_call_ms": round(t_first * 1e3, 1), "timing": "host wall time around thk_model_prefill (host-to-device token copy and 128 KB logits read-back included), median of 5"}
+
+
+def extra_decode_ctx2048(thk, ctx, stream, torch, kv_f16, steps=60, warmup=10):
+    """SURVEY 8(f)3 "context > 512": LLaMA-7B with a 2048-row cache, decode at n_past = 2047 (T = 2048).  The cache is filled by
+    the MFMA prefill path in 128-token slabs; attention splits follow the live context and the auto split count is 8 there."""
+    shape = thk.ModelShape(n_ctx=2048)
+    Tl = shape.n_ctx
+    old = ctx.get_tunable("kv_f16")
+    ctx.set_tunable("kv_f16", 1 if kv_f16 else 0)
+    try:
+        m = thk.Model(ctx, shape, n_seq=1)
+        m.fill_synthetic(); m.finalize()
+    finally:
+        ctx.set_tunable("kv_f16", old)
+    try:
+        prompt = synthetic_prompt(shape, Tl, 0)
+        m.prefill(prompt[:Tl - 1], 0, want_logits=False)
+        m.seq_set(0, int(prompt[Tl - 1]), Tl - 1)
+        m.prepare_steps(warmup); m.prepare_steps(steps)
+        m.decode_steps(warmup, 0, advance=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.decode_steps(steps, 0, advance=False)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kvb = 2 if kv_f16 else 4
+        b_tok = shape.bytes_per_token(Tl, kv_bytes=kvb)
+        tok_s = steps / wall
+        kp = kernel_profile(m, shape, Tl, n_steps=3, kv_bytes=kvb)
+        att = kp.get("attn_decode", {})
+        return {"workload": f"LLaMA-7B f16, n_ctx=2048, single-token greedy decode at n_past=2047, {'binary16' if kv_f16 else 'f32'} KV cache, 1 sequence",
+                "tok_s": round(tok_s, 2), "ms_per_step": round(wall / steps * 1e3, 4), "steps": steps, "bytes_per_token": b_tok,
+                "step_roofline": {"achieved": round(b_tok * tok_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_tok * tok_s / 1e9 / HBM_PEAK_GBS, 4)},
+                "attention": {"alg_bytes": att.get("alg_bytes"), "eager_avg_us": att.get("eager_avg_us"), "eager_gbs": att.get("eager_gbs"),
+                              "eager_frac_of_hbm_peak": round(att["eager_gbs"] / HBM_PEAK_GBS, 4) if att.get("eager_gbs") else None,
+                              "attn_splits": 8, "workgroups": shape.n_head * 8 * 2}}
+    finally:
+        m.close()
 
 
 def extra_decode_13b(thk, ctx, T, stream, torch, steps=100, warmup=20):
@@ -647,8 +686,8 @@ def main():
                                    f"{'1 sequence' if N == 1 else f'{S} sequences in flight, layers pipelined over {N} GPUs (RCCL p2p)'}",
                        "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single", "transport": args.transport if PIPE else None,
                        "lmhead_mode": args.lmhead, "numerics": "f16 GGML weights x f32 activations, f32 accumulate, " + ("f32 KV cache (as the reference)" if kv_bytes == 4 else "binary16 KV cache (OPTION, not the reference's: s_kv = 2 in bytes/token)"),
-                       "decode_path": "persistent engine (1 launch/step)" if model.uses_engine() else "5 fused launches per layer, hipGraph replay (n-step graphs, n <= 32: 20 steps = one graph)",
-                       "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "attn_waves", "use_graph", "engine", "fold_embed")}},
+                       "decode_path": "persistent engine (1 launch/step)" if model.uses_engine() else "5 fused launches per layer + lm-head (greedy pick folded in), kernel arguments preloaded into SGPRs, hipGraph replay (n-step graphs, n <= 32: 20 steps = one graph)",
+                       "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "attn_vsplit", "attn_tc_dyn", "attn_waves", "use_graph", "engine", "fold_embed", "fold_finish")}},
             "bytes_per_token": b_tok,
             "step_roofline": {"achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                               "frac_of_copy_rate": round(step_gbs / COPY_RATE_GBS, 4), "event_ms_per_step": round(ev_ms / args.steps, 4)},
@@ -698,11 +737,11 @@ def main():
         # ---- dominant-kernel roofline (rank 0, eager per-kernel HIP-event timing after the timed region)
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None}
         if rank == 0 and not args.no_kernel_profile:
-            kp = kernel_profile(model, shape, T)
+            kp = kernel_profile(model, shape, T, kv_bytes=2 if ctx.get_tunable("kv_f16") else 4)
             dom = max((k for k in kp if kp[k]["alg_bytes"]), key=lambda k: kp[k]["alg_bytes"] * kp[k]["launches_per_step"])
-            roof.update({"kernel": dom, "achieved": kp[dom]["gbs"], "frac": round(kp[dom]["gbs"] / HBM_PEAK_GBS, 4),
-                         "avg_us": kp[dom]["avg_us"], "alg_bytes_per_launch": kp[dom]["alg_bytes"],
-                         "frac_of_copy_rate": round(kp[dom]["gbs"] / COPY_RATE_GBS, 4)})
+            roof.update({"kernel": dom, "achieved": kp[dom]["eager_gbs"], "frac": round(kp[dom]["eager_gbs"] / HBM_PEAK_GBS, 4),
+                         "avg_us": kp[dom]["eager_avg_us"], "alg_bytes_per_launch": kp[dom]["alg_bytes"],
+                         "frac_of_copy_rate": round(kp[dom]["eager_gbs"] / COPY_RATE_GBS, 4)})
             roof["timing"] = "HIP events around eager launches on the libthk stream (includes the ~1.5-2.5 us launch gap)"
             builder = {}
             for key, fname in (("traffic", "pmc_traffic.json"), ("rocprof_avg_us", "kernel_durations.json")):
@@ -754,6 +793,11 @@ def main():
                     extras["decode_13b"] = extra_decode_13b(thk, ctx, T, stream, torch)
                 except Exception as e:
                     extras["decode_13b"] = {"error": str(e)}
+                for name, f16 in (("decode_ctx2048", False), ("decode_ctx2048_kv_f16", True)):
+                    try:
+                        extras[name] = extra_decode_ctx2048(thk, ctx, stream, torch, f16)
+                    except Exception as e:
+                        extras[name] = {"error": str(e)}
             extras["wall_s"] = round(time.time() - t_x, 1)
             result["extras"] = extras
 

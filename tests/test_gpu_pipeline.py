@@ -221,6 +221,12 @@ def _peer_worker(rank, world, port, n_prompt, n_gen, q):
         stage.connect_peer(handles[(rank + 1) % world])
         dist.barrier()
         drv = PipelineDriver(stage, rank, world, S)
+        # what bench.py does before anything is timed: known patterns through every mailbox slot, both ways round the ring
+        rep = drv.validate_handoff(reps=4, sync=ctx.sync)
+        stage.peer_check()
+        assert rep.ok and rep.checked == 2 * S and rep.handoff_us > 0, rep
+        assert ctx.lib.thk_peer_memory_kind(stage.peer) in (0, 1, 2)
+        print(f"[peer r{rank}] mailbox memory kind {ctx.lib.thk_peer_memory_kind(stage.peer)} (0 coarse, 1 uncached, 2 fine-grained), bare hand-off {rep.handoff_us:.1f} us", flush=True)
         rng = np.random.default_rng(7)
         prompts = rng.integers(3, 2048, (n_prompt, S)); prompts[0, :] = 1
         for s in range(S):
@@ -237,7 +243,7 @@ def _peer_worker(rank, world, port, n_prompt, n_gen, q):
                 full.seq_set(s, int(prompts[0, s]), 0)
                 full.eval(prompts[:, s].astype(np.int32), 0, seq=s, want_logits=False)      # logs the greedy pick after every prompt token
                 exp = full.seq_get(s)[0].tolist()
-                extra = 1 if s < world - 1 else 0                                         # prime + steady + drain issue N - 1 + n_gen * S items
+                extra = 1                                                                 # prime issues N - 1 items beyond whole steps, drain() tops the step up: every sequence ends one token ahead
                 full.seq_set(s, exp[-1], n_prompt)
                 full.decode_steps(n_gen + extra, s, advance=True)
                 exp += full.seq_get(s)[0].tolist()                                        # n_prompt + n_gen + extra picks
