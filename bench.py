@@ -287,7 +287,8 @@ def extra_decode_ctx2048(thk, ctx, stream, torch, kv_f16, steps=60, warmup=10):
                 "step_roofline": {"achieved": round(b_tok * tok_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_tok * tok_s / 1e9 / HBM_PEAK_GBS, 4)},
                 "attention": {"alg_bytes": att.get("alg_bytes"), "eager_avg_us": att.get("eager_avg_us"), "eager_gbs": att.get("eager_gbs"),
                               "eager_frac_of_hbm_peak": round(att["eager_gbs"] / HBM_PEAK_GBS, 4) if att.get("eager_gbs") else None,
-                              "attn_splits": 8, "workgroups": shape.n_head * 8 * 2}}
+                              "attn_splits": 8, "workgroups": shape.n_head * 8 * (2 if ctx.get_tunable("attn_vsplit") == 2 else 1),
+                              "variant": "software-pipelined rounds (two K/V batches in flight per wave)"}}
     finally:
         m.close()
 

@@ -60,11 +60,11 @@ R03_STEP = {"attn_vsplit": 1, "attn_tc_dyn": 0, "fold_finish": 0, "attn_splits":
 
 
 @pytest.mark.parametrize("tunables", [{"attn_waves": 4}, {"attn_waves": 4, "attn_splits": 8}, {"fold_embed": 0}, {"fold_embed": 0, "use_graph": 0},
-                                      {"attn_vsplit": 1}, {"attn_tc_dyn": 0}, {"attn_vsplit": 1, "attn_tc_dyn": 0, "attn_waves": 4},
+                                      {"attn_vsplit": 2}, {"attn_tc_dyn": 0}, {"attn_vsplit": 2, "attn_tc_dyn": 0, "attn_waves": 4},
                                       {"fold_finish": 0}, {"fold_finish": 0, "use_graph": 0}, {"fold_finish": 1, "use_graph": 0}, R03_STEP])
 def test_optional_paths_vs_oracle(thk, orc, ctx, tunables):
     """The off-by-default options stay correct: 4-wave attention blocks, the stand-alone embedding launch (default: the row is
-    fetched by layer 0's qkv prologue), one attention workgroup per (head, split) (default: a pair that halves the V columns),
+    fetched by layer 0's qkv prologue), attention workgroup pairs that halve the V columns (default: one workgroup per (head, split)),
     splits over the cache capacity (default: over the live context), the greedy pick as a launch of its own (default: folded into
     the lm-head launch's last workgroup)."""
     m, om = make_pair(thk, orc, ctx, "TINY", tunables=tunables)
@@ -670,9 +670,8 @@ def test_7b_full_model_prefill_128_vs_token_by_token(thk, ctx):
 
 
 def test_7b_round4_step_equals_round3_step(thk, ctx):
-    """Full 7B, real geometry: the round-4 step (paired attention workgroups that halve the V columns, splits over the live
-    context, greedy pick folded into the lm-head launch, kernel arguments preloaded) against round 3's launch geometry (one
-    workgroup per (head, split), splits over n_ctx, finish_token launch).  The default model free-runs 24 greedy tokens on the
+    """Full 7B, real geometry: the round-4 step (attention splits over the live context, greedy pick folded into the lm-head
+    launch, kernel arguments preloaded) against round 3's launch geometry (splits over n_ctx, finish_token launch).  The default model free-runs 24 greedy tokens on the
     device; the round-3 geometry is teacher-forced with them: logits equal to summation-order noise at every position, the same
     pick wherever the top-2 margin is not itself noise; the same at the last cache slot."""
     shape = thk.LLAMA_7B

@@ -575,7 +575,7 @@ __device__ __forceinline__ f4 ld_kv4(const float* base, size_t elem_off) {
     }
     return __builtin_nontemporal_load(reinterpret_cast<const f4*>(base + elem_off));
 }
-template <int D, int WAVES, bool KVH, int VS = 1>
+template <int D, int WAVES, bool KVH, int VS = 1, bool PIPE = false>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     constexpr int LPP = D / 4;          // lanes per position (K)
     constexpr int PPW = 64 / LPP;       // positions per wave-instruction (K)
@@ -618,6 +618,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     // positions past the end are clamped to a valid row and masked out of the softmax.
     // (Round 3 tried fetching the first batch BEFORE the device-resident position is known - every row below n_ctx is
     // allocated - to take the position's round trip off the critical path: 0.6 us per launch SLOWER on MI355X, removed.)
+    if constexpr (!PIPE) {
     for (int tb = t0 + wave * (PPW * UB); tb < t1; tb += WAVES * PPW * UB) {
         f4 kv[UB], vv[UBV];
 #pragma unroll
@@ -660,6 +661,71 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
         }
         m = mn;
         THK_STAMP(a.trace, bid, 1);
+    }
+    } else {
+    // PIPE (long caches: a (head, split) longer than one round of the workgroup, WAVES * PPW * UB positions): the rounds are software-
+    // pipelined - the next round's K/V batch is requested BEFORE this round's softmax arithmetic, so a wave has two batches in
+    // flight and the rounds are not a chain of dependent HBM round trips.  A variant of its own: the same structure cost the
+    // single-round case (T <= 512 with 4 splits, the headline) 1 us per launch (profiles/r04_attention_ctx2048.txt).
+    auto fetch = [&](int tb, f4 (&kv)[UB], f4 (&vv)[UBV]) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int t = min(tb + u * PPW + grp, t1 - 1);
+            kv[u] = ld_kv4<KVH>(a.kcache, (size_t)t * E + koff);
+        }
+#pragma unroll
+        for (int u = 0; u < UBV; ++u) {
+            const int t = min(tb + (VS * u + sel) * PPW + grp, t1 - 1);
+            vv[u] = ld_kv4<KVH>(a.vcache, (size_t)t * E + voff);
+        }
+    };
+    constexpr int STRIDE = WAVES * PPW * UB;
+    int tb = t0 + wave * (PPW * UB);
+    f4 kv[UB], vv[UBV];
+    if (tb < t1) fetch(tb, kv, vv);
+    while (tb < t1) {
+        f4 kvn[UB], vvn[UBV];
+        const int tn = tb + STRIDE;
+        const bool more = tn < t1;                  // wave-uniform
+        if (more) fetch(tn, kvn, vvn);
+        __builtin_amdgcn_sched_barrier(0);
+        float sc[UB];
+        float bm = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int t = tb + u * PPW + grp;
+            float d = q.x * kv[u].x + q.y * kv[u].y + q.z * kv[u].z + q.w * kv[u].w;
+            d = group_sum<LPP>(d) * a.scale;
+            sc[u] = (t < t1) ? d : -INFINITY;
+            bm = fmaxf(bm, sc[u]);
+        }
+        bm = wave_max(bm);                      // wave-uniform, finite (tb < t1 => lane group 0 valid)
+        const float mn = fmaxf(m, bm);
+        const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
+        l *= alpha; o *= alpha;
+        float p[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { p[u] = expf(sc[u] - mn); l += p[u]; }   // exp(-inf) == 0 for masked positions
+        // VS == 2: the lane's V position of instruction u is K position 2u + sel.  Blended with a bit mask, not with `sel ? a : b`:
+        // the compiler turns a select of two array elements into ONE dynamically indexed access and then moves the whole array
+        // into LDS (18 KB per workgroup, attention 6x slower - measured, round 4).
+        const unsigned selm = 0u - (unsigned)sel;
+#pragma unroll
+        for (int u = 0; u < UBV; ++u) {
+            float pv = p[u % UB];
+            if (VS == 2) pv = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, p[(2 * u + 1) % UB]) & selm) | (__builtin_bit_cast(unsigned, p[(2 * u) % UB]) & ~selm));
+            o += vv[u] * pv;
+        }
+        m = mn;
+        THK_STAMP(a.trace, bid, 1);
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) kv[u] = kvn[u];
+#pragma unroll
+            for (int u = 0; u < UBV; ++u) vv[u] = vvn[u];
+        }
+        tb = tn;
+    }
     }
     // merge the lane groups of the wave (same m): l over the PPW K groups, o over the PPV V groups
 #pragma unroll

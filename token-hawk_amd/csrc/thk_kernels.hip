@@ -167,21 +167,24 @@ hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, b
 
 // leading scalars: preloaded into SGPRs at wave launch (see gemv_kernel) - the position, q and the cache rows are what the chain
 // of dependent loads starts from
-template <int D, int WAVES, bool KVH, int VS>
+template <int D, int WAVES, bool KVH, int VS, bool PIPE = false>
 __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(const int32_t* pos_ptr, const float* q, const float* kcache, const float* vcache,
                                                                  int pos_val, int H, int nsplit, int tc, int tc_dyn, int nq, const AttnArgs a) {
     AttnArgs b = a;
     b.pos_ptr = pos_ptr; b.q = q; b.kcache = kcache; b.vcache = vcache; b.pos_val = pos_val; b.H = H; b.nsplit = nsplit; b.tc = tc; b.tc_dyn = tc_dyn; b.nq = nq;
-    attn_body<D, WAVES, KVH, VS>(b, blockIdx.x);
+    attn_body<D, WAVES, KVH, VS, PIPE>(b, blockIdx.x);
 }
 
 template <int D, int WAVES>
 static void launch_attn_dw(const AttnArgs& a, int grid, hipStream_t st) {
     const bool v2 = a.vsplit == 2;
-#define THK_ATTN_GO(kvh, vs) hipLaunchKernelGGL((attn_decode_kernel<D, WAVES, kvh, vs>), dim3(grid), dim3(WAVES * 64), 0, st, a.pos_ptr, a.q, a.kcache, a.vcache, \
-                                                a.pos_val, a.H, a.nsplit, a.tc, a.tc_dyn, a.nq, a)
-    if (a.kv_f16) { if (v2) THK_ATTN_GO(true, 2); else THK_ATTN_GO(true, 1); }
-    else { if (v2) THK_ATTN_GO(false, 2); else THK_ATTN_GO(false, 1); }
+#define THK_ATTN_GO(kvh, vs, pp) hipLaunchKernelGGL((attn_decode_kernel<D, WAVES, kvh, vs, pp>), dim3(grid), dim3(WAVES * 64), 0, st, a.pos_ptr, a.q, a.kcache, a.vcache, \
+                                                    a.pos_val, a.H, a.nsplit, a.tc, a.tc_dyn, a.nq, a)
+    if constexpr (D == 128 && WAVES == 8) {       // the software-pipelined rounds (long caches) exist for the LLaMA head size, one workgroup per (head, split)
+        if (a.pipe && !v2) { if (a.kv_f16) THK_ATTN_GO(true, 1, true); else THK_ATTN_GO(false, 1, true); return; }
+    }
+    if (a.kv_f16) { if (v2) THK_ATTN_GO(true, 2, false); else THK_ATTN_GO(true, 1, false); }
+    else { if (v2) THK_ATTN_GO(false, 2, false); else THK_ATTN_GO(false, 1, false); }
 #undef THK_ATTN_GO
 }
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {

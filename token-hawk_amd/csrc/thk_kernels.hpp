@@ -63,6 +63,7 @@ struct AttnArgs {
     int H, D, nsplit, tc;      // tc = positions per split ...
     int tc_dyn;                // ... or 1: tc = ceil(T / nsplit) rounded up to the wave batch, computed on the device from the live position
     int vsplit;                // 1 | 2: workgroups per (head, split), each taking 1/vsplit of the V columns (attn_body)
+    int pipe;                  // 1: a split may span several rounds of the workgroup (long caches): take the software-pipelined variant where it exists
     int waves;                 // waves per block of the stand-alone kernel (4 or 8)
     int nq;                    // causal queries in this launch (prefill); 0/1 = single decode query
     int kv_f16;                // the caches hold binary16 (kcache / vcache then point to _Float16 data)

@@ -276,6 +276,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             AttnArgs t{};
             t.q = m->q; t.kcache = kc; t.vcache = vc; t.pos_ptr = &sb.st->pos; t.H = H; t.D = D; t.nsplit = m->nsplit; t.tc = m->tc;
             t.tc_dyn = m->attn_tc_dyn; t.vsplit = m->attn_vsplit;
+            t.pipe = (T + m->nsplit - 1) / m->nsplit > m->attn_waves * (64 / (D / 4)) * 8;      // a split of the full cache is longer than one round
             t.scale = 1.0f / sqrtf((float)D); t.waves = m->attn_waves; t.kv_f16 = m->kv_f16;
             t.out = m->nsplit == 1 ? m->attn_out : nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml;
             GemvArgs a{};
@@ -387,7 +388,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->kv_f16 = tun(ctx, "kv_f16") != 0;
     m->fold_embed = tun(ctx, "fold_embed") != 0;
     m->fold_finish = tun(ctx, "fold_finish") != 0;
-    m->attn_vsplit = tun(ctx, "attn_vsplit") == 1 ? 1 : 2;
+    m->attn_vsplit = tun(ctx, "attn_vsplit") == 2 ? 2 : 1;
     m->attn_tc_dyn = tun(ctx, "attn_tc_dyn") != 0;
     m->gain_alias = tun(ctx, "measure_gain_alias") != 0;
     m->var_qkv = resolve_variant(ctx, "qkv", (int)E); m->var_wo = resolve_variant(ctx, "wo", (int)E);

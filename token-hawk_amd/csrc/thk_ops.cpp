@@ -74,7 +74,8 @@ extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache
     a.q = q; a.kcache = kcache; a.vcache = vcache; a.pos_ptr = nullptr; a.pos_val = (int)T - 1;
     a.H = (int)H; a.D = (int)D; a.nsplit = nsplit; a.tc = (int)((T + nsplit - 1) / nsplit);
     a.scale = 1.0f / sqrtf((float)D); a.waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
-    a.tc_dyn = tun(ctx, "attn_tc_dyn") != 0; a.vsplit = tun(ctx, "attn_vsplit") == 1 ? 1 : 2;
+    a.tc_dyn = tun(ctx, "attn_tc_dyn") != 0; a.vsplit = tun(ctx, "attn_vsplit") == 2 ? 2 : 1;
+    a.pipe = (T + nsplit - 1) / nsplit > a.waves * (64 / ((int)D / 4)) * 8;
     a.part_o = (float*)ctx->scratch; a.part_ml = a.part_o + (size_t)H * nsplit * D;
     a.out = nsplit == 1 ? out : nullptr;
     HIPCHK(ctx, launch_attn_decode(a, ctx->stream));
