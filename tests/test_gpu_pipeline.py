@@ -196,6 +196,37 @@ def test_driver_with_peer_mailbox_transport_single_rank_ring(thk, orc):
     stage.model.close(); ctx.close()
 
 
+def test_peer_timeout_is_sticky(thk):
+    """A hand-off that never arrives: the bounded wait (~2 s) raises the error word instead of hanging the GPU, thk_peer_check
+    reports it - and keeps reporting it - every later send / recv is refused (the flag sequence is out of step from then on), a
+    wait already enqueued behind the failure returns at once; a fresh peer works again.  The mailbox's memory kind is reported."""
+    import time
+    import torch
+    from token_hawk_amd.pipeline import HipStage
+    dev = torch.device("cuda", 0)
+    ctx = thk.Context(0)
+    stage = HipStage(thk, ctx, thk.TINY, 0, 1, 1, dev)
+    stage.attach_peer_transport(1)
+    stage.connect_peer(None)
+    assert ctx.lib.thk_peer_memory_kind(stage.peer) in (0, 1, 2)
+    lib, peer = ctx.lib, stage.peer
+    t0 = time.time()
+    assert lib.thk_peer_recv(peer, 0, 0) == 0          # nobody sent: this wait times out on the device
+    assert lib.thk_peer_recv(peer, 0, 1) == 0          # enqueued behind it: must not wait another 2 s
+    assert lib.thk_peer_check(peer) != 0               # THK_ERR_STATE
+    assert 1.0 < time.time() - t0 < 3.8, time.time() - t0
+    assert b"timed out" in lib.thk_last_error(ctx.h)
+    assert lib.thk_peer_check(peer) != 0               # sticky
+    assert lib.thk_peer_send(peer, 0, 0) != 0 and lib.thk_peer_recv(peer, 0, 0) != 0
+    assert b"destroy" in lib.thk_last_error(ctx.h)
+    lib.thk_peer_destroy(peer)
+    stage.attach_peer_transport(1); stage.connect_peer(None)      # a new peer on the same stage: counters and flags start afresh
+    stage.peer_exchange([("hidden", 0)], [("hidden", 0)])
+    stage.peer_check()
+    lib.thk_peer_destroy(stage.peer)
+    stage.model.close(); ctx.close()
+
+
 def _peer_worker(rank, world, port, n_prompt, n_gen, q):
     """One pipeline stage per PROCESS, both on GPU 0: the hidden state and the token cross the process boundary through
     hipIpc-mapped mailboxes (thk_peer_*); gloo only carries the 64-byte handles and the barriers."""

@@ -159,15 +159,24 @@ struct PrefillPlan {
     size_t ximg_bytes, slot_floats, part_floats;
 };
 PrefillPlan prefill_plan(int M, int R, int nmat, int C, int G /* workgroups; 0 = default (256) */, int tile_rows /* 128 | 256 (default) */);
-hipError_t launch_prefill_ximg(const float* X, const float* gain_or_null, int M, int C, void* ximg, hipStream_t st);
+// ssq != NULL (with a gain): DEFERRED norm - the image holds x * 2^k * gain (2^k = the power of two below 1/rms), the row's sum of squares is added
+// to ssq[token] (2^-24 fixed point, must be zero before), and the reducer of the GEMM that consumes the image applies 1/rms / 2^k
+// (launch_prefill_reduce_qkv / _swiglu with ssq = ssq_scale = this array)
+hipError_t launch_prefill_ximg(const float* X, const float* gain_or_null, int M, int C, void* ximg, hipStream_t st, unsigned long long* ssq = nullptr);
+// X += sum of the partial tiles (residual add), and the deferred-norm image of the result for the next GEMM (x * gain, sum of squares -> ssq)
+// (2^k from ssq_scale: the sum of squares of the token's PREVIOUS norm input - the consumer is given the same array)
+hipError_t launch_prefill_reduce_resid_ximg(const float* part, const PrefillPlan& p, float* X, const float* gain, void* ximg, unsigned long long* ssq,
+                                            const unsigned long long* ssq_scale, hipStream_t st);
 hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& p, const void* ximg, float* part, hipStream_t st);
 size_t prefill_pack_bytes(int R, int C, int tile_rows);
 hipError_t launch_prefill_pack(const uint16_t* W, int R, int C, int tile_rows, void* out, hipStream_t st);
 hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st);
-hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, void* kcache, void* vcache, bool kv_f16, hipStream_t st);
+hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, void* kcache, void* vcache, bool kv_f16, hipStream_t st,
+                                     const unsigned long long* ssq = nullptr, const unsigned long long* ssq_scale = nullptr);
 // causal attention for the M queries of a slab (D = 64 | 128), f32-class accuracy on MFMA
 hipError_t launch_attn_prefill_mfma(const float* Q, const void* Kc, const void* Vc, bool kv_f16, int n_past, int M, int H, int D, float* out /* [M,H*D] or null */,
                                     void* ximg /* if out is null: the X image of the consuming GEMM */, hipStream_t st);
-hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st);
+hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st, const unsigned long long* ssq = nullptr,
+                                        const unsigned long long* ssq_scale = nullptr);
 
 }  // namespace thk

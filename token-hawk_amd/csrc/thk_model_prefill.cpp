@@ -7,9 +7,12 @@
 // is disabled, th-llama.cpp:15, and its causal mask is only right at n_past == 0, Q5): causal
 // attention over the f32 cache, K/V rows appended at [n_past, n_past+M), logits of the last token.
 //
-// Per 128-token slab and layer, 11 launches: norm->X image | wq,wk,wv GEMM | reduce + RoPE + KV write | causal
-// attention -> X image | wo GEMM | reduce + residual | norm->X image | w1,w3 GEMM | reduce + SwiGLU -> X image |
-// w2 GEMM | reduce + residual.  (thk_prefill.hip explains the GEMM: LDS-DMA pipeline, stream-K, hi/lo split.)
+// Per 128-token slab and layer, 9 launches (round 4; 11 before): wq,wk,wv GEMM | reduce + 1/rms + RoPE + KV write | causal
+// attention -> X image | wo GEMM | reduce + residual -> x, image of x * ffn gain, sum of squares | w1,w3 GEMM | reduce + 1/rms +
+// SwiGLU -> X image | w2 GEMM | reduce + residual -> x, image of x * the NEXT layer's attention gain, sum of squares.  The two
+// norm -> image launches are gone: RMSNorm's per-token scalar is applied on the output side of the GEMM ("deferred norm",
+// thk_prefill.hip; tunable prefill_deferred_norm = 0 restores the 11-launch form).  Layer 0's image comes from the embedding rows.
+// (thk_prefill.hip explains the GEMM: LDS-DMA pipeline, stream-K, hi/lo split.)
 // The four GEMM plans of a slab of M tokens (qkv, wo, w13, w2) from the prefill_blocks_* / prefill_tile_* tunables.
 static int slab_plans(thk_model* m, int M, PrefillPlan out[4]) {
     thk_ctx* ctx = m->ctx;
@@ -24,7 +27,7 @@ static int slab_plans(thk_model* m, int M, PrefillPlan out[4]) {
     }
     return THK_OK;
 }
-struct PrefillBufs { float *X, *Q, *ATT; int32_t* tok; char *imgE, *imgF; float* part; };
+struct PrefillBufs { float *X, *Q, *ATT; int32_t* tok; char *imgE, *imgF; float* part; unsigned long long* ssq; size_t ssq_bytes; };
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 static int prefill_workspace(thk_model* m, PrefillBufs* b) {
     thk_ctx* ctx = m->ctx;
@@ -42,7 +45,8 @@ static int prefill_workspace(thk_model* m, PrefillBufs* b) {
         img_f = std::max(img_f, pl[3].ximg_bytes);
     }
     const size_t imgE = align256(img_e), imgF = align256(img_f), part = align256(4 * part_floats);
-    const size_t bytes = 3 * per + 1024 + imgE + imgF + part;
+    const size_t ssq_bytes = align256((size_t)(m->l1 - m->l0) * 2 * 128 * 8);      // deferred norm: sum of squares per (layer, norm, token), 2^-24 fixed point
+    const size_t bytes = 3 * per + 1024 + imgE + imgF + part + ssq_bytes;
     if (m->prefill_ws_bytes < bytes) {
         if (m->prefill_ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(m->prefill_ws)); m->prefill_ws = nullptr; }
         hipError_t e = hipMalloc(&m->prefill_ws, bytes);
@@ -51,7 +55,8 @@ static int prefill_workspace(thk_model* m, PrefillBufs* b) {
     }
     char* p = (char*)m->prefill_ws;
     b->X = (float*)p; p += per; b->Q = (float*)p; p += per; b->ATT = (float*)p; p += per;
-    b->tok = (int32_t*)p; p += 1024; b->imgE = p; p += imgE; b->imgF = p; p += imgF; b->part = (float*)p;
+    b->tok = (int32_t*)p; p += 1024; b->imgE = p; p += imgE; b->imgF = p; p += imgF; b->part = (float*)p; p += part;
+    b->ssq = (unsigned long long*)p; b->ssq_bytes = ssq_bytes;
     return THK_OK;
 }
 
@@ -136,7 +141,11 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
     HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipStreamSynchronize(st));   // tokens may be a stack buffer
     HIPCHK(ctx, launch_embed_rows(m->tok_embeddings, b.tok, M, E, b.X, st));
-    for (int i = 0; i < m->l1 - m->l0; ++i) {
+    const int nl = m->l1 - m->l0;
+    const bool defer = tun(ctx, "prefill_deferred_norm") != 0;
+    if (defer) HIPCHK(ctx, hipMemsetAsync(b.ssq, 0, b.ssq_bytes, st));
+    auto ssq_of = [&](int layer, int which) { return b.ssq + ((size_t)layer * 2 + which) * 128; };      // which: 0 attention norm, 1 ffn norm
+    for (int i = 0; i < nl; ++i) {
         const LayerW& L = m->layers[i];
         float* kc = kcache_of(m, sb, i);
         float* vc = vcache_of(m, sb, i);
@@ -144,9 +153,12 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
         const uint16_t* w13[2] = {pk ? m->pk_w[i][4] : L.w1, pk ? m->pk_w[i][6] : L.w3};
         const uint16_t* wo = pk ? m->pk_w[i][3] : L.wo;
         const uint16_t* w2 = pk ? m->pk_w[i][5] : L.w2;
-        HIPCHK(ctx, launch_prefill_ximg(b.X, L.attention_norm, M, E, b.imgE, st));
+        if (!defer) HIPCHK(ctx, launch_prefill_ximg(b.X, L.attention_norm, M, E, b.imgE, st));
+        else if (i == 0) HIPCHK(ctx, launch_prefill_ximg(b.X, L.attention_norm, M, E, b.imgE, st, ssq_of(0, 0)));     // later layers: written by the previous layer's last reducer
         HIPCHK(ctx, launch_prefill_gemm(wqkv, pq, b.imgE, b.part, st));
-        HIPCHK(ctx, launch_prefill_reduce_qkv(b.part, pq, m->rope_tab, n_past, D, b.Q, kc, vc, m->kv_f16 != 0, st));
+        // the image's power-of-two scale came from: the row itself (layer 0), else the previous layer's ffn-norm input
+        HIPCHK(ctx, launch_prefill_reduce_qkv(b.part, pq, m->rope_tab, n_past, D, b.Q, kc, vc, m->kv_f16 != 0, st, defer ? ssq_of(i, 0) : nullptr,
+                                              defer ? (i == 0 ? ssq_of(0, 0) : ssq_of(i - 1, 1)) : nullptr));
         if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) {
             HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, m->kv_f16 != 0, n_past, M, H, D, nullptr, b.imgE, st));   // writes wo's X image directly
         } else {
@@ -154,12 +166,17 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
             HIPCHK(ctx, launch_prefill_ximg(b.ATT, nullptr, M, E, b.imgE, st));
         }
         HIPCHK(ctx, launch_prefill_gemm(&wo, po, b.imgE, b.part, st));
-        HIPCHK(ctx, launch_prefill_reduce_store(b.part, po, b.X, true, st));
-        HIPCHK(ctx, launch_prefill_ximg(b.X, L.ffn_norm, M, E, b.imgE, st));
+        if (defer) {
+            HIPCHK(ctx, launch_prefill_reduce_resid_ximg(b.part, po, b.X, L.ffn_norm, b.imgE, ssq_of(i, 1), ssq_of(i, 0), st));
+        } else {
+            HIPCHK(ctx, launch_prefill_reduce_store(b.part, po, b.X, true, st));
+            HIPCHK(ctx, launch_prefill_ximg(b.X, L.ffn_norm, M, E, b.imgE, st));
+        }
         HIPCHK(ctx, launch_prefill_gemm(w13, p13, b.imgE, b.part, st));
-        HIPCHK(ctx, launch_prefill_reduce_swiglu(b.part, p13, b.imgF, st));
+        HIPCHK(ctx, launch_prefill_reduce_swiglu(b.part, p13, b.imgF, st, defer ? ssq_of(i, 1) : nullptr, defer ? ssq_of(i, 0) : nullptr));
         HIPCHK(ctx, launch_prefill_gemm(&w2, p2, b.imgF, b.part, st));
-        HIPCHK(ctx, launch_prefill_reduce_store(b.part, p2, b.X, true, st));
+        if (defer && i + 1 < nl) HIPCHK(ctx, launch_prefill_reduce_resid_ximg(b.part, p2, b.X, m->layers[i + 1].attention_norm, b.imgE, ssq_of(i + 1, 0), ssq_of(i, 1), st));
+        else HIPCHK(ctx, launch_prefill_reduce_store(b.part, p2, b.X, true, st));
     }
     return THK_OK;
 }

@@ -141,7 +141,10 @@ __device__ unsigned long long g_pf_trace[4 * 256 * 4 * 8];   // [launch index mo
 #endif
 template <int MT, int NF /* 32-row fragments per wave: 2 (256-row tile) or 1 (128-row tile) */, bool PK /* weights are tile images */, int NST = kNST>
 __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16* __restrict__ w0, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
-                                                                 const char* __restrict__ ximg, float* __restrict__ part, const PrefillPlan plan) {
+                                                                 const char* __restrict__ ximg, const int nchunks, const int per, const int rb_per_mat, const int rb_total,
+                                                                 const int R, const int C, float* __restrict__ part, const PrefillPlan plan) {
+    // the ten leading scalars are everything the prologue needs before its first load: they arrive preloaded in SGPRs
+    // (-amdgpu-kernarg-preload-count, see gemv_kernel in thk_kernels.hip); the rest of the plan is read when the tile is spilled
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     constexpr int XI = MT * 32 * 64 * 2;               // X image bytes per stage (hi rows, then lo rows)
     constexpr int TR = 128 * NF;                       // tile rows
@@ -152,9 +155,9 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31;
     // plain scalars (lambdas capturing the kernarg struct by reference push it to scratch)
-    const int nchunks = plan.nchunks, rb_per_mat = plan.rb_per_mat, R = plan.R, C = plan.C, maxseg = plan.maxseg, per = plan.per;
+    const int maxseg = plan.maxseg;
     const size_t slot_floats = plan.slot_floats;
-    const int total = plan.rb_total * nchunks;          // <= a few 10^4
+    const int total = rb_total * nchunks;               // <= a few 10^4
     const int g0 = blockIdx.x * per;
     const int g1 = g0 + per < total ? g0 + per : total;
     if (g0 >= g1) return;
@@ -370,21 +373,49 @@ __device__ __forceinline__ void ximg_store8(char* img, int MT, int tok, int col,
     *reinterpret_cast<h8*>(img + ximg_off(MT, 0, tok, col)) = hi;
     *reinterpret_cast<h8*>(img + ximg_off(MT, 1, tok, col)) = lo;
 }
-// one workgroup per token row (pad rows are written as zeros).  NORM: v = (x * rsqrt(mean(x^2)+eps)) * gain  (K4+K5)
-template <bool NORM>
-__global__ __launch_bounds__(256) void ximg_from_rows_kernel(const float* __restrict__ X, const float* __restrict__ gain, int M, int MT, int C, char* __restrict__ img) {
+// Deferred RMSNorm (round 4).  x -> (x * inv) * g -> W is computed as inv * (W (x * g)): the per-token scalar inv = 1/sqrt(mean
+// x^2 + eps) moves to the OUTPUT side of the GEMM, so the kernel that produces x (a reducer with the residual add) can write the
+// hi/lo image of x * g itself - it does not have to know the whole row's sum of squares, which lives in other workgroups - and
+// the norm -> image launch between two GEMMs disappears.  The sum of squares travels as 64-bit FIXED POINT (2^-24 units): every
+// producer workgroup adds its share with an integer atomic, so the total does not depend on the order of arrival (bit-repeatable
+// results, no float atomics), and the consuming reducer reads one word per token.
+// The image still has to hold O(1) values: the lo half of the hi/lo split is an f16 too, and for |v| below ~0.1 it falls into
+// f16's subnormals (a residual stream of magnitude 0.02 - the embedding scale - lost a factor 4 of accuracy that way).  So the
+// producer multiplies by a POWER OF TWO near the token's 1/rms - exact, no rounding - taken from a sum of squares it CAN know:
+// the token's previous norm input (the residual stream moves slowly), or the row's own for the first layer; the consumer divides
+// it out again (it reads the same word and derives the same power of two).
+constexpr float kSsqScale = 16777216.f;      // 2^24
+__device__ __forceinline__ unsigned long long ssq_fixed(float ss) { return (unsigned long long)__float2ull_rn(ss * kSsqScale); }
+__device__ __forceinline__ void ssq_add(unsigned long long* ssq, int tok, float ss) { atomicAdd(ssq + tok, ssq_fixed(ss)); }
+__device__ __forceinline__ float ssq_inv_of(unsigned long long v, int C) {
+    const float ss = (float)((double)v * (1.0 / 16777216.0));
+    return 1.0f / sqrtf(ss / (float)C + 1e-6f);
+}
+__device__ __forceinline__ float ssq_inv(const unsigned long long* ssq, int tok, int C) { return ssq_inv_of(ssq[tok], C); }
+__device__ __forceinline__ float pow2_below(float v) { return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & 0x7F800000u); }   // v > 0, normal
+__device__ __forceinline__ float ssq_pow2(const unsigned long long* ssq, int tok, int C) { return pow2_below(ssq_inv(ssq, tok, C)); }
+// one workgroup per token row (pad rows are written as zeros).  MODE 1: v = (x * rsqrt(mean(x^2)+eps)) * gain  (K4+K5);
+// MODE 2: v = x * 2^k * gain with 2^k <= 1/rms < 2^(k+1), the row's sum of squares goes to ssq[tok] (deferred norm; ssq[tok] must be zero)
+template <int MODE>
+__global__ __launch_bounds__(256) void ximg_from_rows_kernel(const float* __restrict__ X, const float* __restrict__ gain, int M, int MT, int C, char* __restrict__ img,
+                                                             unsigned long long* __restrict__ ssq) {
+    constexpr bool NORM = MODE == 1;
     __shared__ float red[4];
     const int tok = blockIdx.x;
     const float* row = X + (size_t)tok * C;
     float inv = 1.f;
-    if (NORM) {
+    if (MODE != 0) {
         float ss = 0.f;
         if (tok < M) for (int i = threadIdx.x; i < C; i += 256) ss += row[i] * row[i];
         ss = wave_sum_prefill(ss);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
         __syncthreads();
         ss = (red[0] + red[1]) + (red[2] + red[3]);
-        inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
+        if (NORM) inv = 1.0f / sqrtf(ss / (float)C + 1e-6f);
+        else {
+            inv = pow2_below(ssq_inv_of(ssq_fixed(ss), C));      // what the consumer derives from the word written below
+            if (threadIdx.x == 0 && tok < M) ssq_add(ssq, tok, ss);
+        }
     }
     for (int col = threadIdx.x * 8; col < C; col += 256 * 8) {
         float v[8];
@@ -394,7 +425,7 @@ __global__ __launch_bounds__(256) void ximg_from_rows_kernel(const float* __rest
             const f4 x0 = *reinterpret_cast<const f4*>(row + col), x1 = *reinterpret_cast<const f4*>(row + col + 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
-            if (NORM) {
+            if (MODE != 0) {
                 const f4 g0 = *reinterpret_cast<const f4*>(gain + col), g1 = *reinterpret_cast<const f4*>(gain + col + 4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = (v[e] * inv) * g0[e]; v[4 + e] = (v[4 + e] * inv) * g1[e]; }
@@ -444,15 +475,58 @@ __global__ __launch_bounds__(256) void reduce_store_kernel(const float* __restri
     if (mode == 1) s = *dst + s;
     *dst = s;
 }
+// x = X + sum (residual, K11) -> X, and straight on to the NEXT GEMM's operand: the hi/lo image of x * gain (deferred norm, see
+// ximg_from_rows_kernel) and this workgroup's share of every token's sum of squares.  A workgroup = 256 consecutive q = one
+// (token tile, 32-row fragment): 32 tokens x 8 threads, each with 4 rows.  Replaces reduce_store + norm -> image (two launches).
+__global__ __launch_bounds__(256) void reduce_resid_ximg_kernel(const float* __restrict__ part, PrefillPlan p, float* __restrict__ X, const float* __restrict__ gain,
+                                                                char* __restrict__ img, unsigned long long* __restrict__ ssq, const unsigned long long* __restrict__ ssq_scale) {
+    __shared__ float red[4][32];
+    const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;
+    const FragPos fp = frag_decode(q, p.MT);
+    const int r = rbk * p.tile_rows + fp.row, tok = fp.tok;
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 hi = h4{0, 0, 0, 0}, lo = h4{0, 0, 0, 0};
+    float ss = 0.f;
+    const bool live = tok < p.M && r < p.R;
+    if (live) {
+        f4* dst = reinterpret_cast<f4*>(X + (size_t)tok * p.R + r);
+        const f4 x = *dst + sum_partials(part, p, rbk, q);
+        *dst = x;
+        const f4 g = *reinterpret_cast<const f4*>(gain + r);
+        const float sc = ssq_pow2(ssq_scale, tok, p.R);          // power of two near this token's 1/rms (from its previous norm input)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = (x[e] * sc) * g[e];
+            hi[e] = (_Float16)v; lo[e] = (_Float16)(v - (float)hi[e]);
+            ss += x[e] * x[e];
+        }
+    }
+    if (r < p.R) {                                  // pad tokens of the image are zeros
+        const size_t sub = (size_t)(r & 4) * 2;     // second half of the 16-byte piece
+        *reinterpret_cast<h4*>(img + ximg_off(p.MT, 0, tok, r) + sub) = hi;
+        *reinterpret_cast<h4*>(img + ximg_off(p.MT, 1, tok, r) + sub) = lo;
+    }
+    // the token's 32 rows of this workgroup: lanes l, l + 32 (row halves), then the four waves (g)
+    ss += __shfl_xor(ss, 32, 64);
+    if ((threadIdx.x & 63) < 32) red[threadIdx.x >> 6][threadIdx.x & 31] = ss;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const int t2 = fp.tok;                      // thread l < 32: lane l of wave 0 -> token (tile) * 32 + l
+        if (t2 < p.M) ssq_add(ssq, t2, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+    }
+}
 // q -> RoPE -> Q[tok];  k -> RoPE -> K-cache row n_past+tok;  v -> V-cache row  (K6, th-llama.cpp:318-339)
+// ssq != NULL: the GEMM ran on the un-normalised image (deferred norm): the token's 1/rms is applied here
 template <bool KVH>
 __global__ __launch_bounds__(256) void reduce_qkv_kernel(const float* __restrict__ part, PrefillPlan p, const float* __restrict__ tab, int n_past, int D,
-                                                         float* __restrict__ Q, void* __restrict__ kc, void* __restrict__ vc) {
+                                                         float* __restrict__ Q, void* __restrict__ kc, void* __restrict__ vc, const unsigned long long* __restrict__ ssq,
+                                                         const unsigned long long* __restrict__ ssq_scale) {
     const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;
     const FragPos fp = frag_decode(q, p.MT);
     const int mat = rbk / p.rb_per_mat, r = (rbk % p.rb_per_mat) * p.tile_rows + fp.row, tok = fp.tok;
     if (tok >= p.M || r >= p.R) return;
     f4 s = sum_partials(part, p, rbk, q);
+    if (ssq) s = s * (ssq_inv(ssq, tok, p.C) / ssq_pow2(ssq_scale, tok, p.C));      // the division by a power of two is exact
     const int pos = n_past + tok;
     if (mat < 2) {
         const int half = D >> 1, jp = (r % D) >> 1;
@@ -469,7 +543,8 @@ __global__ __launch_bounds__(256) void reduce_qkv_kernel(const float* __restrict
 }
 // hidden = silu(w1 x) * (w3 x)  (K10, K11) written straight into the X image of the w2 GEMM (C = R of this plan);
 // a thread owns 4 columns = half of a 16-byte image piece
-__global__ __launch_bounds__(256) void reduce_swiglu_ximg_kernel(const float* __restrict__ part, PrefillPlan p, char* __restrict__ img) {
+__global__ __launch_bounds__(256) void reduce_swiglu_ximg_kernel(const float* __restrict__ part, PrefillPlan p, char* __restrict__ img, const unsigned long long* __restrict__ ssq,
+                                                                 const unsigned long long* __restrict__ ssq_scale) {
     const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;     // rbk < rb_per_mat: w1's tile; w3's is rbk + rb_per_mat
     const FragPos fp = frag_decode(q, p.MT);
     const int r = rbk * p.tile_rows + fp.row, tok = fp.tok;
@@ -477,7 +552,8 @@ __global__ __launch_bounds__(256) void reduce_swiglu_ximg_kernel(const float* __
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 hi = h4{0, 0, 0, 0}, lo = h4{0, 0, 0, 0};
     if (tok < p.M) {
-        const f4 u1 = sum_partials(part, p, rbk, q), u3 = sum_partials(part, p, rbk + p.rb_per_mat, q);
+        f4 u1 = sum_partials(part, p, rbk, q), u3 = sum_partials(part, p, rbk + p.rb_per_mat, q);
+        if (ssq) { const float inv = ssq_inv(ssq, tok, p.C) / ssq_pow2(ssq_scale, tok, p.C); u1 = u1 * inv; u3 = u3 * inv; }    // deferred norm
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float sl = u1[e] / (1.0f + expf(-u1[e])), v = sl * u3[e];
@@ -494,11 +570,18 @@ extern "C" __attribute__((visibility("default"))) int thk_debug_prefill_trace(un
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pf_trace), sizeof(unsigned long long) * 4 * 256 * 4 * 8);
 }
 #endif
-hipError_t launch_prefill_ximg(const float* X, const float* gain, int M, int C, void* ximg, hipStream_t st) {
+hipError_t launch_prefill_ximg(const float* X, const float* gain, int M, int C, void* ximg, hipStream_t st, unsigned long long* ssq) {
     const int MT = (M + 31) / 32;
-    if (M < 1 || M > 128 || C % kKC != 0) return hipErrorInvalidValue;
-    if (gain) hipLaunchKernelGGL(ximg_from_rows_kernel<true>, dim3(MT * 32), dim3(256), 0, st, X, gain, M, MT, C, (char*)ximg);
-    else hipLaunchKernelGGL(ximg_from_rows_kernel<false>, dim3(MT * 32), dim3(256), 0, st, X, gain, M, MT, C, (char*)ximg);
+    if (M < 1 || M > 128 || C % kKC != 0 || (ssq && !gain)) return hipErrorInvalidValue;
+    if (gain && ssq) hipLaunchKernelGGL(ximg_from_rows_kernel<2>, dim3(MT * 32), dim3(256), 0, st, X, gain, M, MT, C, (char*)ximg, ssq);
+    else if (gain) hipLaunchKernelGGL(ximg_from_rows_kernel<1>, dim3(MT * 32), dim3(256), 0, st, X, gain, M, MT, C, (char*)ximg, ssq);
+    else hipLaunchKernelGGL(ximg_from_rows_kernel<0>, dim3(MT * 32), dim3(256), 0, st, X, gain, M, MT, C, (char*)ximg, ssq);
+    return hipGetLastError();
+}
+hipError_t launch_prefill_reduce_resid_ximg(const float* part, const PrefillPlan& p, float* X, const float* gain, void* ximg, unsigned long long* ssq,
+                                            const unsigned long long* ssq_scale, hipStream_t st) {
+    if (!gain || !ximg || !ssq || !ssq_scale || p.R % kKC != 0) return hipErrorInvalidValue;      // the output row count is the next GEMM's column count
+    hipLaunchKernelGGL(reduce_resid_ximg_kernel, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, X, gain, (char*)ximg, ssq, ssq_scale);
     return hipGetLastError();
 }
 hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& plan_in, const void* ximg, float* part, hipStream_t st) {
@@ -517,7 +600,8 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& plan
         static bool attr_done[kMaxDevices] = {};     /* the attribute is per device */                                   \
         const int dev = current_device();                                                                                \
         if (!attr_done[dev]) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3_kernel<MTV, NFV, PKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[dev] = (e == hipSuccess); } \
-        if (e == hipSuccess) hipLaunchKernelGGL((gemm_prefill_v3_kernel<MTV, NFV, PKV>), dim3(p.G), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, part, p); \
+        if (e == hipSuccess) hipLaunchKernelGGL((gemm_prefill_v3_kernel<MTV, NFV, PKV>), dim3(p.G), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, \
+                                                p.nchunks, p.per, p.rb_per_mat, p.rb_total, p.R, p.C, part, p); \
     }
 #define THK_V3(MTV, NFV) { if (p.packed & 1) THK_V3K(MTV, NFV, true) else THK_V3K(MTV, NFV, false) }
     if (p.tile_rows == 128) switch (p.MT) {
@@ -539,13 +623,16 @@ hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, 
     hipLaunchKernelGGL(reduce_store_kernel, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, Y, residual ? 1 : 0);
     return hipGetLastError();
 }
-hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, void* kcache, void* vcache, bool kv_f16, hipStream_t st) {
-    if (kv_f16) hipLaunchKernelGGL(reduce_qkv_kernel<true>, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache);
-    else hipLaunchKernelGGL(reduce_qkv_kernel<false>, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache);
+hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, const float* rope_tab, int n_past, int D, float* Q, void* kcache, void* vcache, bool kv_f16, hipStream_t st,
+                                     const unsigned long long* ssq, const unsigned long long* ssq_scale) {
+    if (ssq && !ssq_scale) return hipErrorInvalidValue;
+    if (kv_f16) hipLaunchKernelGGL(reduce_qkv_kernel<true>, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache, ssq, ssq_scale);
+    else hipLaunchKernelGGL(reduce_qkv_kernel<false>, dim3(p.MT * p.tile_rows / 32, p.rb_total), dim3(256), 0, st, part, p, rope_tab, n_past, D, Q, kcache, vcache, ssq, ssq_scale);
     return hipGetLastError();
 }
-hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_swiglu_ximg_kernel, dim3(p.MT * p.tile_rows / 32, p.rb_per_mat), dim3(256), 0, st, part, p, (char*)ximg_out);
+hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st, const unsigned long long* ssq, const unsigned long long* ssq_scale) {
+    if (ssq && !ssq_scale) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(reduce_swiglu_ximg_kernel, dim3(p.MT * p.tile_rows / 32, p.rb_per_mat), dim3(256), 0, st, part, p, (char*)ximg_out, ssq, ssq_scale);
     return hipGetLastError();
 }
 
