@@ -414,6 +414,35 @@ def test_context_beyond_512(thk, orc, ctx):
     m.close()
 
 
+@pytest.mark.parametrize("dims", [(512, 8, 2), (4096, 32, 2)], ids=["tiny-width", "7B-width"])
+def test_prefill_deferred_norm_equals_explicit_norm(thk, orc, ctx, dims):
+    """The 9-launch layer (RMSNorm's 1/rms applied on the output side of the GEMM, the residual reducers write the next image and
+    the fixed-point sum of squares) against the 11-launch layer with its norm -> image launches (prefill_deferred_norm = 0) and
+    against the oracle fed token by token: small-magnitude residual streams (embedding scale 0.02) are exactly where an
+    un-prescaled image would lose the lo half of the hi/lo split to f16 subnormals."""
+    E, H, L = dims
+    shape = thk.ModelShape(n_vocab=2048, n_embd=E, n_mult=256, n_head=H, n_layer=L, n_ctx=256)
+    oshape = orc.ModelShape(n_vocab=2048, n_embd=E, n_mult=256, n_head=H, n_layer=L, n_ctx=256)
+    m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    om = orc.OracleModel(oshape); om.fill_synthetic()
+    rng = np.random.default_rng(E)
+    toks = np.concatenate([[1], rng.integers(3, 2048, 150)]).astype(np.int32)
+    for i in range(150):
+        lo, _ = om.eval(int(toks[i]), i, flags=0)
+    out = {}
+    old = ctx.get_tunable("prefill_deferred_norm")
+    try:
+        for d in (1, 0):
+            ctx.set_tunable("prefill_deferred_norm", d)      # read per prefill call
+            m.reset_kv(0)
+            out[d] = m.prefill(toks[:150], 0)                 # two slabs: 128 + 22 tokens
+    finally:
+        ctx.set_tunable("prefill_deferred_norm", old)
+    assert np.abs(out[1] - lo).max() < 1e-4 and np.abs(out[0] - lo).max() < 1e-4
+    assert np.abs(out[1] - out[0]).max() < 5e-5 and int(out[1].argmax()) == int(out[0].argmax()) == orc.greedy(lo)
+    m.close(); om.close()
+
+
 @pytest.mark.parametrize("M", [20, 128, 300])
 def test_prefill_is_bitwise_repeatable(thk, ctx, M):
     """Race screen for the hand-synchronised LDS-DMA pipeline (counted vmcnt + raw barriers) and the stream-K

@@ -138,7 +138,7 @@ def test_driver_with_native_transport_single_rank_ring(thk, orc):
     stage.model.close(); ctx.close()
 
 
-@pytest.mark.parametrize("transport", ["native", "torch", "peer"])
+@pytest.mark.parametrize("transport", ["auto", "native", "torch", "peer"])
 def test_bench_pipeline_path_end_to_end_on_one_gpu(transport):
     """`bench.py --force-pipeline --model tiny`: the N>1 code path of the benchmark itself (process group on RCCL, HipStage, ring
     kept full across prime / steady / drain, stage timing, JSON line) runs end to end with one rank and a self send/recv, and the
@@ -150,7 +150,7 @@ def test_bench_pipeline_path_end_to_end_on_one_gpu(transport):
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
-    env["MASTER_PORT"] = str(29800 + os.getpid() % 150 + {"native": 0, "torch": 1, "peer": 2}[transport])
+    env["MASTER_PORT"] = str(29800 + os.getpid() % 150 + {"native": 0, "torch": 1, "peer": 2, "auto": 3}[transport])
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-pipeline", "--model", "tiny", "--steps", "6", "--warmup", "2",
                         "--transport", transport, "--no-cpu-baseline", "--no-kernel-profile"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -158,7 +158,14 @@ def test_bench_pipeline_path_end_to_end_on_one_gpu(transport):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["ranks_joined"] == 1 and d["steps"] == 6 and d["value"] > 0
-    assert d["config"]["transport"] in (transport, "torch")           # native falls back to torch only if librccl cannot be bound
+    if transport == "auto":                                           # the chain native -> peer -> torch: the first that validates, with the reasons
+        assert d["config"]["transport"] in ("native", "peer", "torch") and d["handoff"]["transport_log"]
+    else:
+        assert d["config"]["transport"] == transport                 # a named transport is tried alone (the run fails if it does not validate)
+    h = d["handoff"]                                                  # the pattern round trip every boundary passed before anything was timed
+    assert h["validated"] is True and h["payloads_checked_per_rank"] == 2 and h["handoff_us"] > 0 and len(h["handoff_us_per_rank"]) == 1
+    ls = d["layer_split"]
+    assert ls["used"] == ls["uniform"] == ls["balanced"] == [[0, 2]] and 0 < ls["bound_uniform"] <= 1.0
     for key in ("single_stream", "stage_ms_no_handoff", "ideal_pipeline_tokens_per_s", "pure_replica_upper_bound_tokens_per_s",
                 "ideal_efficiency_bound", "timed_region"):
         assert key in d, key

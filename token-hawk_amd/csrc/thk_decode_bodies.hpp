@@ -553,15 +553,16 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
 // WAVES waves per block share one (head, split): more waves = fewer positions per wave, so every wave needs a single load batch
 // (one HBM round trip) at T = 512 with 4 splits.
 //
-// VS == 2 (round 4): 7B has H * nsplit = 128 (head, split) pairs and the chip has 256 CUs; a CU that pulls a split's 128 KB alone
-// is what bounds the launch.  Doubling the splits doubles the partials every wo workgroup reads (measured -2 %).
-// Instead TWO workgroups share a (head, split): both read its K slice and compute the same scores (bit-identical: same
-// instructions on the same data), each takes half of the V columns and writes half of o with the identical (m, l) - 96 KB per CU
-// on 256 CUs and the consumer's prologue (ProAttn) reads exactly what it read before.  The pair is workgroups b and b + 8 of a
-// group of 16: workgroup i runs on XCD i % 8, so the pair shares an L2 and the second K read is an L2 hit (or merges with the
-// first in flight).  V lanes: D/(4 VS) lanes cover a position's half slice, PPW * VS positions per wave-instruction, UB / VS
-// instructions.  The position a lane takes in V instruction u' is the one its own K lane group handled in K instruction
-// VS*u' + (its V lane group & 1), so the softmax weight is already in the lane's registers (a select, no shuffle).
+// VS == 2 (round 4, an OPTION: tunable attn_vsplit): 7B has H * nsplit = 128 (head, split) pairs and the chip has 256 CUs.  Doubling
+// the splits doubles the partials every wo workgroup reads (measured -2 %); instead TWO workgroups share a (head, split): both read
+// its K slice and compute the same scores (bit-identical: same instructions on the same data), each takes half of the V columns
+// and writes half of o with the identical (m, l) - 96 KB per CU on 256 CUs and the consumer's prologue (ProAttn) reads exactly what
+// it read before.  The pair is workgroups b and b + 8 of a group of 16: workgroup i runs on XCD i % 8, so the pair shares an L2.
+// V lanes: D/(4 VS) lanes cover a position's half slice, PPW * VS positions per wave-instruction, UB / VS instructions.  The
+// position a lane takes in V instruction u' is the one its own K lane group handled in K instruction VS*u' + (its V lane group
+// & 1), so the softmax weight is already in the lane's registers (a bit-mask blend, no shuffle).
+// MEASURED: no gain at T = 512 (5.13 vs 5.07 us span) and 50 % slower at T = 2048 - the launch is a chain of dependent round trips
+// (position -> K/V batch -> softmax -> LDS merge), not bound by what one CU pulls - so VS = 1 is the default.
 //
 // tc_dyn (round 4): tc follows the LIVE context, tc = ceil(T / nsplit) rounded up to the wave batch (PPW * UB positions), computed
 // here from the device-resident position - every (head, split) has work at every T >= nsplit * PPW * UB instead of the splits
