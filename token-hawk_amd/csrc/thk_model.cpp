@@ -553,6 +553,10 @@ static int ensure_multi_graph(thk_model* m, int seq, int n) {
     if ((int)sb.multi.size() >= kMaxMultiGraphs) {
         auto victim = sb.multi.begin();
         for (auto it = sb.multi.begin(); it != sb.multi.end(); ++it) if (sb.multi_used[it->first] < sb.multi_used[victim->first]) victim = it;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) {   // a replay of the victim may still be in flight (rare path: a 7th distinct step count)
+            hipGraphExecDestroy(x); hipGraphDestroy(g);
+            return fail(ctx, THK_ERR_HIP, "hipStreamSynchronize before evicting a %d-step graph failed", victim->first);
+        }
         hipGraphExecDestroy(victim->second.second); hipGraphDestroy(victim->second.first);
         sb.multi_used.erase(victim->first); sb.multi.erase(victim);
     }
