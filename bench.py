@@ -64,6 +64,10 @@ def parse():
     p.add_argument("--balance", action="store_true",
                    help="N>1: size the stages with pipeline.balanced_layer_split() from the byte-based stage cost model (the lm-head rank may carry "
                         "fewer layers) instead of the uniform 32/16/8/4 split BASELINE.md names; the line reports both splits and their bounds either way")
+    p.add_argument("--ranks-share-gpu", action="store_true",
+                   help="PLUMBING CHECK on a one-GPU box: all N ranks use cuda:0 and the process group runs over gloo (RCCL cannot place two ranks on "
+                        "one GPU), so the whole N>1 flow - stage models, transport choice with the hand-off pattern check (peer | torch), ring, "
+                        "timing protocol, JSON line - runs with real HipStages in N processes; the line is marked and its value is not a scaling number")
     p.add_argument("--watchdog-s", type=float, default=900.0,
                    help="N>1: a rank whose warm-up + timed region + drain does not finish in this many seconds reports and exits 3 (a dead peer must not hang the node)")
     p.add_argument("--kv", default="f32", choices=["f32", "f16"],
@@ -83,6 +87,8 @@ def self_launch(args):
     import subprocess
     import torch
     have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if args.ranks_share_gpu and have >= 1:
+        have = args.gpus
     if have < args.gpus and not args.stub_stage:
         log(f"[bench] ERROR: --gpus {args.gpus} requested but only {have} GPU(s) are visible; refusing to run on fewer ranks")
         return 2
@@ -329,16 +335,20 @@ def stage_cost_model_us(shape, T):
     return layer, head
 
 
-def choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, log_lines):
+def choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, log_lines, ctl=None):
     """Set up and VALIDATE the hand-off transport on every rank together: `auto` walks native (thk_pp_*, RCCL) -> peer (thk_peer_*,
     IPC mailboxes) -> torch (torch.distributed P2P ops) and keeps the first one that sets up everywhere and passes
     PipelineDriver.validate_handoff(); a named transport is tried alone.  Returns the HandoffReport (args.transport = the choice)
     or None.  Every decision is all-reduced (MIN) so the ranks never disagree; the reasons go to log_lines."""
     import ctypes as C
     order = ["native", "peer", "torch"] if args.transport == "auto" else [args.transport]
+    if getattr(args, "ranks_share_gpu", False):
+        order = ["peer"]      # RCCL cannot place two ranks on one GPU, and gloo's point-to-point ops take host tensors only
+
+    ctl = dev if ctl is None else ctl
 
     def agree(ok):
-        flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+        flag = torch.tensor([1 if ok else 0], device=ctl, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return int(flag.item()) == 1
 
@@ -522,6 +532,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.ranks_share_gpu:
+        local_rank = 0                            # every rank on cuda:0 (plumbing check)
     if args.stub_stage and world == args.gpus:
         return main_stub(args, json_fd)
     if world != args.gpus:
@@ -530,7 +542,7 @@ def main():
     N = world
     PIPE = N > 1 or args.force_pipeline          # pipeline driver path
     if not os.path.exists(graft.LIB):          # the prebuilt .so travels with the tree; never rebuild concurrently from N ranks
-        if local_rank == 0:
+        if (rank if args.ranks_share_gpu else local_rank) == 0:
             graft.build_libthk()
         else:
             while not os.path.exists(graft.LIB):
@@ -549,8 +561,12 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
+        if args.ranks_share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=N)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=N, device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
+    ctl = torch.device("cpu") if args.ranks_share_gpu else dev      # where the control collectives' tensors live (gloo: host)
     stream = torch.cuda.Stream(device=dev)       # libthk and the RCCL P2P ops share this stream's ordering
     with torch.cuda.stream(stream):
         ctx = thk.Context(local_rank, stream=stream.cuda_stream)
@@ -580,7 +596,7 @@ def main():
             model = stage.model
             drv = PipelineDriver(stage, rank, N, S, force_ring=(N == 1))
             transport_log = []
-            handoff = choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, transport_log)
+            handoff = choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, transport_log, ctl)
             if handoff is None:
                 if rank == 0:
                     log("[bench] ERROR: no transport passed the hand-off check: " + "; ".join(transport_log))
@@ -637,7 +653,7 @@ def main():
         elapsed = time.perf_counter() - t0
         ev_ms = ev0.elapsed_time(ev1)
         if dist is not None:
-            tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            tmax = torch.tensor([elapsed], device=ctl, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
 
@@ -661,7 +677,7 @@ def main():
         joined = 1
         stage_ms = None
         if dist is not None:
-            one = torch.ones(1, device=dev, dtype=torch.int32)
+            one = torch.ones(1, device=ctl, dtype=torch.int32)
             dist.all_reduce(one)                                   # ranks that really took part in the timed region
             joined = int(one.item())
             # this stage alone (no hand-off), for the ideal-pipeline and pure-replica bounds reported next to the measurement
@@ -670,7 +686,7 @@ def main():
             for _ in range(8):
                 stage.step(0, False)
             torch.cuda.synchronize(dev)
-            st_ms = torch.tensor([(time.perf_counter() - ts0) / 8 * 1e3], device=dev, dtype=torch.float64)
+            st_ms = torch.tensor([(time.perf_counter() - ts0) / 8 * 1e3], device=ctl, dtype=torch.float64)
             allst = [torch.zeros_like(st_ms) for _ in range(N)]
             dist.all_gather(allst, st_ms)
             stage_ms = [round(float(t.item()), 4) for t in allst]
@@ -684,7 +700,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (seeded Irwin-Hall~N(0,0.02^2) f16 weights, seeded prompt ids)",
             "config": {"workload": f"LLaMA-{args.model.upper()} f16, {T}-ctx single-token greedy decode (n_past={T - 1}), "
-                                   f"{'1 sequence' if N == 1 else f'{S} sequences in flight, layers pipelined over {N} GPUs (RCCL p2p)'}",
+                                   f"{'1 sequence' if N == 1 else f'{S} sequences in flight, layers pipelined over {N} GPUs (point-to-point hand-off of the hidden state, transport: see config.transport)'}",
                        "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single", "transport": args.transport if PIPE else None,
                        "lmhead_mode": args.lmhead, "numerics": "f16 GGML weights x f32 activations, f32 accumulate, " + ("f32 KV cache (as the reference)" if kv_bytes == 4 else "binary16 KV cache (OPTION, not the reference's: s_kv = 2 in bytes/token)"),
                        "decode_path": "persistent engine (1 launch/step)" if model.uses_engine() else "5 fused launches per layer + lm-head (greedy pick folded in), kernel arguments preloaded into SGPRs, hipGraph replay (n-step graphs, n <= 32: 20 steps = one graph)",
@@ -706,9 +722,11 @@ def main():
                 # the lm-head, rank 0 the embedding fetch) bounds the ring
                 result["ideal_efficiency_bound"] = round(sum(stage_ms) / (N * max(stage_ms)), 4)
             result["timed_region"] = "steady ring: prime() before the warm-up, steps * S micro-steps timed, drain() after (no fill/drain inside)"
+            if args.ranks_share_gpu:
+                result["plumbing_check"] = f"{N} ranks share cuda:0 over gloo: the N>1 flow with real stages, NOT a scaling measurement"
             # the hand-off, validated before anything was timed: known patterns through every (sequence, kind) slot of the chosen
             # transport on every boundary, then bare ring hand-offs timed with no compute between them
-            hmax = torch.tensor([handoff.handoff_us], device=dev, dtype=torch.float64)
+            hmax = torch.tensor([handoff.handoff_us], device=ctl, dtype=torch.float64)
             allh = [torch.zeros_like(hmax) for _ in range(N)]
             dist.all_gather(allh, hmax)
             result["handoff"] = {"validated": True, "payloads_checked_per_rank": handoff.checked, "handoff_us": round(max(float(t.item()) for t in allh), 2),

@@ -203,6 +203,33 @@ def test_driver_with_peer_mailbox_transport_single_rank_ring(thk, orc):
     stage.model.close(); ctx.close()
 
 
+def test_bench_two_ranks_share_one_gpu():
+    """`bench.py --gpus 2 --ranks-share-gpu`: the benchmark's whole N = 2 flow with REAL stages in two processes (self-launch through
+    torch.distributed.run, two HipStages of the tiny model on cuda:0, process group over gloo, transport chosen by the hand-off
+    pattern check = IPC mailboxes, prime / steady / drain, MAX over ranks, stage times gathered, one JSON line) - everything the
+    first multi-GPU run does except the hop across xGMI."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--ranks-share-gpu", "--model", "tiny", "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-kernel-profile", "--master-port", str(29650 + os.getpid() % 200)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["steps"] == 6 and d["value"] > 0 and "plumbing_check" in d
+    assert d["config"]["transport"] == "peer" and d["config"]["sequences"] == 2
+    h = d["handoff"]
+    assert h["validated"] is True and h["payloads_checked_per_rank"] == 4 and len(h["handoff_us_per_rank"]) == 2
+    ls = d["layer_split"]
+    assert ls["used"] == [[0, 1], [1, 2]] and "measured" in ls and len(d["stage_ms_no_handoff"]) == 2
+
+
 def test_peer_timeout_is_sticky(thk):
     """A hand-off that never arrives: the bounded wait (~2 s) raises the error word instead of hanging the GPU, thk_peer_check
     reports it - and keeps reporting it - every later send / recv is refused (the flag sequence is out of step from then on), a
