@@ -1,7 +1,8 @@
 // thk_internal.hpp — shared by the host-side translation units that implement include/thk.h:
 //   thk_ctx.cpp            context, tunables, buffers (TensorBuffer's GPU half, th.cpp:150-229)
 //   thk_ops.cpp            one operator per reference kernel (the 16 cmdbuf_* encoders, th.cpp:617-4351)
-//   thk_model.cpp          model level: th_eval_gpu (th-llama.cpp:464-660) as hipGraph replays, per-sequence state, pipeline stages
+//   thk_model.cpp          model level: objects, tensors, finalize, thk_model_eval, sequence accessors
+//   thk_model_step.cpp     the decode step (th_eval_gpu's body, th-llama.cpp:464-660) as hipGraph replays, step-level API
 //   thk_model_prefill.cpp  MFMA prompt prefill; thk_model_engine.cpp  the optional one-launch engine's program
 //   thk_pp.cpp / thk_peer.hip  stage-to-stage transports
 // Internal; not part of the ABI.
@@ -132,6 +133,9 @@ static inline float* vcache_of(const thk_model* m, const SeqBuf& sb, int i) {
 }
 
 int set_seq_state(thk_model* m, int seq, int token, int pos, bool reset_gen);   // thk_model.cpp
+int step_enqueue(thk_model* m, int seq);                                        // thk_model_step.cpp: one decode step on the ctx stream (eager or under capture)
+int step_run(thk_model* m, int seq);                                            //   ... as a replay of the sequence's one-step graph when graphs are on
+int step_set_advance(thk_model* m, int seq, int advance);                       //   the device-resident "advance the position" flag
 bool engine_plan(thk_model* m);                                                 // thk_model_engine.cpp
 int engine_build_program(thk_model* m, SeqBuf& sb);
 int check_engine_error(thk_model* m);

@@ -81,7 +81,6 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             t.q = m->q; t.kcache = kc; t.vcache = vc; t.pos_ptr = &sb.st->pos; t.H = H; t.D = D; t.nsplit = m->nsplit; t.tc = m->tc;
             t.tc_dyn = m->attn_tc_dyn; t.vsplit = m->attn_vsplit;
             t.pipe = (T + m->nsplit - 1) / m->nsplit > m->attn_waves * (64 / (D / 4)) * 8;      // a split of the full cache is longer than one round
-            t.spec = m->attn_spec && !m->attn_tc_dyn && !t.pipe && T % m->nsplit == 0;
             t.scale = 1.0f / sqrtf((float)D); t.waves = m->attn_waves; t.kv_f16 = m->kv_f16;
             t.out = m->nsplit == 1 ? m->attn_out : nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml;
             GemvArgs a{};
