@@ -20,9 +20,18 @@ static int slab_plans(thk_model* m, int M, PrefillPlan out[4]) {
     static const char* const kind[4] = {"qkv", "wo", "w13", "w2"};
     const int R[4] = {E, E, F, E}, nmat[4] = {3, 1, 2, 1}, C[4] = {E, E, E, F};
     for (int k = 0; k < 4; ++k) {
-        const int g = (int)tun(ctx, (std::string("prefill_blocks_") + kind[k]).c_str());
+        int g = (int)tun(ctx, (std::string("prefill_blocks_") + kind[k]).c_str());
         const int t = (int)tun(ctx, (std::string("prefill_tile_") + kind[k]).c_str());
-        REQUIRE(ctx, g >= 1 && g <= 256, "prefill_blocks_* tunables must be in [1, 256]");
+        REQUIRE(ctx, g >= 0 && g <= 256, "prefill_blocks_* tunables must be in [0 (auto), 256]");
+        if (g == 0) {
+            // auto (round 4): stream-K shares that do not straddle row-blocks - w workgroups per row-block with w | chunks per
+            // row-block - spill one partial tile per workgroup instead of 1.3, but only if that keeps >= 192 of the 256 CUs busy
+            // (7B wq|wk|wv: 48 row-blocks x 4 = 192 workgroups: -1.5 % prefill time; w1|w3: 86 x 2 = 172 measured slower than 256)
+            const PrefillPlan probe = prefill_plan(M, R[k], nmat[k], C[k], 256, t);
+            g = 256;
+            for (int w = 256 / probe.rb_total; w >= 1; --w)
+                if (probe.nchunks % w == 0 && probe.rb_total * w >= 192) { g = probe.rb_total * w; break; }
+        }
         out[k] = prefill_plan(M, R[k], nmat[k], C[k], g, t);
     }
     return THK_OK;
