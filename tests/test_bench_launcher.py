@@ -20,6 +20,25 @@ def test_launch_command_and_env_for_world_2():
     assert bench.launch_env({"HSA_ENABLE_IPC_MODE_LEGACY": "1"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"   # an explicit setting wins
 
 
+def test_stage_cost_model_keeps_the_baseline_split():
+    """bench.py's byte-based stage cost model (layer = its weight + KV bytes at 6.8 TB/s + 5 launches x 3.1 us; lm-head likewise) fed
+    to pipeline.balanced_layer_split: for LLaMA-7B and 13B the lm-head costs about half a layer, so the uniform 32/16/8/4 split
+    BASELINE.md names is the optimum at N = 2, 4, 8 - moving a layer off the last rank would make another rank the slowest."""
+    import types
+    import bench
+    import __graft_entry__ as graft
+    graft.load_package()
+    from token_hawk_amd.pipeline import balanced_layer_split, layer_range, split_efficiency_bound
+    for E, F, L in ((4096, 11008, 32), (5120, 13824, 40)):
+        shape = types.SimpleNamespace(n_embd=E, n_ff=F, n_vocab=32000, n_layer=L)
+        t_layer, t_head = bench.stage_cost_model_us(shape, 512)
+        assert 60 < t_layer < 140 and 0.35 < t_head / t_layer < 0.7
+        for N in (2, 4, 8):
+            uni = [layer_range(L, r, N) for r in range(N)]
+            assert balanced_layer_split(L, N, t_layer, t_head) == uni
+            assert 0.85 < split_efficiency_bound(uni, t_layer, t_head) < 1.0
+
+
 def run_bench(args, env_extra):
     env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     env.update(env_extra)
