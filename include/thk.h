@@ -269,8 +269,10 @@ int thk_model_seq_last_token(thk_model* m, int32_t seq, int32_t* token_out);
 /* Bytes of HBM this stage streams per decode step at context length T
  * (weights + KV read + KV write + gains; SURVEY.md §8d formula) — used by bench.py. */
 int64_t thk_model_bytes_per_token(const thk_model* m, int32_t T);
-/* Time the last `n` kernels of interest: enables per-kernel hipEvent timing of one
- * decode step outside graph replay; fills names/ms arrays (diagnostics for bench.py). */
+/* Diagnostics for bench.py: runs ONE eager (un-graphed) hold-position decode step of sequence `seq` with a HIP event between the
+ * launches and returns, per launch in issue order, its name and the milliseconds to the next event (so each figure carries the
+ * dispatch gap a graph replay does not pay).  The sequence does not advance (its advance setting is restored); at most
+ * max_entries entries are written, *n_out says how many.  No reference counterpart (the reference times whole passes). */
 int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_entries, char (*names)[48], float* ms, int32_t* n_out);
 /* Development aid; needs a library built with -DTHK_TRACE (libthk_trace.so), THK_ERR_STATE otherwise.  Runs TWO hold-position
  * decode steps as one replayed graph (ONE eager step with use_graph = 0) in which every wave of every launch stamps the 100 MHz

@@ -590,6 +590,27 @@ def test_decode_steps_refuse_to_run_past_n_ctx(thk, orc, ctx):
     m.close()
 
 
+def test_profile_step_holds_the_position(thk, ctx):
+    """thk_model_profile_step is a hold-position step whatever the sequence's advance setting was, restores that setting, and
+    is refused like any other step when the position has no cache row left - the host's position mirror stays exact."""
+    shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=16)
+    m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    m.seq_set(0, 1, 0)
+    m.decode_steps(5, 0, advance=True)                        # leaves the advance flag set
+    _, n0, p0 = m.seq_get(0)
+    prof = m.profile_step(0)
+    assert [k for k, _ in prof][:2] == ["norm_qkv_rope_kv", "attn_decode"] and all(ms >= 0 for _, ms in prof)
+    _, _, p1 = m.seq_get(0)
+    assert p1 == p0 == 5
+    m.decode_step(0, advance=True)                            # the advance setting came back
+    _, _, p2 = m.seq_get(0)
+    assert p2 == 6
+    m.decode_steps(10, 0, advance=True)                       # 6..15: the context is full, the mirror says so
+    with pytest.raises(thk.ThkError, match="n_ctx"):
+        m.decode_step(0, advance=True)
+    m.close()
+
+
 def test_prepare_steps_only_captures(thk, orc, ctx):
     """thk_model_prepare_steps builds the 8/4/2-step graphs without running anything; results equal single steps."""
     a, om = make_pair(thk, orc, ctx, "TINY")

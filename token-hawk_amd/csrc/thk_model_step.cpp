@@ -252,9 +252,15 @@ extern "C" int thk_model_profile_step(thk_model* m, int32_t seq, int32_t max_ent
     if (!m || !names || !ms || !n_out) return THK_ERR_INVALID;
     thk_ctx* ctx = m->ctx;
     REQUIRE(ctx, m->finalized && seq >= 0 && seq < m->n_seq, "bad sequence %d (or model not finalized)", seq);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = check_room(m, seq, 1, 0);
+    if (rc != THK_OK) return rc;
+    const int advance_before = m->seqs[seq].advance_host;     // a hold-position step, like thk_model_step_trace: the host's position mirror stays exact
+    if ((rc = set_advance(m, seq, 0)) != THK_OK) return rc;
     StepProf p;
-    int rc = enqueue_step(m, seq, &p);
+    rc = enqueue_step(m, seq, &p);
     if (rc == THK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "sync failed while profiling");
+    if (advance_before >= 0) { const int rc2 = set_advance(m, seq, advance_before); if (rc == THK_OK) rc = rc2; }
     int n = 0;
     if (rc == THK_OK) {
         for (size_t i = 0; i + 1 < p.events.size() && i < p.names.size() && n < max_entries; ++i, ++n) {
@@ -292,11 +298,12 @@ extern "C" int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long lon
     if ((rc = set_advance(m, seq, 0)) != THK_OK) return rc;
     StepProf p;
     p.names_only = true;
-    m->trace_on = true;
     if (m->use_graph) {      // the timeline of a step as it is normally run: a replayed graph (two steps, the SECOND one is recorded)
         hipGraph_t g = nullptr; hipGraphExec_t x = nullptr;
-        HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        m->trace_on = false;
+        if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            if (advance_before >= 0) set_advance(m, seq, advance_before);
+            return fail(ctx, THK_ERR_HIP, "hipStreamBeginCapture (trace) failed");
+        }
         rc = enqueue_step(m, seq, nullptr);
         m->trace_on = true;
         if (rc == THK_OK) rc = enqueue_step(m, seq, &p);
@@ -309,6 +316,7 @@ extern "C" int thk_model_step_trace(thk_model* m, int32_t seq, unsigned long lon
         if (x) hipGraphExecDestroy(x);
         if (g) hipGraphDestroy(g);
     } else {
+        m->trace_on = true;
         rc = enqueue_step(m, seq, &p);
         m->trace_on = false;
         if (rc == THK_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, THK_ERR_HIP, "sync failed while tracing");
