@@ -73,6 +73,9 @@ __device__ __forceinline__ int xs_store_index(int i, int ns) {
 // split in two phases so the kernel can order its memory traffic:
 //   issue()  - fire all global loads of the activation vector (L2-resident, back to back)
 //   [the kernel then fires the wave's first batch of WEIGHT loads]
+//   pin()    - the loaded activation values pass through empty asm statements (the first one clobbers "memory"): the prologue's
+//              arithmetic cannot be placed ahead of the weight requests any more (the compiler did exactly that to the split
+//              combine once its address arithmetic had become cheap: weights requested 525 instructions into the kernel)
 //   finish() - wait for the activation loads only (vmcnt counts in order, so they had to be
 //              issued first), reduce / combine, write LDS, __syncthreads()
 // => the prologue's latency and math hide under the HBM latency of the first weight batch.
@@ -89,6 +92,11 @@ struct ProCopy {
         if (NS == 0) return;
 #pragma unroll
         for (int k = 0; k < KP; ++k) v[k] = *reinterpret_cast<const f4*>(a.x + min((int)(threadIdx.x + k * BT) << 2, a.C - 4));
+    }
+    __device__ __forceinline__ void pin() {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < KP; ++k) asm volatile("" : "+v"(v[k]));
     }
     __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns, int) {
         const int C = a.C;
@@ -135,6 +143,11 @@ struct ProRms {
             v[k] = ldx(a, row, ic);
             g[k] = *reinterpret_cast<const f4*>(a.gain + ic);
         }
+    }
+    __device__ __forceinline__ void pin() {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < KP; ++k) { asm volatile("" : "+v"(v[k])); asm volatile("" : "+v"(g[k])); }
     }
     __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float* red, int ns, int bid) {
         const int C = a.C;
@@ -204,7 +217,10 @@ struct ProAttn {
     float2 ml[KP][NSP];
     f4 ov[KP][NSP];
     __device__ __forceinline__ void load1(const GemvArgs& a, int e, float2 (&m)[NSP], f4 (&o)[NSP]) {
-        const int h = e / a.D, d = e - h * a.D;
+        // element e -> (head, offset) by a multiply-high with d_magic = ceil(2^32 / D), exact for e, D < 65536 (launch_gemv sets it and
+        // checks the range; no division fallback - the compiler would compute it speculatively).  The division was ~130 instructions
+        // between the prologue's requests and a.D a scalar load to wait for: 0.5 us per launch, measured.
+        const int h = (int)__umulhi((unsigned)e, a.d_magic), d = e - h * a.D;
 #pragma unroll
         for (int s = 0; s < NSP; ++s) {
             m[s] = *reinterpret_cast<const float2*>(a.part_ml + (h * NSP + s) * 2);
@@ -215,6 +231,13 @@ struct ProAttn {
         if (NS == 0) return;
 #pragma unroll
         for (int k = 0; k < KP; ++k) load1(a, min((int)(threadIdx.x + k * BT) << 2, a.C - 4), ml[k], ov[k]);
+    }
+    __device__ __forceinline__ void pin() {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < KP; ++k)
+#pragma unroll
+            for (int s = 0; s < NSP; ++s) { asm volatile("" : "+v"(ov[k][s])); asm volatile("" : "+v"(ml[k][s].x), "+v"(ml[k][s].y)); }
     }
     __device__ __forceinline__ void finish(const GemvArgs& a, float* xs, float*, int ns, int) {
         const int C = a.C;
@@ -280,10 +303,15 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     const int half_c = C >> 1;
     const int vlast = nvec - 1;
 
+    // EPI_ROPE_KV: which of wq | wk | wv row r0 of the virtual [3E, E] stack belongs to.  Two compares instead of a division (the
+    // division sat ahead of the kernel's first weight request); the readfirstlane keeps the result opaque - once the optimiser
+    // knows it is 0, 1 or 2 it turns `which == 0 ? a.W[0] : ...` into the dynamically indexed a.W[which] and the whole argument
+    // block moves to scratch memory (seen in the ISA: 304 bytes of private segment, every member reloaded from it).
+    auto matrix_of = [&](int r0) -> int { return __builtin_amdgcn_readfirstlane((r0 >= a.E) + (r0 >= 2 * a.E)); };
     // row pointers of group g (wave-uniform; independent of the activation vector)
     auto row_ptrs = [&](int g, const h8* (&rp)[NR]) {
         if (EPI == EPI_ROPE_KV) {
-            const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E;
+            const int r0 = 2 * g, which = matrix_of(r0), rr = r0 - which * a.E;      // (no division ahead of the first weight request)
             const uint16_t* base = which == 0 ? a.W[0] : (which == 1 ? a.W[1] : a.W[2]);
             rp[0] = reinterpret_cast<const h8*>(base + (size_t)rr * C);
             rp[1 % NR] = reinterpret_cast<const h8*>(base + (size_t)(rr + 1) * C);
@@ -334,13 +362,15 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     // the next group's weights: vmcnt retires in order, so a load issued behind the refill could only be waited for by draining
     // the whole prefetch.
     struct EpiOps { float resid[NR]; float cs, sn; };
-    const int pos_pipe = (PIPE && EPI == EPI_ROPE_KV) ? (a.pos_ptr ? *a.pos_ptr : a.pos_val) : 0;
+    int pos_pipe = 0;        // PIPE && EPI_ROPE_KV: the position, read behind the first weight batch (below) - its null check is a branch that
+                             // would otherwise wait for a scalar load of a struct member before anything has been requested
+    auto head_offset = [&](int rr) -> int { return rr % a.D; };
     auto epi_fetch = [&](int g, EpiOps& eo) {
         if (EPI == EPI_RESID) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) eo.resid[r] = a.resid[min(NR * g + r, a.R - 1)];      // wave-uniform address: one request
         } else if (EPI == EPI_ROPE_KV) {
-            const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E, j = rr % a.D;
+            const int r0 = 2 * g, which = matrix_of(r0), rr = r0 - which * a.E, j = head_offset(rr);
             const float2 t = *reinterpret_cast<const float2*>(a.rope_tab + ((size_t)pos_pipe * (a.D >> 1) + (j >> 1)) * 2);
             eo.cs = t.x; eo.sn = t.y;
         }
@@ -361,10 +391,10 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         } else if (EPI == EPI_ROPE_KV) {     // K6 th.cpp:1476-1490 + K/V append th-llama.cpp:332-339
             if (lane == 0) {
                 const int pos = PIPE ? pos_pipe : (a.pos_ptr ? *a.pos_ptr : a.pos_val);
-                const int r0 = 2 * g, which = r0 / a.E, rr = r0 - which * a.E;
+                const int r0 = 2 * g, which = matrix_of(r0), rr = r0 - which * a.E;
                 float y0 = acc[0], y1 = acc[1 % NR];
                 if (which < 2) {
-                    const int j = rr % a.D;    // even
+                    const int j = head_offset(rr);    // even
                     const float cs = eo ? eo->cs : a.rope_tab[((size_t)pos * (a.D >> 1) + (j >> 1)) * 2];
                     const float sn = eo ? eo->sn : a.rope_tab[((size_t)pos * (a.D >> 1) + (j >> 1)) * 2 + 1];
                     const float t0 = y0 * cs - y1 * sn, t1 = y0 * sn + y1 * cs;
@@ -404,12 +434,16 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     const bool has_first = g < a.n_groups;
     const h8* rp0[NR];
     h8 w0[NR][U];
-    row_ptrs(has_first ? g : a.n_groups - 1, rp0);   // idle waves (more waves than groups) load a valid row:
-    typename ProSelect<NS, PRO, NSP, WPB>::type pro;      // an unconditional load keeps the vmcnt bookkeeping exact
+    typename ProSelect<NS, PRO, NSP, WPB>::type pro;
     pro.issue(a);
     __builtin_amdgcn_sched_barrier(0);
+    row_ptrs(has_first ? g : a.n_groups - 1, rp0);   // idle waves (more waves than groups) load a valid row: an unconditional load keeps
+                                                     // the vmcnt bookkeeping exact.  (Behind issue(): the matrix select of the qkv stack is
+                                                     // ~40 instructions the activation requests need not wait for.)
     load_batch(rp0, 0, w0);
     __builtin_amdgcn_sched_barrier(0);
+    if (NS != 0 && PRO == PRO_ATTN) pro.pin();       // (the other prologues keep their order without it, and lose ~30 instructions of head start with it)
+    if (PIPE && EPI == EPI_ROPE_KV) pos_pipe = a.pos_ptr ? *a.pos_ptr : a.pos_val;
     pro.finish(a, xs, red, ns, bid);
     THK_STAMP(a.trace, bid, 1);
 
@@ -587,6 +621,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     __shared__ float sm_o[WAVES][DV];
     __shared__ float sm_ml[WAVES][2];
 
+    const int pos0 = a.pos_ptr ? *a.pos_ptr : a.pos_val;        // requested first: a scalar load from memory whose latency the index arithmetic below hides
+    __builtin_amdgcn_sched_barrier(0);
     // prefill: nq > 1 causal queries share one launch; query qi sits at position pos + qi
     const int hs = a.H * a.nsplit;
     const int per_q = hs * VS;
@@ -597,16 +633,19 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
         if ((hs & 7) == 0) { vh = (r >> 3) & 1; hb = ((r >> 4) << 3) | (r & 7); }   // the pair = workgroups b, b + 8: same XCD
         else { vh = r & 1; hb = r >> 1; }
     }
-    const int h = hb / a.nsplit, s = hb - h * a.nsplit;
+    // x / nsplit by multiply-high (ns_magic = ceil(2^32 / nsplit); 0 = nsplit is 1): an integer division is ~40 instructions, and two
+    // of them stood between the kernel's entry and the request for the position every K/V address depends on
+    auto div_ns = [&](int x) -> int { return a.ns_magic ? (int)__umulhi((unsigned)x, a.ns_magic) : x; };
+    const int h = div_ns(hb), s = hb - h * a.nsplit;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPP, li = lane - grp * LPP;
     const int grv = lane / LPV, lv = lane - grv * LPV;          // VS == 2: grp == grv >> 1
     const int sel = (VS == 2) ? (grv & 1) : 0;
     THK_STAMP(a.trace, bid, 0);
-    const int T = (a.pos_ptr ? *a.pos_ptr : a.pos_val) + qi + 1;
+    const int T = pos0 + qi + 1;
     const int E = a.H * D;
     int tc = a.tc;
-    if (a.tc_dyn) tc = (((T + a.nsplit - 1) / a.nsplit + PPW * UB - 1) / (PPW * UB)) * (PPW * UB);
+    if (a.tc_dyn) tc = ((div_ns(T + a.nsplit - 1) + PPW * UB - 1) / (PPW * UB)) * (PPW * UB);
     const int t0 = s * tc, t1 = min(t0 + tc, T);
 
     const f4 q = *reinterpret_cast<const f4*>(a.q + qi * E + h * D + li * 4);

@@ -42,6 +42,13 @@ __global__ __launch_bounds__(WPB * 64) void gemv_kernel(const uint16_t* W0, cons
     GemvArgs b = a;
     b.W[0] = W0; b.W[1] = W1; b.W[2] = W2; b.x = x; b.gain = gain; b.C = C; b.n_groups = n_groups;
     if (EPI == EPI_ROPE_KV) b.E = R_or_E; else b.R = R_or_E;
+    // PRO_ATTN (wo: one matrix) has no use for the activation / gain / W1 slots: the split partials and the head size travel there, so
+    // the prologue's first requests need no scalar load of a struct member (and no wait for one) either
+    if (PRO == PRO_ATTN) {
+        b.part_o = x; b.part_ml = gain;
+        const unsigned long long dm = reinterpret_cast<unsigned long long>(W1);
+        b.d_magic = (unsigned)dm; b.D = (int)(dm >> 32);
+    }
     gemv_body<NR, U, NS, PRO, EPI, NT, NSP, PIPE, WPB>(b, blockIdx.x, nblk);
 }
 
@@ -69,7 +76,14 @@ static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kn), WPB * 64, smem);
         fprintf(stderr, "[thk] gemv<NR=%d,U=%d,NS=%d,PRO=%d,EPI=%d,PIPE=%d,WPB=%d> grid=%d smem=%zu: %d blocks/CU (occupancy API)\n", NR, U, NS, PRO, EPI, (int)PIPE, WPB, grid, smem, nb);
     }
-    hipLaunchKernelGGL(kn, dim3(grid), dim3(WPB * 64), smem, st, a.W[0], a.W[1], a.W[2], a.x, a.gain, a.C, a.n_groups, EPI == EPI_ROPE_KV ? a.E : a.R, grid, a);
+    const uint16_t* w1 = a.W[1];
+    if (PRO == PRO_ATTN) {      // see gemv_kernel
+        if (a.D <= 0 || a.D >= 65536 || a.C >= 65536) return hipErrorInvalidValue;
+        const unsigned long long magic = ((1ull << 32) + (unsigned)a.D - 1) / (unsigned)a.D;
+        w1 = reinterpret_cast<const uint16_t*>(magic | ((unsigned long long)a.D << 32));
+    }
+    hipLaunchKernelGGL(kn, dim3(grid), dim3(WPB * 64), smem, st, a.W[0], w1, a.W[2], PRO == PRO_ATTN ? a.part_o : a.x, PRO == PRO_ATTN ? a.part_ml : a.gain, a.C, a.n_groups,
+                       EPI == EPI_ROPE_KV ? a.E : a.R, grid, a);
     return hipGetLastError();
 }
 template <int NR, int U, int NS, int PRO, int EPI, bool PIPE, int WPB>
@@ -169,17 +183,19 @@ hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, b
 // of dependent loads starts from
 template <int D, int WAVES, bool KVH, int VS, bool PIPE = false>
 __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(const int32_t* pos_ptr, const float* q, const float* kcache, const float* vcache,
-                                                                 int pos_val, int H, int nsplit, int tc, int tc_dyn, int nq, const AttnArgs a) {
+                                                                 int pos_val, int H, int nsplit, int tc_signed, unsigned ns_magic, int nq, const AttnArgs a) {
     AttnArgs b = a;
-    b.pos_ptr = pos_ptr; b.q = q; b.kcache = kcache; b.vcache = vcache; b.pos_val = pos_val; b.H = H; b.nsplit = nsplit; b.tc = tc; b.tc_dyn = tc_dyn; b.nq = nq;
+    b.pos_ptr = pos_ptr; b.q = q; b.kcache = kcache; b.vcache = vcache; b.pos_val = pos_val; b.H = H; b.nsplit = nsplit; b.nq = nq;
+    b.tc = tc_signed < 0 ? -tc_signed : tc_signed; b.tc_dyn = tc_signed < 0; b.ns_magic = ns_magic;     // (tc_dyn travels as the sign of tc: its slot carries the magic number)
     attn_body<D, WAVES, KVH, VS, PIPE>(b, blockIdx.x);
 }
 
 template <int D, int WAVES>
 static void launch_attn_dw(const AttnArgs& a, int grid, hipStream_t st) {
     const bool v2 = a.vsplit == 2;
+    const unsigned ns_magic = (unsigned)(((1ull << 32) + (unsigned)a.nsplit - 1) / (unsigned)a.nsplit);     // nsplit == 1: 0 (2^32 truncated) - attn_body does not divide then
 #define THK_ATTN_GO(kvh, vs, pp) hipLaunchKernelGGL((attn_decode_kernel<D, WAVES, kvh, vs, pp>), dim3(grid), dim3(WAVES * 64), 0, st, a.pos_ptr, a.q, a.kcache, a.vcache, \
-                                                    a.pos_val, a.H, a.nsplit, a.tc, a.tc_dyn, a.nq, a)
+                                                    a.pos_val, a.H, a.nsplit, a.tc_dyn ? -a.tc : a.tc, ns_magic, a.nq, a)
     if constexpr (D == 128 && WAVES == 8) {       // the software-pipelined rounds (long caches) exist for the LLaMA head size, one workgroup per (head, split)
         if (a.pipe && !v2) { if (a.kv_f16) THK_ATTN_GO(true, 1, true); else THK_ATTN_GO(false, 1, true); return; }
     }
@@ -189,6 +205,7 @@ static void launch_attn_dw(const AttnArgs& a, int grid, hipStream_t st) {
 }
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     if (a.vsplit != 1 && a.vsplit != 2) return hipErrorInvalidValue;
+    if (a.nsplit < 1 || a.nsplit > 4096 || a.tc <= 0) return hipErrorInvalidValue;
     const int grid = a.H * a.nsplit * a.vsplit * (a.nq > 1 ? a.nq : 1);
     const bool w8 = a.waves == 8;
     switch (a.D) {

@@ -49,6 +49,8 @@ struct GemvArgs {
     int kv_f16;             // caches hold binary16 [n_ctx, H, D] (optional; the reference's and the default are f32)
     // PRO_ATTN
     const float* part_o; const float* part_ml; int H; int nsplit;
+    unsigned d_magic;            // PRO_ATTN: ceil(2^32 / D), set by launch_gemv: element e -> head __umulhi(e, d_magic) (exact for e, D < 65536) instead of a
+                                 // division between the prologue's requests.  Travels to the kernel, with D, in the unused W1 slot of the preloaded scalars.
     // EPI_HEAD
     int lm_faithful; int q1_split; int q1_cov; unsigned long long* block_best;
     FinishArgs fin;              // EPI_HEAD: fin.folded folds the greedy pick into this launch
@@ -62,6 +64,8 @@ struct AttnArgs {
     const int32_t* pos_ptr; int pos_val;   // T = pos + 1
     int H, D, nsplit, tc;      // tc = positions per split ...
     int tc_dyn;                // ... or 1: tc = ceil(T / nsplit) rounded up to the wave batch, computed on the device from the live position
+    unsigned ns_magic;         // ceil(2^32 / nsplit), set by launch_attn_decode: x / nsplit = __umulhi(x, ns_magic) for x * nsplit < 2^32 (no integer
+                               // division between the kernel's entry and its K/V requests); reaches the kernel in the preloaded scalars
     int vsplit;                // 1 | 2: workgroups per (head, split), each taking 1/vsplit of the V columns (attn_body)
     int pipe;                  // 1: a split may span several rounds of the workgroup (long caches): take the software-pipelined variant where it exists
     int waves;                 // waves per block of the stand-alone kernel (4 or 8)

@@ -1,0 +1,21 @@
+#!/bin/bash
+# What stands between a decode kernel's entry and its first weight request?  Compiles thk_kernels.hip to gfx950 assembly and, for
+# the default 7B instantiations, lists the scalar loads / waits / divisions / barriers ahead of the first `global_load ... nt`.
+#   tools/dev/kernel_head.sh [out.s]      (about two minutes; no GPU needed)
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+S=${1:-/tmp/thk_kernels.s}
+cd "$ROOT/token-hawk_amd"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value -Wno-int-to-pointer-cast -Wno-int-to-void-pointer-cast \
+      -mllvm -amdgpu-kernarg-preload-count=14 -x hip --cuda-device-only -S csrc/thk_kernels.hip -o "$S" 2>/dev/null
+# NR,U,NS,PRO,EPI,NT,NSP,PIPE,WPB of the 7B defaults: qkv, wo, w13, w2, lm-head
+for k in "qkv:ILi2ELi8ELi8ELi1ELi2ELb1ELi0ELb1ELi4EE" "wo:ILi1ELi8ELi8ELi2ELi1ELb1ELi4ELb1ELi4EE" "w13:ILi2ELi8ELi8ELi1ELi3ELb1ELi0ELb1ELi4EE" "w2:ILi2ELi11ELi22ELi0ELi1ELb1ELi0ELb0ELi4EE" "head:ILi1ELi8ELi8ELi1ELi4ELb1ELi0ELb1ELi4EE"; do
+  name=${k%%:*}; sym=${k#*:}
+  echo "== $name"
+  awk "/^_ZN3thk11gemv_kernel${sym}[^:]*:/,/s_endpgm/" "$S" | grep -v "^\s*;" | grep -v "^\." | awk '
+    /\.p2align/ { n = 0; next }                      # the entry used when the arguments were preloaded starts here
+    { n++ }
+    /global_load.* nt/ { print "  first weight request after", n, "instructions"; exit }
+    /s_load|s_waitcnt|v_rcp|s_barrier|s_cbranch/ { printf "  %4d %s\n", n, $0 }
+    /global_load/ { if (!p) { printf "  %4d (first activation request)\n", n; p = 1 } }'
+done
