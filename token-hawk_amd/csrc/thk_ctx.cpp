@@ -28,6 +28,7 @@ void default_tunables(thk_ctx* ctx) {
     ctx->tun["prefill_tile_wo"] = 128; ctx->tun["prefill_tile_w2"] = 128;   // 16 row-blocks only: halve the 16-way split-K partials (-3 %)
     for (const char* k : {"qkv", "wo", "w13", "w2", "head"}) {
         ctx->tun[std::string("gemv_bpc_") + k] = -1;
+        ctx->tun[std::string("gemv_grid_") + k] = 0;      // > 0: this many workgroups for the launch, whatever gemv_bpc_* says (fewer than one per CU is allowed)
         ctx->tun[std::string("gemv_variant_") + k] = -1;   // (rows/iteration, slots/batch) variant, see gemv_variant()
     }
     ctx->tun["attn_splits"] = 0;          // context splits per head: 0 = auto (4; 8 when n_ctx > 1024), or 1, 2, 4, 8
@@ -70,6 +71,10 @@ int grid_for(thk_ctx* ctx, const char* specific, int n_groups, int n_embd) {
     if (bpc <= 0) bpc = tun(ctx, "gemv_blocks_per_cu");
     if (bpc <= 0) bpc = 4;
     int64_t g = (int64_t)ctx->n_cu * bpc;
+    if (!strncmp(specific, "gemv_bpc_", 9)) {
+        const std::string gk = std::string("gemv_grid_") + (specific + 9);
+        if (ctx->tun.count(gk) && ctx->tun[gk] > 0) g = ctx->tun[gk];
+    }
     const int64_t need = (n_groups + kWaves - 1) / kWaves;
     if (g > need) g = need;
     if (g < 1) g = 1;

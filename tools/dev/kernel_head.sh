@@ -9,11 +9,12 @@ cd "$ROOT/token-hawk_amd"
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wno-unused-value -Wno-int-to-pointer-cast -Wno-int-to-void-pointer-cast \
       -mllvm -amdgpu-kernarg-preload-count=14 -x hip --cuda-device-only -S csrc/thk_kernels.hip -o "$S" 2>/dev/null
 # NR,U,NS,PRO,EPI,NT,NSP,PIPE,WPB of the 7B defaults: qkv, wo, w13, w2, lm-head
-for k in "qkv:ILi2ELi8ELi8ELi1ELi2ELb1ELi0ELb1ELi4EE" "wo:ILi1ELi8ELi8ELi2ELi1ELb1ELi4ELb1ELi4EE" "w13:ILi2ELi8ELi8ELi1ELi3ELb1ELi0ELb1ELi4EE" "w2:ILi2ELi11ELi22ELi0ELi1ELb1ELi0ELb0ELi4EE" "head:ILi1ELi8ELi8ELi1ELi4ELb1ELi0ELb1ELi4EE"; do
+for k in "qkv:ILi2ELi8ELi8ELi1ELi2ELb1ELi0ELb1ELi4EE" "wo:ILi1ELi8ELi8ELi2ELi1ELb1ELi4ELb1ELi4EE" "w13:ILi2ELi8ELi8ELi1ELi3ELb1ELi0ELb1ELi4EE" "w2:ILi1ELi22ELi22ELi0ELi1ELb1ELi0ELb0ELi4EE" "head:ILi1ELi8ELi8ELi1ELi4ELb1ELi0ELb1ELi4EE"; do
   name=${k%%:*}; sym=${k#*:}
   echo "== $name"
   awk "/^_ZN3thk11gemv_kernel${sym}[^:]*:/,/s_endpgm/" "$S" | grep -v "^\s*;" | grep -v "^\." | awk '
-    /\.p2align/ { n = 0; next }                      # the entry used when the arguments were preloaded starts here
+    /\.p2align/ { n = 0; on = 1; next }              # the entry used when the arguments were preloaded starts here (what precedes it is
+    !on { next }                                     # the fall-back prologue for firmware without kernarg preload)
     { n++ }
     /global_load.* nt/ { print "  first weight request after", n, "instructions"; exit }
     /s_load|s_waitcnt|v_rcp|s_barrier|s_cbranch/ { printf "  %4d %s\n", n, $0 }
