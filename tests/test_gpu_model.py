@@ -61,12 +61,13 @@ R03_STEP = {"attn_vsplit": 1, "attn_tc_dyn": 0, "fold_finish": 0, "attn_splits":
 
 @pytest.mark.parametrize("tunables", [{"attn_waves": 4}, {"attn_waves": 4, "attn_splits": 8}, {"fold_embed": 0}, {"fold_embed": 0, "use_graph": 0},
                                       {"attn_vsplit": 2}, {"attn_tc_dyn": 0}, {"attn_vsplit": 2, "attn_tc_dyn": 0, "attn_waves": 4},
-                                      {"fold_finish": 0}, {"fold_finish": 0, "use_graph": 0}, {"fold_finish": 1, "use_graph": 0}, R03_STEP])
+                                      {"fold_finish": 0}, {"fold_finish": 0, "use_graph": 0}, {"fold_finish": 1, "use_graph": 0}, R03_STEP,
+                                      {"gemv_grid_qkv": 5, "gemv_grid_wo": 3, "gemv_grid_w13": 7, "gemv_grid_w2": 1, "gemv_grid_head": 11}])
 def test_optional_paths_vs_oracle(thk, orc, ctx, tunables):
     """The off-by-default options stay correct: 4-wave attention blocks, the stand-alone embedding launch (default: the row is
     fetched by layer 0's qkv prologue), attention workgroup pairs that halve the V columns (default: one workgroup per (head, split)),
     splits over the cache capacity (default: over the live context), the greedy pick as a launch of its own (default: folded into
-    the lm-head launch's last workgroup)."""
+    the lm-head launch's last workgroup), explicit workgroup counts for the mat-vecs (odd ones, fewer than one per CU)."""
     m, om = make_pair(thk, orc, ctx, "TINY", tunables=tunables)
     rng = np.random.default_rng(5)
     toks = [1] + rng.integers(3, 2048, 30).tolist()
