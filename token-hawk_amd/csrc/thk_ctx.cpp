@@ -54,10 +54,10 @@ void default_tunables(thk_ctx* ctx) {
 // take the 7B row (their run-time slot count maps the pipelined variants back to variant 0).
 Geo auto_geometry(const char* kernel, int n_embd) {
     const bool w13b = n_embd == 5120;
-    if (!strcmp(kernel, "qkv")) return w13b ? Geo{3, 3} : Geo{3, 5};
+    if (!strcmp(kernel, "qkv")) return w13b ? Geo{1, 1} : Geo{1, 6};      // single rows, one workgroup per CU (round 4: 8 KiB chunks; RoPE pairs meet in LDS)
     if (!strcmp(kernel, "wo")) return Geo{1, 6};
     if (!strcmp(kernel, "w13")) return w13b ? Geo{8, 5} : Geo{4, 5};
-    if (!strcmp(kernel, "w2")) return w13b ? Geo{1, 5} : Geo{2, 2};
+    if (!strcmp(kernel, "w2")) return Geo{1, 5};                          // pipelined single rows, one workgroup per CU
     if (!strcmp(kernel, "head")) return w13b ? Geo{8, 2} : Geo{8, 6};
     return Geo{4, 0};
 }

@@ -311,10 +311,10 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     // row pointers of group g (wave-uniform; independent of the activation vector)
     auto row_ptrs = [&](int g, const h8* (&rp)[NR]) {
         if (EPI == EPI_ROPE_KV) {
-            const int r0 = 2 * g, which = matrix_of(r0), rr = r0 - which * a.E;      // (no division ahead of the first weight request)
+            const int r0 = NR == 1 ? g : 2 * g, which = matrix_of(r0), rr = r0 - which * a.E;      // (no division ahead of the first weight request; NR == 1: single rows, below)
             const uint16_t* base = which == 0 ? a.W[0] : (which == 1 ? a.W[1] : a.W[2]);
             rp[0] = reinterpret_cast<const h8*>(base + (size_t)rr * C);
-            rp[1 % NR] = reinterpret_cast<const h8*>(base + (size_t)(rr + 1) * C);
+            if (NR > 1) rp[1 % NR] = reinterpret_cast<const h8*>(base + (size_t)(rr + 1) * C);
         } else if (EPI == EPI_SWIGLU) {
             rp[0] = reinterpret_cast<const h8*>(a.W[0] + (size_t)g * C);
             rp[1 % NR] = reinterpret_cast<const h8*>(a.W[1] + (size_t)g * C);
@@ -365,11 +365,21 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     int pos_pipe = 0;        // PIPE && EPI_ROPE_KV: the position, read behind the first weight batch (below) - its null check is a branch that
                              // would otherwise wait for a scalar load of a struct member before anything has been requested
     auto head_offset = [&](int rr) -> int { return rr % a.D; };
+    // EPI_ROPE_KV with single rows (NR == 1; round 4): a wave owns whole rows w, w + W, ... (8 KiB chunks instead of the 16 KiB of a
+    // row pair - tools/probes/read_floor_probe.hip: the same bytes stream 4-5 % faster in 8 KiB chunks).  The rotation needs rows
+    // 2j and 2j + 1, which then sit in NEIGHBOURING waves of one workgroup (waves 0|1 and 2|3; W is a multiple of 4): the sums go
+    // to LDS (ysm[round][wave]) and thread t < 2 * rounds rotates and stores pair (round t >> 1, waves 2 (t & 1), 2 (t & 1) + 1) after
+    // one barrier at the end of the kernel; its cos/sin are requested right behind the first weight batch.
+    constexpr int kSrRounds = 32;                       // rounds a wave may run (launch_gemv checks the geometry)
+    float* ysm = red + 32;                              // [kSrRounds][WPB]
+    int sr_count = 0;
+    int sr_r0 = -1, sr_which = 0, sr_rr = 0;
+    float2 sr_cs = {1.f, 0.f};
     auto epi_fetch = [&](int g, EpiOps& eo) {
         if (EPI == EPI_RESID) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) eo.resid[r] = a.resid[min(NR * g + r, a.R - 1)];      // wave-uniform address: one request
-        } else if (EPI == EPI_ROPE_KV) {
+        } else if (EPI == EPI_ROPE_KV && NR > 1) {
             const int r0 = 2 * g, which = matrix_of(r0), rr = r0 - which * a.E, j = head_offset(rr);
             const float2 t = *reinterpret_cast<const float2*>(a.rope_tab + ((size_t)pos_pipe * (a.D >> 1) + (j >> 1)) * 2);
             eo.cs = t.x; eo.sn = t.y;
@@ -388,6 +398,9 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
 #pragma unroll
                 for (int r = 0; r < NR; ++r) if (NR * g + r < a.R) a.y[NR * g + r] = (eo ? eo->resid[r] : a.resid[NR * g + r]) + acc[r];
             }
+        } else if (EPI == EPI_ROPE_KV && NR == 1) {     // single rows: the sum waits in LDS for its RoPE partner (the neighbouring wave's row)
+            if (lane == 0) ysm[sr_count * WPB + wave] = acc[0];
+            ++sr_count;
         } else if (EPI == EPI_ROPE_KV) {     // K6 th.cpp:1476-1490 + K/V append th-llama.cpp:332-339
             if (lane == 0) {
                 const int pos = PIPE ? pos_pipe : (a.pos_ptr ? *a.pos_ptr : a.pos_val);
@@ -443,7 +456,17 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     load_batch(rp0, 0, w0);
     __builtin_amdgcn_sched_barrier(0);
     if (NS != 0 && PRO == PRO_ATTN) pro.pin();       // (the other prologues keep their order without it, and lose ~30 instructions of head start with it)
-    if (PIPE && EPI == EPI_ROPE_KV) pos_pipe = a.pos_ptr ? *a.pos_ptr : a.pos_val;
+    if ((PIPE || NR == 1) && EPI == EPI_ROPE_KV) pos_pipe = a.pos_ptr ? *a.pos_ptr : a.pos_val;
+    if (EPI == EPI_ROPE_KV && NR == 1) {
+        static_assert(EPI != EPI_ROPE_KV || NR != 1 || WPB == 4, "RoPE pairs are waves 0|1 and 2|3 of a 4-wave workgroup");
+        const int t = threadIdx.x, r0 = bid * WPB + 2 * (t & 1) + (t >> 1) * total_waves;      // even: bid * 4 and total_waves are
+        const bool mine = t < 2 * kSrRounds && r0 < a.n_groups;
+        const int rc = mine ? r0 : 0;                                                           // branch-free request (a per-lane `if` around a load costs a vmcnt(0))
+        sr_which = (rc >= a.E) + (rc >= 2 * a.E); sr_rr = rc - sr_which * a.E;
+        const int j = head_offset(sr_rr);
+        sr_cs = *reinterpret_cast<const float2*>(a.rope_tab + ((size_t)pos_pipe * (a.D >> 1) + (j >> 1)) * 2);
+        sr_r0 = mine ? r0 : -1;
+    }
     pro.finish(a, xs, red, ns, bid);
     THK_STAMP(a.trace, bid, 1);
 
@@ -551,6 +574,24 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
                 }
             }
             finish_group(g, acc, acc_hi);
+        }
+    }
+    if (EPI == EPI_ROPE_KV && NR == 1) {      // the RoPE pairs of this workgroup (see ysm above)
+        __syncthreads();
+        if (sr_r0 >= 0) {
+            const int t = threadIdx.x;
+            float y0 = ysm[(t >> 1) * WPB + 2 * (t & 1)], y1 = ysm[(t >> 1) * WPB + 2 * (t & 1) + 1];
+            if (sr_which < 2) {                                     // K6 th.cpp:1476-1490
+                const float t0 = y0 * sr_cs.x - y1 * sr_cs.y, t1 = y0 * sr_cs.y + y1 * sr_cs.x;
+                y0 = t0; y1 = t1;
+            }
+            if (sr_which != 0 && a.kv_f16) {                        // K/V append th-llama.cpp:332-339 (optional f16 cache: RNE at the append)
+                _Float16* dh = reinterpret_cast<_Float16*>(sr_which == 1 ? a.kcache : a.vcache) + (size_t)pos_pipe * a.E;
+                dh[sr_rr] = (_Float16)y0; dh[sr_rr + 1] = (_Float16)y1;
+            } else {
+                float* dst = sr_which == 0 ? a.y : (sr_which == 1 ? a.kcache + (size_t)pos_pipe * a.E : a.vcache + (size_t)pos_pipe * a.E);
+                dst[sr_rr] = y0; dst[sr_rr + 1] = y1;
+            }
         }
     }
     THK_STAMP(a.trace, bid, 3);

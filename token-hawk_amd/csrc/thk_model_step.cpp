@@ -65,7 +65,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         const float* xr_in = i == 0 ? xin : m->x;
         {   // rms_norm*gain -> wq,wk,wv -> RoPE -> K/V append   (steps 1-4, th-llama.cpp:299-339)
             GemvArgs a{};
-            a.W[0] = L.wq; a.W[1] = L.wk; a.W[2] = L.wv; a.R = E; a.C = E; a.n_groups = 3 * E / 2;
+            a.W[0] = L.wq; a.W[1] = L.wk; a.W[2] = L.wv; a.R = E; a.C = E; a.n_groups = 3 * E / gemv_rows_per_group(E, GEMV_EPI_ROPE_KV, m->var_qkv);
             a.x = xr_in; a.gain = L.attention_norm; a.y = m->q;
             a.kcache = kc; a.vcache = vc; a.rope_tab = m->rope_tab; a.pos_ptr = &sb.st->pos; a.E = E; a.D = D; a.kv_f16 = m->kv_f16;
             const bool emb = fold_embed && i == 0;

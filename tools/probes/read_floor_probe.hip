@@ -182,6 +182,11 @@ int main(int argc, char** argv) {
             snprintf(buf, sizeof buf, "chain, product geometry and row groups, %2d KiB in flight per wave", U);
             report(buf, chain_ms(step, pool, geo, sink, st, replays));
         }
+        for (int G : {4, 8, 16, 32}) for (int U : {8, 16}) {      // what the chunk size alone is worth: the product's workgroup counts, every launch cut into chunks of G KiB
+            Geo geo; geo.U = U; geo.G = G;
+            snprintf(buf, sizeof buf, "chain, product workgroup counts, chunks of %2d KiB, %2d KiB in flight per wave", G, U);
+            report(buf, chain_ms(step, pool, geo, sink, st, replays));
+        }
         { Geo geo; report("chain, product geometry, 16 KiB in flight, 8 steps per graph", chain_ms(step, pool, geo, sink, st, std::max(1, replays / 4), 8)); }
         {
             hipGraphExec_t x = build_free(step, pool, sink);
