@@ -315,6 +315,11 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
             const uint16_t* base = which == 0 ? a.W[0] : (which == 1 ? a.W[1] : a.W[2]);
             rp[0] = reinterpret_cast<const h8*>(base + (size_t)rr * C);
             if (NR > 1) rp[1 % NR] = reinterpret_cast<const h8*>(base + (size_t)(rr + 1) * C);
+        } else if (EPI == EPI_SWIGLU && NR == 1) {     // single rows: group 2 j is row j of w1, group 2 j + 1 row j of w3 (the pair meets in LDS, below)
+            // (not `g & 1 ? a.W[1] : a.W[0]`: a select of two elements of one array becomes the dynamically indexed a.W[g & 1] and the
+            // whole argument block moves to scratch memory - seen in the ISA)
+            const ptrdiff_t to_w3 = (g & 1) ? a.W[1] - a.W[0] : (ptrdiff_t)0;
+            rp[0] = reinterpret_cast<const h8*>(a.W[0] + to_w3 + (size_t)(g >> 1) * C);
         } else if (EPI == EPI_SWIGLU) {
             rp[0] = reinterpret_cast<const h8*>(a.W[0] + (size_t)g * C);
             rp[1 % NR] = reinterpret_cast<const h8*>(a.W[1] + (size_t)g * C);
@@ -365,11 +370,12 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     int pos_pipe = 0;        // PIPE && EPI_ROPE_KV: the position, read behind the first weight batch (below) - its null check is a branch that
                              // would otherwise wait for a scalar load of a struct member before anything has been requested
     auto head_offset = [&](int rr) -> int { return rr % a.D; };
-    // EPI_ROPE_KV with single rows (NR == 1; round 4): a wave owns whole rows w, w + W, ... (8 KiB chunks instead of the 16 KiB of a
+    // Single rows for the epilogues that need two row sums together (NR == 1; round 4).  EPI_ROPE_KV: a wave owns whole rows w, w + W, ... (8 KiB chunks instead of the 16 KiB of a
     // row pair - tools/probes/read_floor_probe.hip: the same bytes stream 4-5 % faster in 8 KiB chunks).  The rotation needs rows
     // 2j and 2j + 1, which then sit in NEIGHBOURING waves of one workgroup (waves 0|1 and 2|3; W is a multiple of 4): the sums go
     // to LDS (ysm[round][wave]) and thread t < 2 * rounds rotates and stores pair (round t >> 1, waves 2 (t & 1), 2 (t & 1) + 1) after
-    // one barrier at the end of the kernel; its cos/sin are requested right behind the first weight batch.
+    // one barrier at the end of the kernel; its cos/sin are requested right behind the first weight batch.  EPI_SWIGLU the same way:
+    // group 2j = row j of w1, group 2j + 1 = row j of w3, thread t writes silu(u1) * u3 for pair (round t >> 1, waves 2 (t & 1) | + 1).
     constexpr int kSrRounds = 32;                       // rounds a wave may run (launch_gemv checks the geometry)
     float* ysm = red + 32;                              // [kSrRounds][WPB]
     int sr_count = 0;
@@ -421,6 +427,9 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
                     dst[rr] = y0; dst[rr + 1] = y1;
                 }
             }
+        } else if (EPI == EPI_SWIGLU && NR == 1) {      // single rows: the sum waits in LDS for its partner (row j of the other matrix, the neighbouring wave)
+            if (lane == 0) ysm[sr_count * WPB + wave] = acc[0];
+            ++sr_count;
         } else if (EPI == EPI_SWIGLU) {      // K12 th.cpp:2706-2707, K13 :2512-2524
             if (lane == 0) { const float u1 = acc[0]; a.y[g] = (u1 / (1.0f + expf(-u1))) * acc[1 % NR]; }
         } else {                              // EPI_HEAD: K3 th.cpp:3926-3943 (+Q1 switch)
@@ -574,6 +583,15 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
                 }
             }
             finish_group(g, acc, acc_hi);
+        }
+    }
+    if (EPI == EPI_SWIGLU && NR == 1) {       // the (w1, w3) pairs of this workgroup (see ysm above)
+        static_assert(EPI != EPI_SWIGLU || NR != 1 || WPB == 4, "pairs are waves 0|1 and 2|3 of a 4-wave workgroup");
+        __syncthreads();
+        const int t = threadIdx.x, u0 = bid * WPB + 2 * (t & 1) + (t >> 1) * total_waves;       // even
+        if (t < 2 * kSrRounds && u0 < a.n_groups) {
+            const float u1 = ysm[(t >> 1) * WPB + 2 * (t & 1)], u3 = ysm[(t >> 1) * WPB + 2 * (t & 1) + 1];
+            a.y[u0 >> 1] = (u1 / (1.0f + expf(-u1))) * u3;          // K12 th.cpp:2706-2707, K13 :2512-2524
         }
     }
     if (EPI == EPI_ROPE_KV && NR == 1) {      // the RoPE pairs of this workgroup (see ysm above)

@@ -55,8 +55,8 @@ __global__ __launch_bounds__(WPB * 64) void gemv_kernel(const uint16_t* W0, cons
 template <int NR, int U, int NS, int PRO, int EPI, int NSP, bool PIPE, int WPB>
 static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_t st) {
     const int ns = NS ? NS : (((a.C >> 3) + 63) >> 6);
-    const size_t smem = (size_t)ns * 512 * 4 + 128 + ((EPI == EPI_ROPE_KV && NR == 1) ? 512 : 0);      // + ysm[32][4] (single-row qkv, gemv_body)
-    if (EPI == EPI_ROPE_KV && NR == 1 && ((long)grid * WPB * 32 < a.n_groups || (a.n_groups & 1) || WPB != 4)) return hipErrorInvalidValue;     // at most 32 rounds per wave
+    const size_t smem = (size_t)ns * 512 * 4 + 128 + (((EPI == EPI_ROPE_KV || EPI == EPI_SWIGLU) && NR == 1) ? 512 : 0);      // + ysm[32][4] (single-row qkv / w13, gemv_body)
+    if ((EPI == EPI_ROPE_KV || EPI == EPI_SWIGLU) && NR == 1 && ((long)grid * WPB * 32 < a.n_groups || (a.n_groups & 1) || WPB != 4)) return hipErrorInvalidValue;     // at most 32 rounds per wave
     (void)nt;   // weights always stream with non-temporal loads (default-policy loads measured 8 % slower)
     auto kn = gemv_kernel<NR, U, NS, PRO, EPI, true, NSP, PIPE, WPB>;
     static size_t attr_set[kMaxDevices] = {};   // per instantiation AND per device; first call happens outside graph capture
@@ -117,7 +117,7 @@ static int ns_class(int C) {
 //   5-7  software-pipelined loop (gemv_body PIPE): one whole row group in flight, slot c of the next group requested as soon as
 //        slot c of the current one is consumed.  5 = row pair (one row for 11008/13824 columns), 6 = one row, 7 = four rows
 void gemv_variant(int C, int epi, int nru, int* NR, int* U, int* pipe) {
-    const bool pair = epi == EPI_SWIGLU;       // needs rows g of two matrices together; EPI_ROPE_KV takes row pairs (NR = 2) or single rows (NR = 1, pairs meet in LDS)
+    const bool pair = false;                   // EPI_ROPE_KV and EPI_SWIGLU take their two rows together (NR = 2) or as single rows (NR = 1, the pair meets in LDS)
     static const int t8[8][3] = {{2, 8, 0}, {1, 8, 0}, {2, 4, 0}, {4, 4, 0}, {4, 8, 0}, {2, 8, 1}, {1, 8, 1}, {4, 8, 1}};
     static const int t10[8][3] = {{2, 10, 0}, {1, 10, 0}, {2, 5, 0}, {4, 5, 0}, {4, 10, 0}, {2, 10, 1}, {1, 10, 1}, {4, 10, 1}};
     static const int t22[8][3] = {{2, 11, 0}, {1, 11, 0}, {1, 22, 0}, {2, 11, 0}, {2, 11, 0}, {1, 22, 1}, {1, 22, 1}, {1, 22, 1}};
@@ -128,15 +128,15 @@ void gemv_variant(int C, int epi, int nru, int* NR, int* U, int* pipe) {
     if (nru < 0 || nru > 7) nru = 0;
     if (cls == 0 && nru > 4) nru = 0;                  // the pipelined loop needs a compile-time slot count
     if (cls == 0 && nru == 4) nru = 3;
-    if ((pair && t[nru][0] != 2) || (epi == EPI_ROPE_KV && t[nru][0] > 2)) nru = t[nru][2] ? 5 : 0;
+    if ((pair && t[nru][0] != 2) || ((epi == EPI_ROPE_KV || epi == EPI_SWIGLU) && t[nru][0] > 2)) nru = t[nru][2] ? 5 : 0;
     *NR = t[nru][0]; *U = t[nru][1];
     if (pipe) *pipe = t[nru][2];
 }
 
 template <int PRO, int EPI, int NS>
 static hipError_t launch_gemv_ns(int NR, int U, int pipe, const GemvArgs& a, int grid, bool nt, hipStream_t st) {
-    constexpr bool pair = EPI == EPI_SWIGLU;
-    constexpr bool rope = EPI == EPI_ROPE_KV;
+    constexpr bool pair = false;
+    constexpr bool rope = EPI == EPI_ROPE_KV || EPI == EPI_SWIGLU;
 #define THK_TRY(nr, u, pp)                                                                                  \
     if constexpr ((NS == 0 || NS % (u) == 0) && (!pair || (nr) == 2) && (!rope || (nr) <= 2) && (!(pp) || (NS != 0 && (u) == NS))) {   \
         if (NR == (nr) && U == (u) && pipe == (pp)) return launch_gemv_t<nr, u, NS, PRO, EPI, (pp) != 0>(a, grid, nt, st); \

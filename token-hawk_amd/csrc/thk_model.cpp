@@ -240,7 +240,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->var_w13 = resolve_variant(ctx, "w13", (int)E); m->var_w2 = resolve_variant(ctx, "w2", (int)E); m->var_head = resolve_variant(ctx, "head", (int)E);
     m->grid_qkv = grid_for(ctx, "gemv_bpc_qkv", (int)(3 * E / gemv_rows_per_group((int)E, GEMV_EPI_ROPE_KV, m->var_qkv)), (int)E);     // row pairs, or single rows (variants 1, 6)
     m->grid_wo = grid_for(ctx, "gemv_bpc_wo", (int)((E + gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo) - 1) / gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo)), (int)E);
-    m->grid_w13 = grid_for(ctx, "gemv_bpc_w13", (int)F, (int)E);
+    m->grid_w13 = grid_for(ctx, "gemv_bpc_w13", (int)(2 * F / gemv_rows_per_group((int)E, GEMV_EPI_SWIGLU, m->var_w13)), (int)E);     // (w1, w3) row pairs, or single rows (variants 1, 6)
     m->grid_w2 = grid_for(ctx, "gemv_bpc_w2", (int)((E + gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2) - 1) / gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2)), (int)E);
     m->grid_head = grid_for(ctx, "gemv_bpc_head", (int)((V + gemv_rows_per_group((int)E, GEMV_EPI_HEAD, m->var_head) - 1) / gemv_rows_per_group((int)E, GEMV_EPI_HEAD, m->var_head)), (int)E);
     // working buffers

@@ -98,7 +98,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         }
         {   // rms_norm*gain -> w1,w3 -> silu*gate   (steps 12-14, th-llama.cpp:415-438)
             GemvArgs a{};
-            a.W[0] = L.w1; a.W[1] = L.w3; a.R = F; a.C = E; a.n_groups = F;
+            a.W[0] = L.w1; a.W[1] = L.w3; a.R = F; a.C = E; a.n_groups = 2 * F / gemv_rows_per_group(E, GEMV_EPI_SWIGLU, m->var_w13);
             a.x = m->x; a.gain = L.ffn_norm; a.y = m->u;
             if (m->gain_alias) a.gain = a.x;
             a.trace = trace_slab();
