@@ -216,6 +216,12 @@ struct ProAttn {
     static constexpr int BT = WPB * 64;
     float2 ml[KP][NSP];
     f4 ov[KP][NSP];
+    // contig: the thread's KP float4 are CONSECUTIVE (thread t owns #(t * KP + k)) and lie in one head - true for every head size the
+    // attention kernels accept (64 | 128 | 256) when 4 KP divides 64.  One (m, l) set per thread instead of KP, and the merge's exp /
+    // reciprocal are computed once (same arithmetic, same order - the compiler shares them across the KP calls of attn_merge);
+    // otherwise float4 #(t + k * BT) as the other prologues.  (Compile-time: a run-time branch around the requests made the
+    // compiler wait for vmcnt(0) at the join, ahead of the weight requests.)
+    static constexpr bool contig = (64 % (4 * KP)) == 0;
     __device__ __forceinline__ void load1(const GemvArgs& a, int e, float2 (&m)[NSP], f4 (&o)[NSP]) {
         // element e -> (head, offset) by a multiply-high with d_magic = ceil(2^32 / D), exact for e, D < 65536 (launch_gemv sets it and
         // checks the range; no division fallback - the compiler would compute it speculatively).  The division was ~130 instructions
@@ -227,10 +233,26 @@ struct ProAttn {
             o[s] = *reinterpret_cast<const f4*>(a.part_o + (h * NSP + s) * a.D + d);
         }
     }
+    __device__ __forceinline__ int f4_index(int k) const { return contig ? (int)threadIdx.x * KP + k : (int)threadIdx.x + k * BT; }
     __device__ __forceinline__ void issue(const GemvArgs& a) {
         if (NS == 0) return;
+        if constexpr (contig) {
+            const int e0 = min((int)threadIdx.x * KP * 4, a.C - 4 * KP);
+            const int h = (int)__umulhi((unsigned)e0, a.d_magic), d = e0 - h * a.D;
 #pragma unroll
-        for (int k = 0; k < KP; ++k) load1(a, min((int)(threadIdx.x + k * BT) << 2, a.C - 4), ml[k], ov[k]);
+            for (int s = 0; s < NSP; ++s) {
+                ml[0][s] = *reinterpret_cast<const float2*>(a.part_ml + (h * NSP + s) * 2);
+#pragma unroll
+                for (int k = 0; k < KP; ++k) ov[k][s] = *reinterpret_cast<const f4*>(a.part_o + (h * NSP + s) * a.D + d + 4 * k);
+            }
+#pragma unroll
+            for (int k = 1; k < KP; ++k)
+#pragma unroll
+                for (int s = 0; s < NSP; ++s) ml[k][s] = float2{0.f, 0.f};
+        } else {
+#pragma unroll
+            for (int k = 0; k < KP; ++k) load1(a, min((int)(threadIdx.x + k * BT) << 2, a.C - 4), ml[k], ov[k]);
+        }
     }
     __device__ __forceinline__ void pin() {
         asm volatile("" ::: "memory");
@@ -244,8 +266,8 @@ struct ProAttn {
         if (NS != 0) {
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
-                const int i = threadIdx.x + k * BT;
-                f4 res = attn_merge<NSP>(ml[k], ov[k]);
+                const int i = f4_index(k);
+                f4 res = contig ? attn_merge<NSP>(ml[0], ov[k]) : attn_merge<NSP>(ml[k], ov[k]);
                 if ((i << 2) >= C) res = f4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f4*>(xs + xs_store_index(i, ns)) = res;
             }

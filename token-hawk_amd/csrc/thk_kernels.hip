@@ -79,7 +79,7 @@ static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_
     }
     const uint16_t* w1 = a.W[1];
     if (PRO == PRO_ATTN) {      // see gemv_kernel
-        if (a.D <= 0 || a.D >= 65536 || a.C >= 65536) return hipErrorInvalidValue;
+        if ((a.D != 64 && a.D != 128 && a.D != 256) || a.C >= 65536) return hipErrorInvalidValue;      // the head sizes attention accepts; ProAttn's thread mapping relies on 64 | D
         const unsigned long long magic = ((1ull << 32) + (unsigned)a.D - 1) / (unsigned)a.D;
         w1 = reinterpret_cast<const uint16_t*>(magic | ((unsigned long long)a.D << 32));
     }
