@@ -282,13 +282,15 @@ def test_error_paths(thk, ctx):
 GEMV_KERNELS = ("qkv", "wo", "w13", "w2", "head")
 
 
-@pytest.mark.parametrize("variant", [None, 0, 3, 5, 6, 7])
+@pytest.mark.parametrize("variant", [None, 0, 1, 3, 5, 6, 7, 8, 9])
 @pytest.mark.parametrize("E,H,L,name", [(4096, 32, 2, "7B-dims"), (5120, 40, 1, "13B-dims")])
 def test_full_width_layers_vs_oracle(thk, orc, ctx, E, H, L, name, variant):
     """Real 7B/13B row geometry (E, F=11008/13824, V=32000, T up to 512) on a 1-2 layer model: exercises every
     compile-time-specialised kernel against the oracle's fast flavour - with the default launch geometry (None) and with every
     mat-vec forced to one loop variant (batch loops 0-4, software-pipelined loops 5-7), so each fused prologue/epilogue
-    (norm, embedding fetch, split combine | RoPE + K/V append, residual, SwiGLU, lm-head + arg-max) runs in both loop forms."""
+    (norm, embedding fetch, split combine | RoPE + K/V append, residual, SwiGLU, lm-head + arg-max) runs in both loop forms.
+    Variants 1 and 6 are the single-row forms of qkv and w13 (the RoPE / SwiGLU pair meets in LDS), 8 and 9 the quarter-row
+    form of w2 (a workgroup per row; the other kernels take variant 0 then)."""
     tun = {} if variant is None else {f"gemv_variant_{k}": variant for k in GEMV_KERNELS}
     old = {k: ctx.get_tunable(k) for k in tun}
     for k, v in tun.items():

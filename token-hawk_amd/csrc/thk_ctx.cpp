@@ -57,7 +57,7 @@ Geo auto_geometry(const char* kernel, int n_embd) {
     if (!strcmp(kernel, "qkv")) return w13b ? Geo{1, 1} : Geo{1, 6};      // single rows, one workgroup per CU (round 4: 8 KiB chunks; RoPE pairs meet in LDS)
     if (!strcmp(kernel, "wo")) return Geo{1, 6};
     if (!strcmp(kernel, "w13")) return w13b ? Geo{8, 6} : Geo{1, 6};     // single rows of w1 | w3 alternating, one workgroup per CU (the pair meets in LDS)
-    if (!strcmp(kernel, "w2")) return Geo{1, 5};                          // pipelined single rows, one workgroup per CU
+    if (!strcmp(kernel, "w2")) return Geo{1, 8};                          // a workgroup per row, a wave per quarter of it (gemv_quarter_body), one workgroup per CU
     if (!strcmp(kernel, "head")) return w13b ? Geo{8, 2} : Geo{8, 6};
     return Geo{4, 0};
 }

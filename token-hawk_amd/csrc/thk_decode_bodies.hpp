@@ -658,6 +658,83 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         }
     }
 }
+// ---------------------------------------------------------------- quarter-row mat-vec (w2: y = resid + W u, rows of 21.5 / 27 KiB)
+// Round 4.  tools/probes/read_floor_probe.hip: a launch streams 6-8 % faster when a wave's contiguous chunk is 4-8 KiB than when it
+// is a whole w2 row (21.5 KiB for F = 11008).  Here a WORKGROUP owns a row - its four waves take a quarter each (5.5 KiB; quarters
+// are whole half-slots of 32 vectors, the last one is the short one) - and workgroup b takes rows b, b + B, ...: the launch sweeps
+// the matrix front to back in 4-5 KiB pieces.  The quarter sums meet in LDS (qsm[round][wave]) and thread t adds row t's four and the
+// residual after ONE barrier at the end of the kernel (residuals requested at the start).  NR rows are in flight per wave (a ring of
+// NR * NSQ 16-byte loads per lane, slot c of row k + NR requested right behind the multiply of slot c of row k).
+// NS = slot class of the column count (22 | 27 | 8 | 10), NSQ = slots a quarter spans (its last slot may be half or less).
+template <int NS, int NR, int WPB = kWaves>
+__device__ __forceinline__ void gemv_quarter_body(const GemvArgs& a, const int bid, const int nblk) {
+    static_assert(WPB == 4 && NS != 0, "a row is cut into one quarter per wave of a 4-wave workgroup");
+    constexpr int QV = ((NS * 64 + 3) / 4 + 31) / 32 * 32;        // vectors (8 columns) per quarter: whole half-slots
+    constexpr int NSQ = (QV + 63) / 64;
+    constexpr int kRounds = 32;                                  // rows a workgroup may own (launch_gemv_quarter checks)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int C = a.C, nvec = C >> 3;
+    float* xs = smem;
+    float* red = smem + (NS << 9);
+    float* qsm = red + 32;                                        // [kRounds][WPB]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const f4* xlo = reinterpret_cast<const f4*>(xs);
+    const f4* xhi = reinterpret_cast<const f4*>(xs + (NS << 8));
+    const int v0 = wave * QV, v1 = min(v0 + QV, nvec);           // this wave's vectors of every row
+    THK_STAMP(a.trace, bid, 0);
+    ProCopy<NS, WPB> pro;
+    pro.issue(a);
+    __builtin_amdgcn_sched_barrier(0);
+    const int rows = a.R;
+    const int t_row = bid + (int)threadIdx.x * nblk;             // the row thread t finishes (t < rounds)
+    const float my_resid = a.resid[min(t_row, rows - 1)];
+    const uint16_t* W = a.W[0];
+    auto row_ptr = [&](int r) -> const h8* { return reinterpret_cast<const h8*>(W + (size_t)min(r, rows - 1) * C); };
+    h8 ring[NR][NSQ];
+    auto slot_vec = [&](int c) -> int { return v0 + c * 64 + lane; };
+    auto load_slot = [&](const h8* rp, int c, h8& dst) { dst = __builtin_nontemporal_load(rp + min(slot_vec(c), v1 - 1)); };
+    int r = bid;                                                 // row of ring position 0
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const h8* rp = row_ptr(r + k * nblk);
+#pragma unroll
+        for (int c = 0; c < NSQ; ++c) load_slot(rp, c, ring[k][c]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pro.finish(a, xs, red, NS, bid);
+    THK_STAMP(a.trace, bid, 1);
+    int round = 0;
+    for (; r < rows; r += NR * nblk) {
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int rk = r + k * nblk;                         // wave-uniform
+            // past the matrix the refills go to row 0 (the same 22 KiB for every workgroup: L2 hits); a branch around the requests would
+            // cost a vmcnt(0) at its join
+            const h8* rpn = rk + NR * nblk < rows ? row_ptr(rk + NR * nblk) : reinterpret_cast<const h8*>(W);
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < NSQ; ++c) {
+                const int v = slot_vec(c);
+                const f4 xl = xlo[min(v, (NS << 6) - 1)], xh = xhi[min(v, (NS << 6) - 1)];
+                const float p = dot8(ring[k][c], xl, xh, 0.f);
+                acc += v < v1 ? p : 0.f;                         // a quarter's last slot(s) reach past its end (the last quarter is the short one)
+                __builtin_amdgcn_sched_barrier(0);
+                load_slot(rpn, c, ring[k][c]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0 && rk < rows) qsm[(round + k) * WPB + wave] = acc;
+        }
+        round += NR;
+    }
+    THK_STAMP(a.trace, bid, 2);
+    __syncthreads();
+    if ((int)threadIdx.x < kRounds && t_row < rows) {
+        const float* q = qsm + threadIdx.x * WPB;
+        a.y[t_row] = my_resid + ((q[0] + q[1]) + (q[2] + q[3]));    // K11 th.cpp:2136-2147 on top of K1
+    }
+    THK_STAMP(a.trace, bid, 3);
+}
 // ---------------------------------------------------------------- attention (decode)
 // grid = H * nsplit * VS blocks; block (h, s, vh) owns positions [s*tc, (s+1)*tc) of head h and, when VS == 2, half vh of the
 // head's V columns.

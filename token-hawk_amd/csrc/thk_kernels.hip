@@ -162,6 +162,47 @@ static hipError_t launch_gemv_pe(int nru, const GemvArgs& a, int grid, bool nt, 
     }
 }
 
+// quarter-row form of y = resid + W x (gemv_quarter_body; tunable gemv_variant_w2 = 8 | 9: one | two rows in flight per wave)
+template <int NS, int NR>
+__global__ __launch_bounds__(kWaves * 64) void gemv_quarter_kernel(const uint16_t* W0, const float* x, const float* resid, float* y, int C, int R, int nblk, const GemvArgs a) {
+    GemvArgs b = a;
+    b.W[0] = W0; b.x = x; b.resid = resid; b.y = y; b.C = C; b.R = R;
+    gemv_quarter_body<NS, NR>(b, blockIdx.x, nblk);
+}
+template <int NS, int NR>
+static hipError_t launch_gemv_quarter_k(const GemvArgs& a, int grid, hipStream_t st) {
+    const size_t smem = (size_t)NS * 512 * 4 + 128 + 512;
+    auto kn = gemv_quarter_kernel<NS, NR>;
+    static size_t attr_set[kMaxDevices] = {};
+    if (smem > 48 * 1024) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+        if (smem > attr_set[dev]) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(kn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            attr_set[dev] = smem;
+        }
+    }
+    hipLaunchKernelGGL(kn, dim3(grid), dim3(kWaves * 64), smem, st, a.W[0], a.x, a.resid, a.y, a.C, a.R, grid, a);
+    return hipGetLastError();
+}
+// rows per workgroup <= 32 (the LDS slots of the quarter sums); false = the shape / geometry has no quarter-row form
+bool gemv_quarter_ok(int C, int R, int grid) {
+    return (C == 4096 || C == 5120 || C == 11008 || C == 13824) && grid > 0 && (long)grid * 32 >= R;
+}
+hipError_t launch_gemv_quarter(int rows_in_flight, const GemvArgs& a, int grid, hipStream_t st) {
+    if (!gemv_quarter_ok(a.C, a.R, grid) || !a.resid) return hipErrorInvalidValue;
+    const bool two = rows_in_flight >= 2;
+    switch (a.C) {
+        case 4096: return two ? launch_gemv_quarter_k<8, 2>(a, grid, st) : launch_gemv_quarter_k<8, 1>(a, grid, st);
+        case 5120: return two ? launch_gemv_quarter_k<10, 2>(a, grid, st) : launch_gemv_quarter_k<10, 1>(a, grid, st);
+        case 11008: return two ? launch_gemv_quarter_k<22, 2>(a, grid, st) : launch_gemv_quarter_k<22, 1>(a, grid, st);
+        default: return two ? launch_gemv_quarter_k<27, 2>(a, grid, st) : launch_gemv_quarter_k<27, 1>(a, grid, st);
+    }
+}
+
 int gemv_rows_per_group(int C, int epi, int nru) {
     int NR, U; gemv_variant(C, epi, nru, &NR, &U, nullptr);
     return NR;

@@ -83,6 +83,10 @@ struct AttnArgs {
 int gemv_rows_per_group(int C, int epi, int nru);
 void gemv_variant(int C, int epi, int nru, int* NR, int* U, int* pipe);
 hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, bool nt, hipStream_t st);
+// y = resid + W x with a WORKGROUP per row (its four waves take a quarter of the columns each; round 4, thk_decode_bodies.hpp):
+// rows_in_flight 1 | 2 per wave; gemv_quarter_ok = the shape and workgroup count have this form (<= 32 rows per workgroup)
+bool gemv_quarter_ok(int C, int R, int grid);
+hipError_t launch_gemv_quarter(int rows_in_flight, const GemvArgs& a, int grid, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_combine(const float* part_o, const float* part_ml, float* out, int H, int D, int nsplit, hipStream_t st);
 hipError_t launch_rms_norm(float* x, int rows, int N, hipStream_t st);

@@ -114,7 +114,10 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.y = (i == nl - 1 && !(m->flags & THK_STAGE_HEAD)) ? sb.hidden_out : m->x;
             a.trace = trace_slab();
             MARK("w2_resid");
-            if (m->skip_kernel != 5) HIPCHK(ctx, launch_gemv(GEMV_PRO_COPY, GEMV_EPI_RESID, m->var_w2, a, m->grid_w2, nt, st));
+            if (m->skip_kernel != 5) {
+                if (m->var_w2 >= 8 && gemv_quarter_ok(F, E, m->grid_w2)) HIPCHK(ctx, launch_gemv_quarter(m->var_w2 - 7, a, m->grid_w2, st));     // a workgroup per row (variants 8, 9)
+                else HIPCHK(ctx, launch_gemv(GEMV_PRO_COPY, GEMV_EPI_RESID, m->var_w2, a, m->grid_w2, nt, st));
+            }
         }
     }
     if (m->flags & THK_STAGE_HEAD) {   // final norm -> lm-head -> greedy pick   (th-llama.cpp:240-268, :826-838)
