@@ -472,6 +472,9 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     };
 
     THK_STAMP(a.trace, bid, 0);
+    // EPI_ROPE_KV: the position is requested with the kernel's first instruction (its pointer arrives preloaded, gemv_kernel) and
+    // first needed behind finish(): by then the scalar load has returned and finish()'s own lgkmcnt waits (LDS) find nothing pending
+    if (EPI == EPI_ROPE_KV && (PIPE || NR == 1)) { pos_pipe = *a.pos_ptr; __builtin_amdgcn_sched_barrier(0); }
     // --- memory traffic is ordered: activation loads, then the wave's first weight batch (weights
     // do not depend on the activations), then the prologue math while the weights are in flight.
     int g = wave_global;
@@ -487,7 +490,7 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
     load_batch(rp0, 0, w0);
     __builtin_amdgcn_sched_barrier(0);
     if (NS != 0 && PRO == PRO_ATTN) pro.pin();       // (the other prologues keep their order without it, and lose ~30 instructions of head start with it)
-    if ((PIPE || NR == 1) && EPI == EPI_ROPE_KV) pos_pipe = a.pos_ptr ? *a.pos_ptr : a.pos_val;
+    pro.finish(a, xs, red, ns, bid);
     if (EPI == EPI_ROPE_KV && NR == 1) {
         static_assert(EPI != EPI_ROPE_KV || NR != 1 || WPB == 4, "RoPE pairs are waves 0|1 and 2|3 of a 4-wave workgroup");
         const int t = threadIdx.x, r0 = bid * WPB + 2 * (t & 1) + (t >> 1) * total_waves;      // even: bid * 4 and total_waves are
@@ -498,7 +501,6 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         sr_cs = *reinterpret_cast<const float2*>(a.rope_tab + ((size_t)pos_pipe * (a.D >> 1) + (j >> 1)) * 2);
         sr_r0 = mine ? r0 : -1;
     }
-    pro.finish(a, xs, red, ns, bid);
     THK_STAMP(a.trace, bid, 1);
 
     if constexpr (PIPE) {

@@ -18,6 +18,7 @@
 //   * Positions/tokens are read from device memory so one captured hipGraph
 //     serves every token.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,12 +37,25 @@ namespace thk {
 // the members of a by-value struct, so everything the code needs before its first `s_waitcnt lgkmcnt` - the weight bases, the
 // activation and gain vectors, the column / group / row counts and the grid size (gridDim.x is an implicit argument at the END of
 // the segment) - travels as leading scalars and the rest of the argument block follows as the struct it always was.
+// the argument slot behind the gain pointer: (C | n_groups << 32), or - EPI_ROPE_KV, where both follow from E - the position pointer
+// (a specialisation on the plain integer, not std::conditional on `EPI == EPI_ROPE_KV`: the comparison with an unnamed enumerator is
+// mangled into the kernel's name, differently by the host and the device pass - "cannot find symbol" at the first launch)
+template <int EPI> struct GemvSlotT { typedef unsigned long long type; };
+template <> struct GemvSlotT<2> { typedef const int32_t* type; };
+static_assert(GEMV_EPI_ROPE_KV == 2, "GemvSlotT<2> is the RoPE epilogue");
+template <int EPI> using GemvSlot = typename GemvSlotT<EPI>::type;
 template <int NR, int U, int NS, int PRO, int EPI, bool NT, int NSP, bool PIPE, int WPB>
 __global__ __launch_bounds__(WPB * 64) void gemv_kernel(const uint16_t* W0, const uint16_t* W1, const uint16_t* W2, const float* x, const float* gain,
-                                                        int C, int n_groups, int R_or_E, int nblk, const GemvArgs a) {
+                                                        GemvSlot<EPI> cg, int R_or_E, int nblk, const GemvArgs a) {
     GemvArgs b = a;
-    b.W[0] = W0; b.W[1] = W1; b.W[2] = W2; b.x = x; b.gain = gain; b.C = C; b.n_groups = n_groups;
+    b.W[0] = W0; b.W[1] = W1; b.W[2] = W2; b.x = x; b.gain = gain;
+    if constexpr (EPI != EPI_ROPE_KV) { b.C = (int)(unsigned)cg; b.n_groups = (int)(unsigned)(cg >> 32); }
     if (EPI == EPI_ROPE_KV) b.E = R_or_E; else b.R = R_or_E;
+    // EPI_ROPE_KV (wq | wk | wv are [E, E]: C == E, n_groups == 3 E / NR): the two slots carry the POSITION POINTER instead, so the
+    // kernel can request the position with its first instruction - as a struct member its address was a scalar load away, and the
+    // prologue's LDS reduction then waited for the position's round trip to memory (same counter), staging the activation vector
+    // 2.8 us after entry instead of 1.3 us (tools/step_trace.py)
+    if constexpr (EPI == EPI_ROPE_KV) { b.pos_ptr = cg; b.C = R_or_E; b.n_groups = 3 * R_or_E / NR; }
     // PRO_ATTN (wo: one matrix) has no use for the activation / gain / W1 slots: the split partials and the head size travel there, so
     // the prologue's first requests need no scalar load of a struct member (and no wait for one) either
     if (PRO == PRO_ATTN) {
@@ -83,7 +97,14 @@ static hipError_t launch_gemv_k(const GemvArgs& a, int grid, bool nt, hipStream_
         const unsigned long long magic = ((1ull << 32) + (unsigned)a.D - 1) / (unsigned)a.D;
         w1 = reinterpret_cast<const uint16_t*>(magic | ((unsigned long long)a.D << 32));
     }
-    hipLaunchKernelGGL(kn, dim3(grid), dim3(WPB * 64), smem, st, a.W[0], w1, a.W[2], PRO == PRO_ATTN ? a.part_o : a.x, PRO == PRO_ATTN ? a.part_ml : a.gain, a.C, a.n_groups,
+    GemvSlot<EPI> cg;
+    if constexpr (EPI == EPI_ROPE_KV) {       // see gemv_kernel
+        if (!a.pos_ptr || a.C != a.E || a.n_groups != 3 * a.E / NR) return hipErrorInvalidValue;
+        cg = a.pos_ptr;
+    } else {
+        cg = (unsigned long long)(unsigned)a.C | ((unsigned long long)(unsigned)a.n_groups << 32);
+    }
+    hipLaunchKernelGGL(kn, dim3(grid), dim3(WPB * 64), smem, st, a.W[0], w1, a.W[2], PRO == PRO_ATTN ? a.part_o : a.x, PRO == PRO_ATTN ? a.part_ml : a.gain, cg,
                        EPI == EPI_ROPE_KV ? a.E : a.R, grid, a);
     return hipGetLastError();
 }
