@@ -332,11 +332,14 @@ int thk_peer_destroy(thk_peer* p);
  * rebuilding.  Decode knobs must be set before thk_model_finalize; prefill knobs are read
  * per call.  Unknown names return THK_ERR_NOTFOUND.
  *   decode : gemv_blocks_per_cu; gemv_bpc_{qkv,wo,w13,w2,head} and gemv_variant_{...}
- *            (-1 = per-shape default, 0 = generic, >0 explicit); attn_splits (1|2|4|8);
+ *            (-1 = per-shape default, 0 = generic, >0 explicit; variants 0-4 batch loops, 5-7 software-pipelined loops,
+ *            1 | 6 = single rows - for qkv and w13 the RoPE / SwiGLU pair then meets in LDS -, w2 only: 8 | 9 = a workgroup
+ *            per row with one | two rows in flight per wave); gemv_grid_{...} (> 0: that many workgroups, whatever
+ *            gemv_bpc_* says); attn_splits (1|2|4|8);
  *            attn_waves (4|8); use_graph; kv_f16 (1 = K/V caches stored as binary16, rounded RNE at the append: half the
  *            KV bytes, thk_model_bytes_per_token then counts s_kv = 2; default 0 = f32 like the reference,
  *            th-llama-loader.cpp:335); engine (1 = persistent loader/consumer launch per step when the
- *            shape allows, 0 = launches); experiments kept off: fuse_attn_wo, attn_combine;
+ *            shape allows, 0 = launches); attn_vsplit, attn_tc_dyn, fold_finish, fold_embed;
  *            measure_skip_kernel (1..6: that kernel is not launched -- bench.py's marginal-cost
  *            measurement; results are garbage; REFUSED unless the environment has THK_MEASURE_HOOKS=1)
  *   prefill: prefill_blocks_{qkv,wo,w13,w2} (workgroups per GEMM launch, <= 256);

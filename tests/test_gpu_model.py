@@ -312,6 +312,29 @@ def test_full_width_layers_vs_oracle(thk, orc, ctx, E, H, L, name, variant):
     m.close(); om.close()
 
 
+def test_single_row_forms_fall_back_when_a_wave_would_own_too_many_rows(thk, orc, ctx):
+    """The single-row forms of qkv / w13 keep their pair sums in 32 LDS rounds per wave and the quarter-row w2 in 32 rows per
+    workgroup: with a grid too small for that (8 workgroups here) finalize takes the row-pair / whole-row forms instead of failing
+    at the first launch - same logits as the default geometry within the tolerance."""
+    shape = thk.ModelShape(n_embd=4096, n_head=32, n_layer=1)
+    oshape = orc.ModelShape(n_embd=4096, n_head=32, n_layer=1)
+    tun = {"gemv_grid_qkv": 8, "gemv_grid_w13": 8, "gemv_grid_w2": 8}
+    old = {k: ctx.get_tunable(k) for k in tun}
+    for k, v in tun.items():
+        ctx.set_tunable(k, v)
+    try:
+        m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    finally:
+        for k, v in old.items():
+            ctx.set_tunable(k, v)
+    om = orc.OracleModel(oshape); om.fill_synthetic()
+    for i, t in enumerate([1, 77, 4242]):
+        lg, _ = m.eval([t], i); lo, _ = om.eval(t, i, flags=0)
+        assert np.abs(lg - lo).max() < LOGIT_TOL, i
+        assert int(lg.argmax()) == orc.greedy(lo)
+    m.close(); om.close()
+
+
 def test_7b_full_model_properties(thk, ctx):
     """Full 7B (13.2 GB of synthetic f16 weights) at T=512 — size-independent properties:
     determinism, hold-position idempotence, device loop == eval path greedy tokens,

@@ -239,8 +239,13 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->var_qkv = resolve_variant(ctx, "qkv", (int)E); m->var_wo = resolve_variant(ctx, "wo", (int)E);
     m->var_w13 = resolve_variant(ctx, "w13", (int)E); m->var_w2 = resolve_variant(ctx, "w2", (int)E); m->var_head = resolve_variant(ctx, "head", (int)E);
     m->grid_qkv = grid_for(ctx, "gemv_bpc_qkv", (int)(3 * E / gemv_rows_per_group((int)E, GEMV_EPI_ROPE_KV, m->var_qkv)), (int)E);     // row pairs, or single rows (variants 1, 6)
+    // the single-row forms keep their pair sums in 32 LDS rounds per wave (gemv_body): a geometry with more rows per wave than that
+    // (few CUs, a small explicit grid) takes the row-pair form instead of failing at the first launch
+    auto fits_single_rows = [&](int var, int epi, int64_t rows, int grid) { return gemv_rows_per_group((int)E, epi, var) != 1 || (int64_t)grid * kWaves * 32 >= rows; };
+    if (!fits_single_rows(m->var_qkv, GEMV_EPI_ROPE_KV, 3 * E, m->grid_qkv)) { m->var_qkv = 5; m->grid_qkv = grid_for(ctx, "gemv_bpc_qkv", (int)(3 * E / 2), (int)E); }
     m->grid_wo = grid_for(ctx, "gemv_bpc_wo", (int)((E + gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo) - 1) / gemv_rows_per_group((int)E, GEMV_EPI_RESID, m->var_wo)), (int)E);
     m->grid_w13 = grid_for(ctx, "gemv_bpc_w13", (int)(2 * F / gemv_rows_per_group((int)E, GEMV_EPI_SWIGLU, m->var_w13)), (int)E);     // (w1, w3) row pairs, or single rows (variants 1, 6)
+    if (!fits_single_rows(m->var_w13, GEMV_EPI_SWIGLU, 2 * F, m->grid_w13)) { m->var_w13 = 5; m->grid_w13 = grid_for(ctx, "gemv_bpc_w13", (int)F, (int)E); }
     m->grid_w2 = grid_for(ctx, "gemv_bpc_w2", (int)((E + gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2) - 1) / gemv_rows_per_group((int)F, GEMV_EPI_RESID, m->var_w2)), (int)E);
     m->grid_head = grid_for(ctx, "gemv_bpc_head", (int)((V + gemv_rows_per_group((int)E, GEMV_EPI_HEAD, m->var_head) - 1) / gemv_rows_per_group((int)E, GEMV_EPI_HEAD, m->var_head)), (int)E);
     // working buffers
