@@ -158,6 +158,9 @@ int main(int argc, char** argv) {
     const int LAYERS = 32;
     struct Kind { const char* name; size_t bytes; int blocks, threads, G; double product_us; };
     const Kind kinds[6] = {
+        // workgroups / threads / chunk (KiB a wave reads before it jumps) / rocprofv3 us of the product WHEN THE PROBE WAS WRITTEN (row pairs for
+        // qkv and w13, whole w2 rows, 3 / 4 / 2 workgroups per CU: profiles/r04_kernel_stats_final_binary.csv).  The product the probe
+        // led to reads 8 KiB chunks at one workgroup per CU: 16.11 / 5.48 / 7.30 / 27.09 / 14.90 / 41.37 us (r04_kernel_stats_final.csv)
         {"norm_qkv_rope_kv", 3 * E * E * 2, 768, 256, 16, 17.11}, {"attn_decode", 2 * T * E * 4, 128, 512, 16, 5.49}, {"attn_wo_resid", E * E * 2, 256, 256, 8, 8.41},
         {"norm_w13_swiglu", 2 * E * F * 2, 1024, 256, 16, 27.55}, {"w2_resid", E * F * 2, 512, 256, 43, 15.98}, {"norm_lmhead", V * E * 2, 2048, 256, 8, 41.60}};
     std::vector<Launch> step;
@@ -172,7 +175,7 @@ int main(int argc, char** argv) {
     CHECK(hipStreamSynchronize(st));
     printf("# read_floor_probe on %s (%d CUs): LLaMA-7B decode step at T = 512 as %zu bare streaming reads, %.3f GB per step, %d replays x 5, median\n",
            prop.gcnArchName, CU, step.size(), step_bytes / 1e9, replays);
-    printf("# product on the same pool of boxes (bench.py, rocprofv3): 2.43-2.46 ms per step = 5.59-5.66 TB/s = 69.9-70.8 %% of 8 TB/s\n");
+    printf("# product on the same pool of boxes (bench.py): 2.43-2.46 ms per step when the probe was written, 2.31-2.34 ms after its tables were built into the kernels (DESIGN.md 4.8)\n");
     auto report = [&](const char* what, double ms) { printf("%-76s %8.4f ms/step  %6.3f TB/s  %5.1f %%\n", what, ms, step_bytes / ms / 1e9, step_bytes / ms / 1e9 / 8.0 * 100); fflush(stdout); };
     char buf[160];
 
