@@ -398,7 +398,7 @@ def choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, log_li
             teardown()
             continue
         try:
-            rep = drv.validate_handoff(reps=16, sync=lambda: torch.cuda.synchronize(dev))
+            rep = drv.validate_handoff(reps=16, sync=lambda: torch.cuda.synchronize(dev), fence=lambda: agree(True))   # fence: the mailbox has no back-pressure of its own
             if getattr(stage, "peer", None) is not None:
                 stage.peer_check()
             ok, why = rep.ok, "; ".join(rep.errors[:2])

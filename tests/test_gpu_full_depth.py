@@ -13,6 +13,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 1e-3   # north_star: logits within 1e-3
+PREFILL_TOKENS = 128   # BASELINE config C3
 
 
 def _mem_available():
@@ -71,8 +72,26 @@ def _full_depth(thk, orc, ctx, name, early, T):
         mf.close(); mf = None
         # the rest of the prompt: n_past = early .. T-2 (the cache fill bench.py does), then the timed position n_past = T-1
         m.eval(prompt[early:T - 1], early, want_logits=False)
+        lo_pf = ho_pf = None
         for i in range(early, T - 1):
-            om.eval(int(prompt[i]), i, want_logits=False, flags=0)
+            if i == PREFILL_TOKENS - 1:
+                lo_pf, ho_pf = om.eval(int(prompt[i]), i, flags=0)       # what a 128-token prefill must reproduce
+            else:
+                om.eval(int(prompt[i]), i, want_logits=False, flags=0)
+        # config C3 at full depth against the ORACLE (not against the HIP decode path): the first 128 tokens of the very prompt through
+        # the MFMA prefill path (GEMMs with the in-launch split-K combine, MFMA attention) on a second HIP model - logits and the final
+        # hidden state at position 127 (semantics th-llama.cpp:464-660 with the batch branch :307-311)
+        mp = thk.Model(ctx, shape); mp.fill_synthetic(); mp.finalize()
+        try:
+            lp = mp.prefill(prompt[:PREFILL_TOKENS], 0)
+            hp = mp.debug_buffer("x")
+        finally:
+            mp.close()
+        dpl, dph = float(np.abs(lp - lo_pf).max()), float(np.abs(hp - ho_pf).max())
+        print(f"\n[full-depth {name}] {PREFILL_TOKENS}-token prefill vs oracle at position {PREFILL_TOKENS - 1}: max |dlogit| {dpl:.3e} (hidden {dph:.3e})")
+        assert dpl < LOGIT_TOL, (name, "prefill", dpl)
+        assert dph < LOGIT_TOL * max(1.0, float(np.abs(ho_pf).max())), (name, "prefill", dph)
+        assert int(lp.argmax()) == orc.greedy(lo_pf)
         lg, hid = m.eval([int(prompt[T - 1])], T - 1, want_hidden=True)
         lo, ho = om.eval(int(prompt[T - 1]), T - 1, flags=0)
         dl, dh = float(np.abs(lg - lo).max()), float(np.abs(hid - ho).max())

@@ -168,7 +168,7 @@ struct PrefillPlan {
 };
 PrefillPlan prefill_plan(int M, int R, int nmat, int C, int G /* workgroups; 0 = default (256) */, int tile_rows /* 128 | 256 (default) */);
 // ssq != NULL (with a gain): DEFERRED norm - the image holds x * 2^k * gain (2^k = the power of two below 1/rms), the row's sum of squares is added
-// to ssq[token] (2^-24 fixed point, must be zero before), and the reducer of the GEMM that consumes the image applies 1/rms / 2^k
+// to ssq[token] (2^-32 fixed point, must be zero before), and the reducer of the GEMM that consumes the image applies 1/rms / 2^k
 // (launch_prefill_reduce_qkv / _swiglu with ssq = ssq_scale = this array)
 hipError_t launch_prefill_ximg(const float* X, const float* gain_or_null, int M, int C, void* ximg, hipStream_t st, unsigned long long* ssq = nullptr);
 // X += sum of the partial tiles (residual add), and the deferred-norm image of the result for the next GEMM (x * gain, sum of squares -> ssq)

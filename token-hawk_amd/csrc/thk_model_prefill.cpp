@@ -54,7 +54,7 @@ static int prefill_workspace(thk_model* m, PrefillBufs* b) {
         img_f = std::max(img_f, pl[3].ximg_bytes);
     }
     const size_t imgE = align256(img_e), imgF = align256(img_f), part = align256(4 * part_floats);
-    const size_t ssq_bytes = align256((size_t)(m->l1 - m->l0) * 2 * 128 * 8);      // deferred norm: sum of squares per (layer, norm, token), 2^-24 fixed point
+    const size_t ssq_bytes = align256((size_t)(m->l1 - m->l0) * 2 * 128 * 8);      // deferred norm: sum of squares per (layer, norm, token), 2^-32 fixed point
     const size_t bytes = 3 * per + 1024 + imgE + imgF + part + ssq_bytes;
     if (m->prefill_ws_bytes < bytes) {
         if (m->prefill_ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(m->prefill_ws)); m->prefill_ws = nullptr; }

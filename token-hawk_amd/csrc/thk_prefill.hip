@@ -376,7 +376,7 @@ __device__ __forceinline__ void ximg_store8(char* img, int MT, int tok, int col,
 // Deferred RMSNorm (round 4).  x -> (x * inv) * g -> W is computed as inv * (W (x * g)): the per-token scalar inv = 1/sqrt(mean
 // x^2 + eps) moves to the OUTPUT side of the GEMM, so the kernel that produces x (a reducer with the residual add) can write the
 // hi/lo image of x * g itself - it does not have to know the whole row's sum of squares, which lives in other workgroups - and
-// the norm -> image launch between two GEMMs disappears.  The sum of squares travels as 64-bit FIXED POINT (2^-24 units): every
+// the norm -> image launch between two GEMMs disappears.  The sum of squares travels as 64-bit FIXED POINT (2^-32 units): every
 // producer workgroup adds its share with an integer atomic, so the total does not depend on the order of arrival (bit-repeatable
 // results, no float atomics), and the consuming reducer reads one word per token.
 // The image still has to hold O(1) values: the lo half of the hi/lo split is an f16 too, and for |v| below ~0.1 it falls into
@@ -384,11 +384,12 @@ __device__ __forceinline__ void ximg_store8(char* img, int MT, int tok, int col,
 // producer multiplies by a POWER OF TWO near the token's 1/rms - exact, no rounding - taken from a sum of squares it CAN know:
 // the token's previous norm input (the residual stream moves slowly), or the row's own for the first layer; the consumer divides
 // it out again (it reads the same word and derives the same power of two).
-constexpr float kSsqScale = 16777216.f;      // 2^24
+constexpr float kSsqScale = 4294967296.f;    // 2^32: a 64-bit word holds sums up to 2^32, and a workgroup's share of a row with rms 1e-4 still has four digits
+                                             // (2^24, rounds 3-4, left percent-level errors in 1/rms for residual streams of rms < 1e-3; advisor, round 4)
 __device__ __forceinline__ unsigned long long ssq_fixed(float ss) { return (unsigned long long)__float2ull_rn(ss * kSsqScale); }
 __device__ __forceinline__ void ssq_add(unsigned long long* ssq, int tok, float ss) { atomicAdd(ssq + tok, ssq_fixed(ss)); }
 __device__ __forceinline__ float ssq_inv_of(unsigned long long v, int C) {
-    const float ss = (float)((double)v * (1.0 / 16777216.0));
+    const float ss = (float)((double)v * (1.0 / 4294967296.0));
     return 1.0f / sqrtf(ss / (float)C + 1e-6f);
 }
 __device__ __forceinline__ float ssq_inv(const unsigned long long* ssq, int tok, int C) { return ssq_inv_of(ssq[tok], C); }

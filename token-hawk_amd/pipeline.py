@@ -259,12 +259,18 @@ class PipelineDriver:
         i_prev = j - ((r - 1) % N)                       # item the previous rank just finished
         self._xfer(i_done % S if live(i_done) else None, i_prev % S if live(i_prev) else None)
 
-    def validate_handoff(self, reps: int = 16, sync=None) -> HandoffReport:
+    def validate_handoff(self, reps: int = 16, sync=None, fence=None) -> HandoffReport:
         """Before anything is timed: every rank writes a known pattern into each sequence's output slot (hidden state, or token on
         the last stage), the ring hands all of them over on the transport in use, and every receiver checks what arrived against the
         pattern its predecessor must have written.  Then `reps` bare hand-offs per sequence are timed (every rank sends and receives in
         each, as in a steady micro-step) -> handoff_us.  Clobbers hidden_in / token: call it before the sequences are set up.
-        sync: callable that waits for the device (None: CPU stage).  All ranks must call it together."""
+        sync: callable that waits for the device (None: CPU stage).  All ranks must call it together.
+        fence: callable that is a CROSS-RANK barrier (e.g. an all-reduce on the control plane).  The mailbox transport has no
+        back-pressure of its own - a (sequence, kind) slot may only be rewritten after its reader has consumed it, which the ring
+        schedule guarantees by its S-in-flight flow control and this loop does not - so every round of the check and every timed
+        repetition ends with sync + fence: a rank a few ms ahead can then never overwrite a payload its successor is still checking
+        (a healthy transport would report a false failure, or the timing loop would copy torn payloads).  Timed: the hand-offs
+        only, not the fences.  None with more than one rank: torch.distributed.barrier() when a process group exists."""
         st, r, N, S = self.stage, self.rank, self.world, self.S
         if not self.ring:
             return HandoffReport(True, 0, 0.0)
@@ -276,6 +282,15 @@ class PipelineDriver:
 
         def token_code(rank, s, rep):
             return 7 + 100 * rank + 10 * s + rep
+
+        if fence is None and self.world > 1:
+            fence = dist.barrier if (dist is not None and dist.is_available() and dist.is_initialized()) else None
+
+        def settle():                                    # everything this rank sent has landed AND every rank has finished reading
+            if sync is not None:
+                sync()
+            if fence is not None:
+                fence()
 
         errors, checked = [], 0
         for rep in range(2):                             # twice: the second round proves nothing stale from the first is read
@@ -299,15 +314,18 @@ class PipelineDriver:
                         bad = int((got != want).sum())
                         errors.append(f"rank {r} seq {s} round {rep}: {bad} of {E} hidden-state words differ from rank {self.prev}'s pattern")
                 checked += 1
-        if sync is not None:
-            sync()
-        t0 = time.perf_counter()
+            settle()                                     # nobody starts round 2 (or the timing) while a neighbour still checks round 1
+        spent = 0.0
         for k in range(reps):
+            t0 = time.perf_counter()
             for s in range(S):
                 self._xfer(s, s)
-        if sync is not None:
-            sync()
-        us = (time.perf_counter() - t0) / max(1, reps * S) * 1e6
+            if sync is not None:
+                sync()
+            spent += time.perf_counter() - t0
+            if fence is not None:
+                fence()                                  # a slot is rewritten only after every rank has taken the previous payload
+        us = spent / max(1, reps * S) * 1e6
         return HandoffReport(not errors, checked, us, errors)
 
     def _micro(self, n_micro: int, lo: int, hi, advance: bool, forced_tokens=None) -> int:
