@@ -299,6 +299,97 @@ def extra_decode_ctx2048(thk, ctx, stream, torch, kv_f16, steps=60, warmup=10):
         m.close()
 
 
+def host_lib():
+    """libthk_host.so (the TokenHawk host API over libthk: loader, tokenizer, sampler, do_inference) with the test hooks' signatures."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(ROOT, "token-hawk_amd", "libthk_host.so"))
+    lib.thh_last_error.restype = C.c_char_p
+    lib.thh_make_synthetic.restype = C.c_int64
+    lib.thh_make_synthetic.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float]
+    lib.thh_set_sampler.argtypes = [C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float]
+    lib.thh_set_step_limit.argtypes = [C.c_int64, C.c_int64]
+    lib.thh_collect_stats.argtypes = [C.c_int64, C.c_int]
+    lib.thh_stats.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+    lib.thh_do_inference.argtypes = [C.c_int64, C.c_char_p, C.c_void_p, C.c_char_p, C.c_int]
+    lib.thh_set_greedy_device_loop.argtypes = [C.c_int64, C.c_int]
+    lib.thh_set_device_topk.argtypes = [C.c_int64, C.c_int]
+    lib.thh_free.argtypes = [C.c_int64]; lib.thh_reset.argtypes = [C.c_int64]
+    lib.thh_tokenize.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    return lib
+
+
+def host_api_generate(lib, h, prompt, n_prompt, n_new, timed=True):
+    """One th::do_inference call (th-llama.cpp:111-238 mirrored in host/thk_llama.cpp) limited to n_prompt + n_new steps; returns
+    (text, n_tokens_emitted, stats dict | None).  The generation rate counts the steps AFTER the prompt's last one."""
+    import ctypes as C
+    lib.thh_reset(h)
+    lib.thh_set_step_limit(h, n_prompt + n_new)
+    lib.thh_collect_stats(h, 1 if timed else 0)
+    n_past = C.c_int32(); text = C.create_string_buffer(1 << 16)
+    t0 = time.perf_counter()
+    n_tok = lib.thh_do_inference(h, prompt, C.byref(n_past), text, len(text))
+    wall = time.perf_counter() - t0
+    if not timed:
+        return text.value, n_tok, None
+    out8 = (C.c_double * 8)(); ends = (C.c_double * 1024)()
+    n_steps = lib.thh_stats(h, out8, ends, 1024)
+    ends = np.array(ends[:n_steps])
+    gen = ends[n_prompt - 1:]                                   # end of the prompt's last step (= first generated token) .. end of the last step
+    st = {"steps": n_steps, "n_past_end": int(n_past.value), "tokens_emitted": n_tok, "end_to_end_s": round(wall, 4)}
+    if len(gen) >= 2:
+        st["gen_tokens"] = len(gen) - 1
+        st["gen_tok_s"] = round((len(gen) - 1) / (gen[-1] - gen[0]), 2)
+        st["gen_ms_per_token"] = round((gen[-1] - gen[0]) / (len(gen) - 1) * 1e3, 4)
+    n_eval, n_topk, n_rb = int(out8[4]), int(out8[5]), int(out8[6])
+    if n_eval:
+        st["per_token_us"] = {"step_replay_plus_topk_kernel_one_sync" if n_topk else "step_replay_and_sync": round(out8[0] / n_eval * 1e6, 1),
+                              "host_softmax_top_p_draw": round(out8[3] / n_eval * 1e6, 1),
+                              "full_logits_readbacks": n_rb, "evals": n_eval,
+                              "note": "thk_model_eval_topk: graph replay, top-k kernel behind it on the stream, k x 8 B written by the kernel into host-mapped memory, one synchronisation"
+                                      if n_topk else "thk_model_eval with the 4 * n_vocab-byte read-back"}
+    return text.value, n_tok, st
+
+
+def extra_host_api(thk, ctx, n_new=128):
+    """What a TokenHawk user gets per token behind the kept host API: th::do_inference on the synthetic 7B through libthk_host.so, a
+    32-token prompt fed one token per step as the reference does (th-llama.cpp:15), then n_new generated tokens - with the reference's
+    default STOCHASTIC sampler (temp 0.8, top-k 40, top-p 0.95, th-llama.cpp:719-724: single-step graph replay + device top-k + k x 8 B
+    read-back + host softmax / draw per token) and with greedy sampling (device-resident loop, 4-byte read-backs per 8 tokens).  The
+    reference's own published figure is this end-to-end rate (README.md:67-76: 37 tk/s on a 4090)."""
+    import ctypes as C
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ggjt", os.path.join(ROOT, "tests", "ggjt.py"))
+    ggjt = importlib.util.module_from_spec(spec); spec.loader.exec_module(ggjt)
+    lib = host_lib()
+    shape = thk.LLAMA_7B
+    words, scores = ggjt.toy_vocab(shape.n_vocab)
+    blob = b"".join(words); lens = np.array([len(w) for w in words], np.int32)
+    hp6 = np.array([shape.n_vocab, shape.n_embd, shape.n_mult, shape.n_head, shape.n_layer, 512], np.int32)
+    prompt = b"012345678901234567890123456789"                # no merges in the toy vocabulary: BOS + ' ' + 30 byte tokens = 32
+    ids = np.zeros(256, np.int32)
+    n_prompt = lib.thh_tokenize(blob, lens.ctypes.data, scores.ctypes.data, shape.n_vocab, b" " + prompt, len(prompt) + 1, 1, ids.ctypes.data, 256)
+    h = lib.thh_make_synthetic(ctx.h, hp6.ctypes.data, blob, lens.ctypes.data, scores.ctypes.data, thk.TENSOR_SEED, thk.TENSOR_SIGMA)
+    if h <= 0:
+        raise RuntimeError((lib.thh_last_error() or b"").decode())
+    try:
+        out = {"workload": f"th::do_inference (libthk_host.so) on synthetic LLaMA-7B f16: {n_prompt}-token prompt fed token by token, then {n_new} generated tokens "
+                           f"(positions {n_prompt}..{n_prompt + n_new - 1}), 1 sequence", "prompt_tokens": n_prompt, "new_tokens": n_new}
+        for name, (k, p, t) in (("stochastic_default_sampler", (40, 0.95, 0.8)), ("greedy", (40, 0.95, 0.0))):
+            lib.thh_set_sampler(h, k, p, t, 1.1)
+            host_api_generate(lib, h, prompt, n_prompt, 16, timed=False)              # warm-up: graphs captured, scratch allocated
+            text_u, n_u, _ = host_api_generate(lib, h, prompt, n_prompt, n_new, timed=False)
+            text_t, n_t, st = host_api_generate(lib, h, prompt, n_prompt, n_new, timed=True)
+            st["sampler"] = f"temp {t}, top-k {k}, top-p {p}" if t > 0 else "temp 0 (arg-max on the device, device-resident loop)"
+            st["timed_text_equals_untimed"] = bool(n_u == n_t and (text_u == text_t or t > 0))   # (the seeded generator moves on between stochastic calls)
+            out[name] = st
+        s, g = out["stochastic_default_sampler"].get("gen_tok_s"), out["greedy"].get("gen_tok_s")
+        if s and g:
+            out["stochastic_over_greedy"] = round(s / g, 4)
+        return out
+    finally:
+        lib.thh_free(h)
+
+
 def extra_decode_13b(thk, ctx, T, stream, torch, steps=100, warmup=20):
     """Config C5: LLaMA-13B f16 on the same GPU, same protocol as the headline (KV filled by the 511-token prompt, hold position)."""
     shape = thk.LLAMA_13B
@@ -808,6 +899,10 @@ def main():
                     extras["prefill_128"] = extra_prefill_128(thk, model, shape, ctx)
                 except Exception as e:
                     extras["prefill_128"] = {"error": str(e)}
+                try:
+                    extras["host_api"] = extra_host_api(thk, ctx)
+                except Exception as e:
+                    extras["host_api"] = {"error": str(e)}
                 try:
                     extras["decode_13b"] = extra_decode_13b(thk, ctx, T, stream, torch)
                 except Exception as e:

@@ -187,6 +187,9 @@ int thk_model_set_tensor(thk_model* m, const char* name, int dtype, int64_t ne0,
 /* Same, payload already on the device (e.g. thk_buf_ptr of a buffer the caller uploaded -- the host layer's TensorBuffer,
  * th.hpp:83-148): one stream-ordered device-to-device copy; the source may be freed after thk_sync / thk_buf_free. */
 int thk_model_set_tensor_dev(thk_model* m, const char* name, int dtype, int64_t ne0, int64_t ne1, const void* dev_ptr);
+/* Reads bytes [offset_bytes, offset_bytes + n_bytes) of a tensor this stage owns back to the host (row-major, as it was set): the inverse of
+ * thk_model_set_tensor, for a loader's self-check (the reference keeps a cpuBackup for the same purpose, th.hpp:142).  Blocking. */
+int thk_model_get_tensor(thk_model* m, const char* name, int64_t offset_bytes, int64_t n_bytes, void* host_out);
 /* Device-side fill of every tensor this stage owns with the synthetic generator. */
 int thk_model_fill_synthetic(thk_model* m, uint64_t seed, float sigma);
 /* Allocates caches/working buffers, builds the RoPE table and captures the
@@ -257,6 +260,9 @@ void* thk_model_logits_dev(thk_model* m, int32_t seq);  /* dev f32[V] (head stag
 int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out, int32_t cap, int32_t* n_out, int32_t* pos_out);
 /* Logits of the sequence's last evaluated token (head stages): the k largest via thk_topk_f32's kernel, or all n_vocab of them. */
 int thk_model_logits_topk(thk_model* m, int32_t seq, int32_t k, float* values_out, int32_t* ids_out);
+/* thk_model_eval and thk_model_logits_topk in ONE stream round trip (what a stochastic sampler needs per token, th-llama.cpp:686-724 without
+ * the 4 * n_vocab-byte mapping): the steps, the selection kernel behind them, its k keys written into host-mapped memory, one synchronisation. */
+int thk_model_eval_topk(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past, int32_t k, float* values_out, int32_t* ids_out);
 int thk_model_read_logits(thk_model* m, int32_t seq, float* logits_out);
 /* Device-side step clock (head stages): clock_out[i] = the chip-wide 100 MHz counter (s_memrealtime) at the end of the step that
  * logged token i of thk_model_seq_get.  Differences are per-step durations taken on the GPU, inside replayed multi-step graphs,

@@ -41,17 +41,16 @@ def write_ggjt(path, hp, vocab_words, vocab_scores, tensors, magic=MAGIC_GGJT, v
             pad = (-f.tell()) % 32
             f.write(b"\0" * pad)
             offs[name] = f.tell()
-            f.write(arr.tobytes())
+            f.write(memoryview(arr).cast("B"))
     return offs
 
 
 def synthetic_model_tensors(orc, oshape):
-    out = []
+    """(name, array) of every tensor in file order, generated one at a time (a 7B-shaped model is 13.5 GB: never all in memory)."""
     for name, dt, shp in oshape.tensor_specs():
         n = int(np.prod(shp))
-        out.append((name, orc.synth_f16(name, orc.TENSOR_SEED, orc.TENSOR_SIGMA, n).reshape(shp) if dt == "f16"
-                    else orc.synth_gain(name, orc.TENSOR_SEED, orc.TENSOR_SIGMA, n)))
-    return out
+        yield (name, orc.synth_f16(name, orc.TENSOR_SEED, orc.TENSOR_SIGMA, n).reshape(shp) if dt == "f16"
+               else orc.synth_gain(name, orc.TENSOR_SEED, orc.TENSOR_SIGMA, n))
 
 
 def write_synthetic_model(path, orc, oshape):

@@ -42,6 +42,13 @@ def host(thk):
     lib.capi_load_model_header.argtypes = [C.c_char_p, C.c_double]
     lib.capi_load_model_weights.argtypes = [C.c_char_p, C.c_double, C.c_double]
     lib.capi_set_sampler.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
+    lib.thh_make_synthetic.restype = C.c_int64
+    lib.thh_make_synthetic.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_float]
+    lib.thh_set_step_limit.argtypes = [C.c_int64, C.c_int64]
+    lib.thh_collect_stats.argtypes = [C.c_int64, C.c_int]
+    lib.thh_stats.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+    lib.thh_device_model.restype = C.c_void_p; lib.thh_device_model.argtypes = [C.c_int64]
+    lib.capi_device_model.restype = C.c_void_p; lib.capi_device_model.argtypes = []
     return lib
 
 
@@ -301,3 +308,156 @@ def test_cli_matches_library(host, ctx, model_file):
         assert b"tokens generated" in r.stderr
     r = subprocess.run([cli, "--bogus"], capture_output=True, timeout=60)
     assert r.returncode == 2 and b"unknown option" in r.stderr
+
+
+@pytest.mark.parametrize("temp", [0.8, 0.0])
+def test_timed_generation_equals_untimed_and_honours_the_step_limit(host, thk, orc, ctx, model_file, temp):
+    """bench.py's extras.host_api: th::do_inference limited to prompt + n steps (LlamaModel::stepLimit) with the per-section timers on
+    (LlamaModel::collectStats) generates exactly the text of the untimed call, stops after prompt + n steps, and accounts for every
+    step; the same generation on a LlamaModel made WITHOUT a file (thh_make_synthetic: device-side synthetic fill + the caller's
+    vocabulary, what the bench uses for the 7B) gives the same text as the file-loaded model."""
+    path, _, words, scores = model_file
+    prompt = b"the quick brown fox"
+    import test_host_cpu as thc
+    n_prompt = len(thc.py_tokenize(words, scores, b" " + prompt, True))
+    n_new = 24
+    got = []
+    for how, timed in (("file", 0), ("file", 1), ("synthetic", 1)):
+        if how == "file":
+            h = host.thh_load_file(ctx.h, path.encode(), 0)
+        else:
+            s = orc.TINY
+            hp6 = np.array([s.n_vocab, s.n_embd, s.n_mult, s.n_head, s.n_layer, 512], np.int32)
+            blob = b"".join(words); lens = np.array([len(w) for w in words], np.int32)
+            h = host.thh_make_synthetic(ctx.h, hp6.ctypes.data, blob, lens.ctypes.data, np.asarray(scores, np.float32).ctypes.data, thk.TENSOR_SEED, thk.TENSOR_SIGMA)
+        assert h > 0, host.thh_last_error()
+        host.thh_set_sampler(h, 40, 0.95, temp, 1.1)
+        host.thh_set_step_limit(h, n_prompt + n_new)
+        host.thh_collect_stats(h, timed)
+        n_past = C.c_int32(); text = C.create_string_buffer(1 << 16)
+        n_tok = host.thh_do_inference(h, prompt, C.byref(n_past), text, len(text))
+        out8 = (C.c_double * 8)(); ends = (C.c_double * 1024)()
+        n_steps = host.thh_stats(h, out8, ends, 1024)
+        if timed:
+            ends = np.array(ends[:n_steps])
+            assert n_steps == n_past.value and (np.diff(ends) >= 0).all()
+            if temp > 0:
+                assert int(out8[4]) == n_steps and int(out8[5]) + int(out8[6]) >= n_steps      # one eval per step; top-k or the full read-back after each
+        else:
+            assert n_steps == 0
+        got.append((n_tok, n_past.value, text.value))
+        host.thh_free(h)
+    assert got[0][1] <= n_prompt + n_new and got[0][0] >= 1
+    assert got[0] == got[1] == got[2]
+
+
+def _avail(path="/proc/meminfo"):
+    try:
+        return [int(l.split()[1]) * 1024 for l in open(path) if l.startswith("MemAvailable")][0]
+    except Exception:
+        return 0
+
+
+def test_7b_sized_ggjt_file_through_the_kept_loader(host, thk, orc, ctx, tmp_path_factory):
+    """Config C1 at FULL size (north_star keeps "the GGML-f16 loader"): the synthetic LLaMA-7B written as a real ggjt v1 file
+    (291 tensors, 32000-entry vocabulary, 13.5 GB) goes through load_llama_file (th-llama-loader.cpp:485-635: record by record through
+    a host buffer, TensorBuffer upload, device-to-device hand-over) and through the streamed capi_* path (web/main.cpp:83-104); the
+    loaded weights are compared byte for byte with the device-side synthetic fill (three whole tensors + every norm vector), the
+    logits of three positions and the greedy tokens bit for bit with the fill-synthetic model.  Reports the load rate."""
+    import mmap
+    import shutil
+    import time
+    oshape = orc.LLAMA_7B
+    file_bytes = sum(int(np.prod(shp)) * (2 if dt == "f16" else 4) for _, dt, shp in oshape.tensor_specs())
+    shm = "/dev/shm"
+    use_shm = os.path.isdir(shm) and shutil.disk_usage(shm).free > file_bytes + (2 << 30)
+    base = shm if use_shm else str(tmp_path_factory.mktemp("ggjt7b"))
+    if not use_shm and shutil.disk_usage(base).free < file_bytes + (2 << 30):
+        pytest.skip(f"no place for a {file_bytes / 2**30:.1f} GiB model file (/dev/shm and the temp directory are too small)")
+    need = (file_bytes if use_shm else 0) + (6 << 30)            # the file's pages (tmpfs) + generator / loader buffers
+    if _avail() < need:
+        pytest.skip(f"host RAM: {_avail() / 2**30:.0f} GiB available < {need / 2**30:.0f} GiB for a 7B-sized ggjt file in {base}")
+    path = os.path.join(base, f"thk-synth-7b-f16-{os.getpid()}.bin")
+    threads = orc.num_threads()
+    orc.set_num_threads(orc.usable_cpus())
+    a = None
+    try:
+        t0 = time.time()
+        offs, words, scores = ggjt.write_synthetic_model(path, orc, oshape)
+        t_write = time.time() - t0
+        size = os.path.getsize(path)
+        assert len(offs) == 3 + 9 * oshape.n_layer == 291 and size > file_bytes
+        a = thk.Model(ctx, thk.LLAMA_7B); a.fill_synthetic(); a.finalize()
+        toks = [1, 17, 400]
+        want = [a.eval([t], i)[0].copy() for i, t in enumerate(toks)]
+        E, F, V = oshape.n_embd, oshape.n_ff, oshape.n_vocab
+        whole = [("tok_embeddings.weight", np.uint16, V * E), ("layers.0.attention.wq.weight", np.uint16, E * E),
+                 ("layers.31.feed_forward.w2.weight", np.uint16, E * F), ("output.weight", np.uint16, V * E), ("norm.weight", np.float32, E)]
+        whole += [(f"layers.{l}.{n}_norm.weight", np.float32, E) for l in range(oshape.n_layer) for n in ("attention", "ffn")]
+        lib = ctx.lib
+
+        def check(dev, how):
+            for name, dt, n in whole:
+                got = np.empty(n, dt)
+                ctx.check(lib.thk_model_get_tensor(dev, name.encode(), 0, got.nbytes, got.ctypes.data), "thk_model_get_tensor")
+                assert np.array_equal(got, a.get_tensor(name, dt, n)), (how, name)
+            for name in ("layers.7.feed_forward.w1.weight", "layers.19.attention.wo.weight", "layers.31.feed_forward.w3.weight"):   # head and tail of some more
+                n = E * F if "feed_forward" in name else E * E
+                for off in (0, n - 65536):
+                    got = np.empty(65536, np.uint16)
+                    ctx.check(lib.thk_model_get_tensor(dev, name.encode(), off * 2, got.nbytes, got.ctypes.data), "thk_model_get_tensor")
+                    assert np.array_equal(got, a.get_tensor(name, np.uint16, 65536, off)), (how, name, off)
+
+        # ---- load_llama_file
+        t0 = time.time()
+        h = host.thh_load_file(ctx.h, path.encode(), 0)
+        t_load = time.time() - t0
+        assert h > 0, host.thh_last_error()
+        hp = (C.c_int32 * 7)(); host.thh_hparams(h, hp)
+        assert list(hp)[:5] == [V, E, oshape.n_mult, oshape.n_head, oshape.n_layer]
+        check(host.thh_device_model(h), "load_llama_file")
+        host.thh_set_sampler(h, 40, 0.95, 0.0, 1.1)                 # greedy: th_eval reads the logits back
+        lg = np.empty(V, np.float32)
+        for i, t in enumerate(toks):
+            tok = host.thh_eval(h, (C.c_int32 * 1)(t), 1, i, lg.ctypes.data)
+            assert np.array_equal(lg.view(np.uint32), want[i].view(np.uint32)) and tok == int(want[i].argmax()), ("load_llama_file", i)
+        host.thh_free(h)
+        # ---- the streamed capi_* path: header, then one tensor record at a time straight from the mapped file
+        t0 = time.time()
+        with open(path, "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+            view = np.frombuffer(mm, np.uint8)
+            base_addr = view.ctypes.data
+            hp7 = (C.c_int32 * 7)(); consumed = C.c_int64(); nv = C.c_int32()
+            assert host.thh_parse_header(C.c_void_p(base_addr), C.c_int64(min(size, 8 << 20)), hp7, C.byref(consumed), C.byref(nv)) == 1
+            host.capi_set_context(ctx.h)
+            host.capi_model_begin_load()
+            host.capi_load_model_header(C.cast(base_addr, C.c_char_p), float(consumed.value))
+            pos, n_rec = consumed.value, 0
+            name = C.create_string_buffer(128); ty = C.c_int32(); shape4 = (C.c_int64 * 4)(); ne = (C.c_int64 * 2)()
+            d0, d1, rb = C.c_int64(), C.c_int64(), C.c_int64()
+            while pos < size:
+                assert host.thh_parse_tensor(C.c_void_p(base_addr + pos), C.c_int64(size - pos), C.c_int64(pos), name, 128, C.byref(ty), shape4, ne,
+                                             C.byref(d0), C.byref(d1), C.byref(rb)) == 1
+                host.capi_load_model_weights(C.cast(base_addr + pos, C.c_char_p), float(pos), float(rb.value))
+                pos += rb.value; n_rec += 1
+            assert n_rec == 291
+            assert host.capi_model_end_load() is True, host.capi_last_error()
+            del view
+        t_stream = time.time() - t0
+        dev = host.capi_device_model()
+        check(dev, "capi_*")
+        for i, t in enumerate(toks):
+            ctx.check(lib.thk_model_eval(dev, 0, (C.c_int32 * 1)(t), 1, i, None, lg.ctypes.data), "thk_model_eval")
+            assert np.array_equal(lg.view(np.uint32), want[i].view(np.uint32)), ("capi_*", i)
+        host.capi_model_unload()
+        print(f"\n[C1 full size] {size / 1e9:.2f} GB ggjt v1 file in {base}: written in {t_write:.1f} s (oracle generator, {orc.num_threads()} threads); "
+              f"load_llama_file {t_load:.1f} s = {size / t_load / 1e9:.2f} GB/s; streamed capi_* load {t_stream:.1f} s = {size / t_stream / 1e9:.2f} GB/s; "
+              f"{len(whole)} tensors byte-identical to the device-side fill, logits of {len(toks)} positions bit-identical")
+    finally:
+        orc.set_num_threads(threads)
+        if a is not None:
+            a.close()
+        try:
+            os.remove(path)
+        except OSError:
+            pass

@@ -264,6 +264,12 @@ class Model:
         self.ctx.check(self.ctx.lib.thk_model_set_tensor(self.h, name.encode(), dtype, ne0, ne1, arr.ctypes.data),
                        f"thk_model_set_tensor({name})")
 
+    def get_tensor(self, name: str, dtype, count: int, offset: int = 0) -> np.ndarray:
+        """`count` elements of a tensor starting at element `offset`, read back from the device (thk_model_get_tensor)."""
+        out = np.empty(count, dtype)
+        self.ctx.check(self.ctx.lib.thk_model_get_tensor(self.h, name.encode(), offset * out.itemsize, out.nbytes, out.ctypes.data), "thk_model_get_tensor")
+        return out
+
     def fill_synthetic(self, seed: int = TENSOR_SEED, sigma: float = TENSOR_SIGMA):
         self.ctx.check(self.ctx.lib.thk_model_fill_synthetic(self.h, seed, sigma), "thk_model_fill_synthetic")
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     "thk_model_n_ff": (i32, [vp]),
     "thk_model_set_tensor": (C.c_int, [vp, C.c_char_p, C.c_int, i64, i64, vp]),
     "thk_model_set_tensor_dev": (C.c_int, [vp, C.c_char_p, C.c_int, i64, i64, vp]),
+    "thk_model_get_tensor": (C.c_int, [vp, C.c_char_p, i64, i64, vp]),
     "thk_model_fill_synthetic": (C.c_int, [vp, u64, C.c_float]),
     "thk_model_finalize": (C.c_int, [vp]),
     "thk_model_reset_kv": (C.c_int, [vp, i32]),
@@ -90,6 +91,7 @@ SIGNATURES = {
     "thk_model_seq_last_token": (C.c_int, [vp, i32, C.POINTER(i32)]),
     "thk_model_seq_clock": (C.c_int, [vp, i32, vp, i32, C.POINTER(i32)]),
     "thk_model_logits_topk": (C.c_int, [vp, i32, i32, vp, vp]),
+    "thk_model_eval_topk": (C.c_int, [vp, i32, vp, i32, i32, i32, vp, vp]),
     "thk_model_read_logits": (C.c_int, [vp, i32, vp]),
     "thk_model_bytes_per_token": (i64, [vp, i32]),
     "thk_model_profile_step": (C.c_int, [vp, i32, i32, vp, vp, C.POINTER(i32)]),

@@ -156,6 +156,7 @@ extern "C" int thk_ctx_destroy(thk_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) hipFree(ctx->scratch);
+    if (ctx->pinned_keys) hipHostFree(ctx->pinned_keys);
     if (ctx->rope_tab) hipFree(ctx->rope_tab);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;

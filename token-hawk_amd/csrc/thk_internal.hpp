@@ -43,6 +43,9 @@ struct thk_ctx {
     size_t scratch_bytes = 0;
     float* rope_tab = nullptr;      // operator-API RoPE table
     size_t rope_tab_floats = 0;
+    unsigned long long* pinned_keys = nullptr;       // host-mapped page the top-k kernel writes its k keys into (thk_model_eval_topk): no copy operation,
+    unsigned long long* pinned_keys_dev = nullptr;   // word [1024] is the kernel's "done" stamp: the host polls it instead of synchronising the stream
+    unsigned long long topk_epoch = 0;
 };
 
 struct LayerW {
@@ -162,4 +165,7 @@ int valid_head_dim(int64_t D);
 int valid_splits(int64_t s);
 void q1_constants(int V, int* split, int* cov);
 int topk_to_host(thk_ctx* ctx, const float* logits_dev, int64_t V, int32_t k, float* values_out, int32_t* ids_out);
+int topk_enqueue_pinned(thk_ctx* ctx, const float* logits_dev, int64_t V, int32_t k);                 // kernel -> ctx->pinned_keys, no synchronisation
+int topk_wait_pinned(thk_ctx* ctx);                                                                   // until the kernel's stamp arrives (spin, then the stream)
+void topk_decode_keys(const unsigned long long* keys, int32_t k, float* values_out, int32_t* ids_out);
 hipError_t attn_prefill_dispatch(thk_ctx* ctx, const float* q, const float* kc, const float* vc, int n_past, int M, int H, int D, float* out, bool kv_f16 = false);

@@ -473,44 +473,58 @@ hipError_t launch_argmax(const float* logits, int V, unsigned long long* block_b
 // ---------------------------------------------------------------- top-k of a logits vector (stochastic sampler, th-llama.cpp:814-907)
 // keys[j] = (order-preserving map of logits[i]) << 32 | ~i  for the k largest, sorted descending: value descending, ties by
 // ascending index - a total order, so the selection and its order are unique.  ONE workgroup of 1024 threads: every thread holds
-// up to kTopkPer keys in registers; the k-th largest key is found by an 8-pass radix select on the 64-bit keys (256-bin LDS
-// histogram of the next byte among the keys that match the prefix so far), the keys >= it are compacted into LDS (exactly k: keys
-// are unique) and sorted with a bitonic network.  V <= 1024 * kTopkPer = 32768, k <= 1024.
+// up to kTopkPer keys in registers; the k-th largest key is found by bisection (below), the keys >= it are compacted into LDS
+// (exactly k: keys are unique) and sorted with a bitonic network.  V <= 1024 * kTopkPer = 32768, k <= 1024.
 constexpr int kTopkThreads = 1024, kTopkPer = 32, kTopkMax = 1024;     // 32 keys = 64 VGPRs per thread (16 waves per workgroup leave 128)
-__global__ __launch_bounds__(kTopkThreads) void topk_kernel(const float* __restrict__ logits, int V, int k, unsigned long long* __restrict__ keys_out) {
-    __shared__ unsigned hist[256];
+// Round 5: the k-th largest key is found by BISECTION on the 64-bit key - per step every thread counts its keys >= the trial value,
+// the counts are summed with wave shuffles and one LDS hop across the 16 waves, no atomics - instead of an 8-pass radix select whose
+// first passes sent all 32000 LDS atomics to the two or three bins the logits' exponents share (the kernel took 4x as long).  The
+// search starts from the range [min key, max key] of the vector, so the shared high bits cost no steps.
+__global__ __launch_bounds__(kTopkThreads) void topk_kernel(const float* __restrict__ logits, int V, int k, unsigned long long* __restrict__ keys_out,
+                                                            unsigned long long* done /* host-mapped word or NULL */, unsigned long long epoch) {
     __shared__ unsigned long long sel[kTopkMax];
-    __shared__ unsigned long long s_prefix;
-    __shared__ unsigned s_need, s_count;
-    const int tid = threadIdx.x;
+    __shared__ unsigned long long red_hi[16], red_lo[16];
+    __shared__ unsigned red_cnt[2][16];
+    __shared__ unsigned s_count;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned long long key[kTopkPer];
+    unsigned long long hi = 0ull, lo = ~0ull;
 #pragma unroll
     for (int j = 0; j < kTopkPer; ++j) {
         const int i = tid + j * kTopkThreads;
         key[j] = i < V ? argmax_key(logits[i], (unsigned)i) : 0ull;      // 0 is below every real key (a real key has ~idx != 0 in its low word or a non-zero value word)
+        if (i < V) { hi = key[j] > hi ? key[j] : hi; lo = key[j] < lo ? key[j] : lo; }
     }
-    if (tid == 0) { s_prefix = 0ull; s_need = (unsigned)k; s_count = 0u; }
-    __syncthreads();
-    for (int pass = 7; pass >= 0; --pass) {                                  // most significant byte first
-        if (tid < 256) hist[tid] = 0u;
-        __syncthreads();
-        const unsigned long long prefix = s_prefix;
-        const unsigned long long hi_mask = pass == 7 ? 0ull : (~0ull << ((pass + 1) * 8));
 #pragma unroll
-        for (int j = 0; j < kTopkPer; ++j) {
-            const int i = tid + j * kTopkThreads;
-            if (i < V && (key[j] & hi_mask) == prefix) atomicAdd(&hist[(unsigned)(key[j] >> (pass * 8)) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {                                                      // walk the bins from the top until the k-th largest falls into one
-            unsigned need = s_need, b = 255;
-            for (;; --b) { if (hist[b] >= need || b == 0) break; need -= hist[b]; }
-            s_need = need;
-            s_prefix = prefix | ((unsigned long long)b << (pass * 8));
-        }
-        __syncthreads();
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long h2 = __shfl_xor(hi, o, 64), l2 = __shfl_xor(lo, o, 64);
+        hi = h2 > hi ? h2 : hi; lo = l2 < lo ? l2 : lo;
     }
-    const unsigned long long kth = s_prefix;                                 // the k-th largest key itself
+    if (lane == 0) { red_hi[wave] = hi; red_lo[wave] = lo; }
+    if (tid == 0) s_count = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { hi = red_hi[w] > hi ? red_hi[w] : hi; lo = red_lo[w] < lo ? red_lo[w] : lo; }
+    // invariant: count(keys >= lo) >= k  and  count(keys >= hi + 1) < k; the answer is the largest t with count(keys >= t) >= k
+    unsigned long long a = lo, b = hi;                                    // search t in [a, b]
+    int it = 0;
+    while (a < b) {
+        const unsigned long long mid = a + ((b - a) >> 1) + 1ull;          // upper middle: a < mid <= b
+        unsigned c = 0;
+#pragma unroll
+        for (int j = 0; j < kTopkPer; ++j) c += key[j] >= mid ? 1u : 0u;   // (padding keys are 0 < mid)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        unsigned* rc = red_cnt[it & 1];                                    // two buffers: one barrier per step
+        if (lane == 0) rc[wave] = c;
+        __syncthreads();
+        unsigned total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) total += rc[w];
+        if (total >= (unsigned)k) a = mid; else b = mid - 1ull;
+        ++it;
+    }
+    const unsigned long long kth = a;                                       // the k-th largest key itself (keys are unique)
 #pragma unroll
     for (int j = 0; j < kTopkPer; ++j) {
         const int i = tid + j * kTopkThreads;
@@ -527,17 +541,22 @@ __global__ __launch_bounds__(kTopkThreads) void topk_kernel(const float* __restr
                 const int p = i ^ stride;
                 if (p > i) {
                     const bool desc = (i & size) == 0;
-                    const unsigned long long a = sel[i], b = sel[p];
-                    if ((a < b) == desc) { sel[i] = b; sel[p] = a; }
+                    const unsigned long long x = sel[i], y = sel[p];
+                    if ((x < y) == desc) { sel[i] = y; sel[p] = x; }
                 }
             }
             __syncthreads();
         }
     for (int i = tid; i < k; i += kTopkThreads) keys_out[i] = sel[i];
+    if (done) {                                   // keys_out is host-mapped: tell the polling host thread (every storing thread fences, then one publishes)
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
-hipError_t launch_topk(const float* logits, int V, int k, unsigned long long* keys_out, hipStream_t st) {
+hipError_t launch_topk(const float* logits, int V, int k, unsigned long long* keys_out, hipStream_t st, unsigned long long* done, unsigned long long epoch) {
     if (V < 1 || V > kTopkThreads * kTopkPer || k < 1 || k > kTopkMax || k > V) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(kTopkThreads), 0, st, logits, V, k, keys_out);
+    hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(kTopkThreads), 0, st, logits, V, k, keys_out, done, epoch);
     return hipGetLastError();
 }
 

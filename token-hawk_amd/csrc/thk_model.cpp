@@ -164,6 +164,22 @@ extern "C" int thk_model_set_tensor_dev(thk_model* m, const char* name, int dtyp
     HIPCHK(ctx, hipMemcpyAsync(dst, dev_ptr, (size_t)(c * r) * (t == THK_F16 ? 2 : 4), hipMemcpyDeviceToDevice, ctx->stream));
     return THK_OK;
 }
+// Read a tensor (or a byte range of it) back from the model's slot: the inverse of thk_model_set_tensor, for loaders' self-checks.
+extern "C" int thk_model_get_tensor(thk_model* m, const char* name, int64_t offset_bytes, int64_t n_bytes, void* host_out) {
+    if (!m || !name || !host_out) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    void* src; int64_t c, r; int t;
+    const int rc = tensor_slot(m, name, &src, &c, &r, &t);
+    if (rc < 0) return fail(ctx, THK_ERR_NOTFOUND, "unknown tensor '%s'", name);
+    REQUIRE(ctx, rc == 0, "tensor '%s' belongs to another stage", name);
+    const int64_t total = c * r * (t == THK_F16 ? 2 : 4);
+    REQUIRE(ctx, offset_bytes >= 0 && n_bytes >= 0 && offset_bytes <= total && n_bytes <= total - offset_bytes, "tensor '%s': bytes [%lld, +%lld) outside its %lld bytes",
+            name, (long long)offset_bytes, (long long)n_bytes, (long long)total);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemcpyAsync(host_out, (const char*)src + offset_bytes, (size_t)n_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return THK_OK;
+}
 extern "C" int thk_model_fill_synthetic(thk_model* m, uint64_t seed, float sigma) {
     if (!m) return THK_ERR_INVALID;
     thk_ctx* ctx = m->ctx;
@@ -355,6 +371,31 @@ extern "C" int thk_model_eval(thk_model* m, int32_t seq, const int32_t* tokens, 
     if (hidden_inout) HIPCHK(ctx, hipMemcpyAsync(hidden_inout, head ? m->x : sb.hidden_out, E * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return check_engine_error(m);
+}
+
+// th_eval_gpu + the candidate selection of a STOCHASTIC sampler in one stream round trip: the step(s), then the top-k kernel behind them on the
+// same stream, its k keys written straight into host-mapped memory and a stamp behind them that the host thread polls (no stream synchronisation).  (thk_model_eval + thk_model_logits_topk cost two
+// synchronisations, a launch from an idle stream and a copy operation per token: 96 us next to a 2.27 ms step; this form 4 x less.)
+extern "C" int thk_model_eval_topk(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past, int32_t k, float* values_out, int32_t* ids_out) {
+    if (!m || !tokens || !values_out || !ids_out) return THK_ERR_INVALID;
+    thk_ctx* ctx = m->ctx;
+    REQUIRE(ctx, m->finalized, "thk_model_eval_topk before thk_model_finalize");
+    REQUIRE(ctx, seq >= 0 && seq < m->n_seq, "bad sequence %d", seq);
+    REQUIRE(ctx, (m->flags & THK_STAGE_EMBED) && (m->flags & THK_STAGE_HEAD), "thk_model_eval_topk needs a full-model stage (embedding + head)");
+    REQUIRE(ctx, n_tokens >= 1 && n_past >= 0 && n_past + n_tokens <= m->hp.n_ctx, "n_past=%d + n_tokens=%d exceeds n_ctx=%d", n_past, n_tokens, m->hp.n_ctx);
+    REQUIRE(ctx, k >= 1 && k <= 1024 && k <= m->hp.n_vocab && m->hp.n_vocab <= 32768, "top-k: k=%d / n_vocab=%d outside the device kernel's range (n_vocab <= 32768, k <= 1024)", k, m->hp.n_vocab);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int rc = step_set_advance(m, seq, 0);
+    if (rc != THK_OK) return rc;
+    for (int i = 0; i < n_tokens; ++i) {
+        REQUIRE(ctx, tokens[i] >= 0 && tokens[i] < m->hp.n_vocab, "token id %d out of range", tokens[i]);
+        if ((rc = set_seq_state(m, seq, tokens[i], n_past + i, false)) != THK_OK) return rc;
+        if ((rc = step_run(m, seq)) != THK_OK) return rc;
+    }
+    if ((rc = topk_enqueue_pinned(ctx, m->seqs[seq].logits, m->hp.n_vocab, k)) != THK_OK) return rc;
+    if ((rc = topk_wait_pinned(ctx)) != THK_OK) return rc;
+    topk_decode_keys(ctx->pinned_keys, k, values_out, ids_out);
+    return m->engine ? check_engine_error(m) : THK_OK;
 }
 
 extern "C" int thk_model_seq_set(thk_model* m, int32_t seq, int32_t token, int32_t pos) {

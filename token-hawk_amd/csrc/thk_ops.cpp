@@ -2,6 +2,7 @@
 // their WGSL, th.cpp:396-4351), explicit dimensions instead of baked shader constants.  Used by the parity tests per op;
 // the model level (thk_model.cpp) launches the fused forms directly.
 #include "thk_internal.hpp"
+#include <time.h>
 
 // ---------------------------------------------------------------- operators
 static int gemv_simple(thk_ctx* ctx, int pro, int epi, const char* var_name, const char* bpc_name, GemvArgs& a, int rows) {
@@ -165,12 +166,48 @@ int topk_to_host(thk_ctx* ctx, const float* logits_dev, int64_t V, int32_t k, fl
     std::vector<unsigned long long> keys((size_t)k);
     HIPCHK(ctx, hipMemcpyAsync(keys.data(), keys_dev, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    topk_decode_keys(keys.data(), k, values_out, ids_out);
+    return THK_OK;
+}
+void topk_decode_keys(const unsigned long long* keys, int32_t k, float* values_out, int32_t* ids_out) {
     for (int i = 0; i < k; ++i) {
         const unsigned hi = (unsigned)(keys[i] >> 32), lo = (unsigned)(keys[i] & 0xFFFFFFFFull);
         const unsigned bits = (hi & 0x80000000u) ? (hi & 0x7FFFFFFFu) : ~hi;     // inverse of argmax_key's order-preserving map
         memcpy(&values_out[i], &bits, 4);
         ids_out[i] = (int32_t)(0xFFFFFFFFu - lo);
     }
+}
+// The top-k kernel enqueued behind whatever the stream holds, writing its keys straight into a host-mapped page: the caller
+// synchronises the stream ONCE (for the step and the selection together) and decodes ctx->pinned_keys.
+int topk_enqueue_pinned(thk_ctx* ctx, const float* logits_dev, int64_t V, int32_t k) {
+    REQUIRE(ctx, logits_dev && V >= 1 && V <= 32768 && k >= 1 && k <= 1024 && k <= V, "top-k: V=%lld k=%d outside the device kernel's range (V <= 32768, k <= 1024)", (long long)V, k);
+    if (!ctx->pinned_keys) {
+        HIPCHK(ctx, hipHostMalloc((void**)&ctx->pinned_keys, 1025 * 8, hipHostMallocMapped));
+        HIPCHK(ctx, hipHostGetDevicePointer((void**)&ctx->pinned_keys_dev, ctx->pinned_keys, 0));
+        ctx->pinned_keys[1024] = 0;
+    }
+    HIPCHK(ctx, launch_topk(logits_dev, (int)V, k, ctx->pinned_keys_dev, ctx->stream, ctx->pinned_keys_dev + 1024, ++ctx->topk_epoch));
+    return THK_OK;
+}
+// The kernel's last act is a system-scope store of this call's epoch behind its keys: the host thread polls that word in its own memory
+// (a hipStreamSynchronize wake-up costs tens of microseconds per token); after 0.2 s of polling it falls back to the stream, so a fault
+// still surfaces as an error.
+int topk_wait_pinned(thk_ctx* ctx) {
+    volatile unsigned long long* stamp = ctx->pinned_keys + 1024;
+    const unsigned long long want = ctx->topk_epoch;
+    timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spins = 0; *stamp != want; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xFFFu) == 0xFFFu) {
+            timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9 > 0.2) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                REQUIRE(ctx, *stamp == want, "top-k: the kernel finished without publishing its stamp");
+                break;
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return THK_OK;
 }
 extern "C" int thk_topk_f32(thk_ctx* ctx, const float* logits, int64_t V, int32_t k, float* values_out, int32_t* ids_out) {

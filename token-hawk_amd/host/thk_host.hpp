@@ -109,6 +109,20 @@ struct LlamaModel {
     // 4-byte token read-backs in chunks of 8) instead of one blocking 128 KB logits read-back per token; same text.
     bool greedyDeviceLoop = true;
     bool deviceTopK = true;           // temp > 0: top-k candidates selected on the device instead of reading all n_vocab logits back per token
+    // Steps (prompt tokens + generated tokens) one do_inference call may take: the reference's kMaxOutputTokens (th-llama.cpp:17)
+    // unless the embedder asks for less (bench.py's host_api figure generates a fixed number of tokens).
+    int64_t stepLimit = 500;
+    // Optional per-call timing of the token loop (off by default: two clock reads per section).  Seconds, accumulated over the
+    // calls since the last clear(): th_eval's sections and the wall-clock time at which every step of do_inference ended.
+    struct LoopStats {
+        double eval_s = 0, topk_s = 0, readback_s = 0, draw_s = 0;      // device step (replay + sync) | top-k kernel + k x 8 B read-back | 4 n_vocab B read-back | host sampler
+        int64_t n_eval = 0, n_topk = 0, n_readback = 0;
+        double t_begin = 0;                                             // do_inference entry
+        std::vector<double> step_end;                                   // one entry per step (the greedy device loop stamps a chunk's steps together)
+        void clear() { *this = LoopStats{}; }
+    };
+    bool collectStats = false;
+    LoopStats stats;
 
     std::function<void(std::string /*token*/, std::string /*messageSoFar*/)> onNewToken;
     std::function<void(std::string /*fullMessage*/)> onInferenceComplete;

@@ -202,6 +202,48 @@ EXPORT int64_t thh_load_file(thk_ctx* ctx, const char* path, int lmhead_mode) {
     g_handles[g_next_handle] = m;
     return g_next_handle++;
 }
+// A LlamaModel without a file: the device model is filled with the seeded synthetic weights (thk_model_fill_synthetic) and the
+// vocabulary is the caller's (tests/ggjt.py toy_vocab).  bench.py times th::do_inference on the synthetic 7B through this (extras.host_api).
+EXPORT int64_t thh_make_synthetic(thk_ctx* ctx, const int32_t* hp6 /* n_vocab n_embd n_mult n_head n_layer n_ctx */, const char* blob, const int32_t* lens,
+                                  const float* scores, uint64_t seed, float sigma) {
+    auto m = std::make_shared<LlamaModel>();
+    m->onError = [](std::string e) { g_last_error = e; };
+    m->n_vocab = hp6[0]; m->n_embd = hp6[1]; m->n_mult = hp6[2]; m->n_head = hp6[3]; m->n_layer = hp6[4]; m->n_ctx = hp6[5];
+    m->n_rot = m->n_embd / m->n_head;
+    m->vocab = make_vocab(blob, lens, scores, m->n_vocab);
+    m->ctx = ctx;
+    m->rng = std::mt19937(780658349);   // th-llama-loader.cpp:332-333
+    thk_hparams hp{m->n_vocab, m->n_embd, m->n_mult, m->n_head, m->n_layer, m->n_ctx};
+    if (thk_model_create(ctx, &hp, 0, m->n_layer, THK_STAGE_EMBED | THK_STAGE_HEAD, 1, &m->dev) != THK_OK || thk_model_fill_synthetic(m->dev, seed, sigma) != THK_OK ||
+        thk_model_finalize(m->dev) != THK_OK) {
+        g_last_error = std::string("thh_make_synthetic: ") + thk_last_error(ctx);
+        return 0;
+    }
+    g_handles[g_next_handle] = m;
+    return g_next_handle++;
+}
+EXPORT int thh_set_step_limit(int64_t h, int64_t steps) {            // prompt tokens + generated tokens per do_inference call (<= the reference's 500)
+    auto it = g_handles.find(h); if (it == g_handles.end()) return 0;
+    it->second->stepLimit = steps;
+    return 1;
+}
+EXPORT int thh_collect_stats(int64_t h, int on) {                    // clears the counters
+    auto it = g_handles.find(h); if (it == g_handles.end()) return 0;
+    it->second->collectStats = on != 0; it->second->stats.clear();
+    return 1;
+}
+// out8: eval_s topk_s readback_s draw_s n_eval n_topk n_readback t_begin; step_end[cap]: wall-clock seconds at the end of every step; returns the number of steps
+EXPORT int thh_stats(int64_t h, double* out8, double* step_end, int cap) {
+    auto it = g_handles.find(h); if (it == g_handles.end()) return -1;
+    const LlamaModel::LoopStats& s = it->second->stats;
+    const double v[8] = {s.eval_s, s.topk_s, s.readback_s, s.draw_s, (double)s.n_eval, (double)s.n_topk, (double)s.n_readback, s.t_begin};
+    memcpy(out8, v, sizeof v);
+    for (size_t i = 0; i < s.step_end.size() && (int)i < cap; ++i) step_end[i] = s.step_end[i];
+    return (int)s.step_end.size();
+}
+EXPORT double thh_now() { return get_time_seconds(); }
+EXPORT thk_model* thh_device_model(int64_t h) { auto it = g_handles.find(h); return it == g_handles.end() ? nullptr : it->second->dev; }   // for thk_model_get_tensor & co.
+EXPORT thk_model* capi_device_model() { return g_model ? g_model->dev : nullptr; }
 EXPORT void thh_free(int64_t h) { g_handles.erase(h); }
 EXPORT int thh_hparams(int64_t h, int32_t* hp7) {
     auto it = g_handles.find(h); if (it == g_handles.end()) return 0;

@@ -127,25 +127,39 @@ tk_llama_token th_eval(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, const tk_lla
     // th-llama.cpp:686-724): the device selects the few raw logits that can reach the sampler's top_k (thk_model_logits_topk) and
     // the unchanged softmax / top-p / discrete_distribution runs on those.  Ties that would make the result depend on
     // std::partial_sort's internals fall back to the full vector, so the draws are the reference's in every case.
+    // optional section timing (LlamaModel::collectStats): tick() returns the seconds since the previous tick
+    const bool timed = m->collectStats;
+    double t_last = timed ? get_time_seconds() : 0;
+    auto tick = [&]() { if (!timed) return 0.0; const double now = get_time_seconds(), d = now - t_last; t_last = now; return d; };
+    LlamaModel::LoopStats& stt = m->stats;
     if (m->deviceTopK && sp.temp > 0 && sp.top_k > 0 && sp.top_k < m->n_vocab && m->n_vocab <= 32768) {
         const int K = llama_topk_candidates_needed(m->n_vocab, last, sp.top_k, sp.repeat_penalty);
         if (K <= 1024) {
-            int rc = thk_model_eval(m->dev, 0, ids.data(), n_tokens, n_past, nullptr, nullptr);
             std::vector<float> cv((size_t)K); std::vector<int32_t> ci((size_t)K);
-            if (rc == THK_OK) rc = thk_model_logits_topk(m->dev, 0, K, cv.data(), ci.data());
+            int rc = thk_model_eval_topk(m->dev, 0, ids.data(), n_tokens, n_past, K, cv.data(), ci.data());   // the step and the selection: one stream round trip
+            stt.eval_s += tick(); stt.n_eval += 1; stt.n_topk += 1;
             tk_llama_token tok = -1;
-            if (rc == THK_OK && llama_sample_from_topk(m->rng, m->n_vocab, last, sp.top_k, sp.top_p, sp.temp, sp.repeat_penalty, cv.data(), ci.data(), K, &tok)) return tok;
+            if (rc == THK_OK && llama_sample_from_topk(m->rng, m->n_vocab, last, sp.top_k, sp.top_p, sp.temp, sp.repeat_penalty, cv.data(), ci.data(), K, &tok)) {
+                stt.draw_s += tick();
+                return tok;
+            }
             if (rc == THK_OK) rc = thk_model_read_logits(m->dev, 0, m->logits.data());
+            stt.readback_s += tick(); stt.n_readback += 1;
             if (rc != THK_OK) { report_error(*m, std::string("th_eval failed: ") + thk_last_error(m->ctx)); return -1; }
-            return llama_sample_top_p_top_k(m->rng, m->n_vocab, last, sp.top_k, sp.top_p, sp.temp, sp.repeat_penalty, m->logits);
+            const tk_llama_token t2 = llama_sample_top_p_top_k(m->rng, m->n_vocab, last, sp.top_k, sp.top_p, sp.temp, sp.repeat_penalty, m->logits);
+            stt.draw_s += tick();
+            return t2;
         }
     }
     const int rc = thk_model_eval(m->dev, 0, ids.data(), n_tokens, n_past, nullptr, m->logits.data());
+    stt.eval_s += tick(); stt.n_eval += 1; stt.n_readback += 1;          // the step and its 4 n_vocab-byte read-back are one call here
     if (rc != THK_OK) {
         report_error(*m, std::string("th_eval failed: ") + thk_last_error(m->ctx));
         return -1;                                  // callers stop on a negative token (the reference returns 0 and carries on)
     }
-    return llama_sample_top_p_top_k(m->rng, m->n_vocab, last, sp.top_k, sp.top_p, sp.temp, sp.repeat_penalty, m->logits);
+    const tk_llama_token t3 = llama_sample_top_p_top_k(m->rng, m->n_vocab, last, sp.top_k, sp.top_p, sp.temp, sp.repeat_penalty, m->logits);
+    stt.draw_s += tick();
+    return t3;
 }
 
 // Greedy generation without a per-token host round trip: the reference drains the GPU and maps 128 KB
@@ -182,13 +196,16 @@ static bool greedy_device_loop(std::shared_ptr<LlamaModel> m, int n_ctx, int64_t
         m->last_n_tokens.push_back(t);
         return true;
     };
+    const int64_t limit = std::min<int64_t>(kMaxOutputTokens, m->stepLimit);
+    if (m->collectStats && n_prompt_left > 0) m->stats.step_end.insert(m->stats.step_end.end(), (size_t)n_prompt_left, get_time_seconds());
     if (n_prompt_left > 0 && !emit(cur)) return true;
-    while (step < kMaxOutputTokens && m->n_past < n_ctx) {
-        const int chunk = (int)std::min<int64_t>(std::min<int64_t>(8, kMaxOutputTokens - step), n_ctx - m->n_past);
+    while (step < limit && m->n_past < n_ctx) {
+        const int chunk = (int)std::min<int64_t>(std::min<int64_t>(8, limit - step), n_ctx - m->n_past);
         if (thk_model_seq_set(m->dev, 0, cur, m->n_past) != THK_OK) return false;
         if (thk_model_decode_steps(m->dev, 0, chunk, 1) != THK_OK) return false;
         int32_t toks[8], n_log = 0, pos = 0;
         if (thk_model_seq_get(m->dev, 0, toks, chunk, &n_log, &pos) != THK_OK || n_log != chunk) return false;
+        if (m->collectStats) m->stats.step_end.insert(m->stats.step_end.end(), (size_t)chunk, get_time_seconds());
         for (int i = 0; i < chunk; ++i) {
             m->n_past += 1; step += 1;
             if (!emit(toks[i])) return true;                           // EOS: tokens the device produced beyond it are discarded
@@ -218,9 +235,11 @@ void do_inference(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, std::string promp
     if (m->last_n_tokens.empty()) m->last_n_tokens.assign(kMaxContext, 0);
     m->generatedMessage.clear();
     const int n_ctx = std::min<int>(m->n_ctx, kMaxContext);
+    const int64_t limit = std::min<int64_t>(kMaxOutputTokens, m->stepLimit);
+    if (m->collectStats) m->stats.t_begin = get_time_seconds();
     int64_t step = 0;
     const int n_prompt = (int)m->embd_inp.size();
-    if (m->prefillPrompt && n_prompt >= 2 && m->n_past + n_prompt <= n_ctx && n_prompt <= kMaxOutputTokens) {
+    if (m->prefillPrompt && n_prompt >= 2 && m->n_past + n_prompt <= n_ctx && n_prompt <= limit) {
         // Batched prompt ingestion: one thk_model_prefill call replaces n_prompt steps of the loop below: same KV rows,
         // logits of the last prompt token, every prompt token pushed through last_n_tokens.  The sampler's random stream
         // is advanced by one draw per earlier prompt token (the loop samples after every token and throws the result
@@ -245,6 +264,7 @@ void do_inference(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, std::string promp
         m->lastGeneratedToken = llama_sample_top_p_top_k(m->rng, m->n_vocab, sp.use_last_n_tokens ? m->last_n_tokens : none, sp.top_k, sp.top_p,
                                                          sp.temp, sp.repeat_penalty, m->logits);
         m->n_consumed = n_prompt; m->n_past += n_prompt; step = n_prompt;
+        if (m->collectStats) m->stats.step_end.insert(m->stats.step_end.end(), (size_t)n_prompt, get_time_seconds());
         if (m->lastGeneratedToken != tk_llama_token_eos()) {
             const char* str = tk_llama_token_to_str(m, m->lastGeneratedToken);
             if (str) {
@@ -254,15 +274,15 @@ void do_inference(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, std::string promp
             m->last_n_tokens.erase(m->last_n_tokens.begin());
             m->last_n_tokens.push_back(m->lastGeneratedToken);
         } else {
-            step = kMaxOutputTokens;                                    // EOS straight after the prompt
+            step = limit;                                               // EOS straight after the prompt
         }
     }
-    if (m->greedyDeviceLoop && m->sampler.temp <= 0 && step < kMaxOutputTokens && m->n_past < n_ctx) {
+    if (m->greedyDeviceLoop && m->sampler.temp <= 0 && step < limit && m->n_past < n_ctx) {
         if (!greedy_device_loop(m, n_ctx, step)) report_error(*m, std::string("greedy decode loop failed: ") + thk_last_error(m->ctx));
         if (m->onInferenceComplete) m->onInferenceComplete(m->generatedMessage);
         return;
     }
-    for (; step < kMaxOutputTokens && m->n_past < n_ctx; ++step) {
+    for (; step < limit && m->n_past < n_ctx; ++step) {
         tk_llama_token in;
         const bool from_prompt = m->n_consumed < (int)m->embd_inp.size();
         if (from_prompt) {
@@ -273,6 +293,7 @@ void do_inference(thk_ctx* ctx, std::shared_ptr<LlamaModel> m, std::string promp
             in = m->lastGeneratedToken;
         }
         m->lastGeneratedToken = th_eval(ctx, m, &in, 1, m->n_past);
+        if (m->collectStats) m->stats.step_end.push_back(get_time_seconds());
         if (m->lastGeneratedToken < 0) break;                           // evaluation failed (already reported): do not feed garbage back
         m->n_past += 1;
         if (m->n_consumed < (int)m->embd_inp.size()) continue;          // still consuming the prompt
