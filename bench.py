@@ -39,7 +39,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
     p.add_argument("--warmup", type=int, default=20)
-    p.add_argument("--model", default="7b", choices=["7b", "13b", "tiny"])
+    p.add_argument("--model", default="7b", choices=["7b", "13b", "tiny", "tiny4"])     # tiny4: the tiny parity model with 4 layers (a 4-rank plumbing run)
     p.add_argument("--ctx", type=int, default=512, help="context length T of the timed steps")
     p.add_argument("--kv-fill", default="prompt", choices=["prompt", "seeded"],
                    help="prompt: run the 511-token synthetic prompt through the decode path; seeded: (N>1 default off)")
@@ -64,6 +64,8 @@ def parse():
     p.add_argument("--balance", action="store_true",
                    help="N>1: size the stages with pipeline.balanced_layer_split() from the byte-based stage cost model (the lm-head rank may carry "
                         "fewer layers) instead of the uniform 32/16/8/4 split BASELINE.md names; the line reports both splits and their bounds either way")
+    p.add_argument("--no-n1-reference", action="store_true",
+                   help="N > 1: do not measure the single-GPU line (`n1_same_invocation`) on rank 0 after the pipelined measurement")
     p.add_argument("--ranks-share-gpu", action="store_true",
                    help="PLUMBING CHECK on a one-GPU box: all N ranks use cuda:0 and the process group runs over gloo (RCCL cannot place two ranks on "
                         "one GPU), so the whole N>1 flow - stage models, transport choice with the hand-off pattern check (peer | torch), ring, "
@@ -110,6 +112,9 @@ def launch_env(base):
 
 
 def model_shape(thk, name):
+    if name == "tiny4":
+        import dataclasses
+        return dataclasses.replace(thk.TINY, n_layer=4)
     return {"7b": thk.LLAMA_7B, "13b": thk.LLAMA_13B, "tiny": thk.TINY}[name]
 
 
@@ -413,6 +418,33 @@ def extra_decode_13b(thk, ctx, T, stream, torch, steps=100, warmup=20):
                 "ms_per_step": round(wall / steps * 1e3, 4), "event_ms_per_step": round(e0.elapsed_time(e1) / steps, 4), "steps": steps, "warmup": warmup,
                 "bytes_per_token": b_tok,
                 "step_roofline": {"achieved": round(b_tok * tok_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_tok * tok_s / 1e9 / HBM_PEAK_GBS, 4)}}
+    finally:
+        m.close()
+
+
+def n1_reference_line(thk, ctx, shape, T, steps, warmup, torch, dev, stream):
+    """The N = 1 point of the scaling curve measured INSIDE an N > 1 invocation (rank 0, after the pipelined measurement): the whole
+    model on this rank's GPU, the headline's own protocol (KV filled by the (T-1)-token prompt through the decode path, hold position at
+    n_past = T-1, `warmup` untimed steps, `steps` timed ones bracketed by device synchronisations).  The driver's BENCH (N = 1) value and
+    the curve's first point then come from the same code on the same day - and here from the same process tree."""
+    m = thk.Model(ctx, shape, n_seq=1)
+    try:
+        m.fill_synthetic(); m.finalize()
+        prompt = synthetic_prompt(shape, T, 0)
+        if T > 1:
+            m.eval(prompt[:T - 1], 0, want_logits=False)
+        m.seq_set(0, int(prompt[T - 1]), T - 1)
+        m.prepare_steps(warmup); m.prepare_steps(steps)
+        m.decode_steps(warmup, 0, advance=False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        m.decode_steps(steps, 0, advance=False)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        b_tok = shape.bytes_per_token(T, kv_bytes=2 if ctx.get_tunable("kv_f16") else 4)
+        return {"value": round(steps / wall, 2), "unit": "tokens/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(wall / steps * 1e3, 4),
+                "step_roofline_frac": round(b_tok * steps / wall / 1e9 / HBM_PEAK_GBS, 4),
+                "protocol": "bench.py's N = 1 protocol on rank 0's GPU, after the pipelined measurement of this invocation"}
     finally:
         m.close()
 
@@ -813,6 +845,13 @@ def main():
                 # the lm-head, rank 0 the embedding fetch) bounds the ring
                 result["ideal_efficiency_bound"] = round(sum(stage_ms) / (N * max(stage_ms)), 4)
             result["timed_region"] = "steady ring: prime() before the warm-up, steps * S micro-steps timed, drain() after (no fill/drain inside)"
+            if N > 1 and not args.no_n1_reference:
+                if rank == 0:
+                    try:
+                        result["n1_same_invocation"] = n1_reference_line(thk, ctx, shape, T, args.steps, args.warmup, torch, dev, stream)
+                    except Exception as e:
+                        result["n1_same_invocation"] = {"error": str(e)}
+                dist.barrier()                                # nobody tears the group down while rank 0 measures
             if args.ranks_share_gpu:
                 result["plumbing_check"] = f"{N} ranks share cuda:0 over gloo: the N>1 flow with real stages, NOT a scaling measurement"
             # the hand-off, validated before anything was timed: known patterns through every (sequence, kind) slot of the chosen

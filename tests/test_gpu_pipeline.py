@@ -223,11 +223,36 @@ def test_bench_two_ranks_share_one_gpu():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["steps"] == 6 and d["value"] > 0 and "plumbing_check" in d
+    assert d["n1_same_invocation"]["n_gpus"] == 1 and d["n1_same_invocation"]["value"] > 0
     assert d["config"]["transport"] == "peer" and d["config"]["sequences"] == 2
     h = d["handoff"]
     assert h["validated"] is True and h["payloads_checked_per_rank"] == 4 and len(h["handoff_us_per_rank"]) == 2
     ls = d["layer_split"]
     assert ls["used"] == [[0, 1], [1, 2]] and "measured" in ls and len(d["stage_ms_no_handoff"]) == 2
+
+
+def test_bench_four_ranks_share_one_gpu_and_carry_the_n1_line():
+    """`bench.py --gpus 4 --ranks-share-gpu --model tiny4`: four processes, four one-layer HipStages on cuda:0 (the deepest ring the GPU
+    suite can build), and the N = 1 line of the same invocation on rank 0 (`n1_same_invocation`: what SCALE's first point must agree with)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--ranks-share-gpu", "--model", "tiny4", "--steps", "6", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-kernel-profile", "--master-port", str(29850 + os.getpid() % 100)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["ranks_joined"] == 4 and d["value"] > 0 and d["config"]["sequences"] == 4 and d["config"]["transport"] == "peer"
+    assert d["layer_split"]["used"] == [[0, 1], [1, 2], [2, 3], [3, 4]] and len(d["stage_ms_no_handoff"]) == 4
+    assert d["handoff"]["validated"] is True
+    n1 = d["n1_same_invocation"]
+    assert n1["n_gpus"] == 1 and n1["steps"] == 6 and n1["value"] > 0
 
 
 def test_peer_timeout_is_sticky(thk):

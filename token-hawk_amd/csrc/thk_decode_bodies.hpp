@@ -340,8 +340,10 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
         } else if (EPI == EPI_SWIGLU && NR == 1) {     // single rows: group 2 j is row j of w1, group 2 j + 1 row j of w3 (the pair meets in LDS, below)
             // (not `g & 1 ? a.W[1] : a.W[0]`: a select of two elements of one array becomes the dynamically indexed a.W[g & 1] and the
             // whole argument block moves to scratch memory - seen in the ISA)
-            const ptrdiff_t to_w3 = (g & 1) ? a.W[1] - a.W[0] : (ptrdiff_t)0;
-            rp[0] = reinterpret_cast<const h8*>(a.W[0] + to_w3 + (size_t)(g >> 1) * C);
+            // (the distance in BYTES on integers: w1 and w3 may live in different allocations, where a typed pointer difference is undefined
+            // and would drop an odd byte; advisor, round 4)
+            const uintptr_t to_w3 = (g & 1) ? reinterpret_cast<uintptr_t>(a.W[1]) - reinterpret_cast<uintptr_t>(a.W[0]) : (uintptr_t)0;
+            rp[0] = reinterpret_cast<const h8*>(reinterpret_cast<uintptr_t>(a.W[0]) + to_w3 + (uintptr_t)(g >> 1) * (uintptr_t)C * 2u);
         } else if (EPI == EPI_SWIGLU) {
             rp[0] = reinterpret_cast<const h8*>(a.W[0] + (size_t)g * C);
             rp[1 % NR] = reinterpret_cast<const h8*>(a.W[1] + (size_t)g * C);

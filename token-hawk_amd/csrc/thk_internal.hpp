@@ -94,6 +94,7 @@ struct thk_model {
     float *x = nullptr, *q = nullptr, *u = nullptr, *attn_out = nullptr, *part_o = nullptr, *part_ml = nullptr;
     unsigned long long* block_best = nullptr;       // arg-max key per lm-head workgroup of the decode step
     unsigned long long* block_best_aux = nullptr;   // the same for head launches outside the step (prefill)
+    size_t block_best_slots = 0;                    // key slots in each of the two arrays
     float* rope_tab = nullptr;        // [n_ctx][D/2][2]
     // launch geometry resolved at finalize
     int nsplit = 4, tc = 128, nt = 1, use_graph = 1;
@@ -142,6 +143,7 @@ int step_set_advance(thk_model* m, int seq, int advance);                       
 bool engine_plan(thk_model* m);                                                 // thk_model_engine.cpp
 int engine_build_program(thk_model* m, SeqBuf& sb);
 int check_engine_error(thk_model* m);
+int report_pick_timeout(thk_model* m, int seq);                                 // thk_model.cpp: SeqState::pad seen - repair the key slots, clear the word, fail
 // ---------------------------------------------------------------- helpers (thk_ctx.cpp)
 int fail(thk_ctx* ctx, int code, const char* fmt, ...);
 #define HIPCHK(ctx, call)                                                                                  \

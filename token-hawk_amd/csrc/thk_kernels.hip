@@ -243,6 +243,10 @@ hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, b
 }
 
 
+static_assert(KernargLead<decltype(&gemv_kernel<1, 8, 8, 1, 3, true, 0, true, 4>)>::bytes() == kKernargPreloadBytes &&
+              KernargLead<decltype(&gemv_kernel<1, 8, 8, 0, 2, true, 0, true, 4>)>::bytes() == kKernargPreloadBytes,
+              "gemv_kernel: the explicit scalars ahead of GemvArgs must fill exactly the 14 preloaded dwords");
+
 // leading scalars: preloaded into SGPRs at wave launch (see gemv_kernel) - the position, q and the cache rows are what the chain
 // of dependent loads starts from
 template <int D, int WAVES, bool KVH, int VS, bool PIPE = false>
@@ -282,6 +286,8 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
 }
 
 // Stand-alone combine of split partials -> out[H*D] (used by thk_attn_decode when nsplit > 1).
+static_assert(KernargLead<decltype(&attn_decode_kernel<128, 8, false, 1, false>)>::bytes() == kKernargPreloadBytes,
+              "attn_decode_kernel: the explicit scalars ahead of AttnArgs must fill exactly the 14 preloaded dwords");
 __global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, float* out,
                                     int H, int D, int nsplit) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;

@@ -156,6 +156,21 @@ struct EngArgs {
 size_t engine_lds_bytes(int NS, int v0_bytes, int v1_bytes);
 hipError_t launch_engine(const EngArgs& a, int n_cu, hipStream_t st);
 
+// Byte offset of a kernel's LAST parameter in its kernarg segment = size of the explicit leading scalars in front of the by-value argument struct.
+// The build preloads exactly 14 dwords (hipcc -mllvm -amdgpu-kernarg-preload-count=14, __graft_entry__.py) and the kernels that depend on it read
+// those scalars before their first s_waitcnt: adding, removing or reordering a leading argument must be a compile error, not a silent slow path.
+template <class F> struct KernargLead;
+template <class... A> struct KernargLead<void (*)(A...)> {
+    static constexpr size_t bytes() {
+        constexpr size_t n = sizeof...(A);
+        const size_t sz[] = {sizeof(A)...}, al[] = {alignof(A)...};
+        size_t off = 0;
+        for (size_t i = 0; i + 1 < n; ++i) off = (off + al[i] - 1) / al[i] * al[i] + sz[i];
+        return (off + al[n - 1] - 1) / al[n - 1] * al[n - 1];
+    }
+};
+constexpr size_t kKernargPreloadBytes = 14 * 4;
+
 // thk_prefill.hip
 hipError_t launch_gemm_f16_prefill(const uint16_t* W, int R, int C, const float* X, int M, float* Y, void* workspace, hipStream_t st);
 size_t gemm_prefill_workspace_bytes(int M, int R, int C);

@@ -280,6 +280,7 @@ extern "C" int thk_model_finalize(thk_model* m) {
         const size_t slots = (size_t)std::max(m->grid_head > 0 ? m->grid_head : 1, ctx->n_cu) + 512;
         ALLOCZ(m->block_best, slots * 8 * 2);
         m->block_best_aux = m->block_best + slots;
+        m->block_best_slots = slots;
     }
     ALLOCZ(m->rope_tab, T * (D / 2) * 2 * 4);
     {
@@ -419,6 +420,20 @@ extern "C" void* thk_model_hidden_out(thk_model* m, int32_t seq) { return (m && 
 extern "C" void* thk_model_token_dev(thk_model* m, int32_t seq) { return (m && m->finalized && seq >= 0 && seq < m->n_seq) ? (void*)&m->seqs[seq].st->token : nullptr; }
 extern "C" void* thk_model_logits_dev(thk_model* m, int32_t seq) { return (m && m->finalized && seq >= 0 && seq < m->n_seq) ? m->seqs[seq].logits : nullptr; }
 
+// The folded greedy pick gave up on a key slot (a workgroup of an lm-head launch never delivered within 1 s of device time): the
+// finisher zeroed the slot and set SeqState::pad, but the late workgroup's write-through key may have landed AFTERWARDS - a non-zero
+// slot at the start of the next launch, i.e. a stale key that every later step could reduce (advisor, round 4).  Nothing on the device
+// repairs that, so the host does when it sees the word: drain the stream, zero every key slot, clear the word, report the failure once.
+int report_pick_timeout(thk_model* m, int seq) {
+    thk_ctx* ctx = m->ctx;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (m->block_best && m->block_best_slots) HIPCHK(ctx, hipMemsetAsync(m->block_best, 0, m->block_best_slots * 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(&m->seqs[seq].st->pad, 0, 4, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return fail(ctx, THK_ERR_STATE, "sequence %d: the lm-head launch's folded greedy pick gave up waiting for an arg-max key (a workgroup of the launch never delivered); "
+                "tokens from that step on are not trustworthy - the key slots have been cleared, set the sequence again (thk_model_seq_set) before decoding on", seq);
+}
+
 extern "C" int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out, int32_t cap, int32_t* n_out, int32_t* pos_out) {
     if (!m) return THK_ERR_INVALID;
     thk_ctx* ctx = m->ctx;
@@ -435,7 +450,7 @@ extern "C" int thk_model_seq_get(thk_model* m, int32_t seq, int32_t* tokens_out,
     }
     if (n_out) *n_out = h.n_gen;
     if (pos_out) *pos_out = h.pos;
-    if (h.pad != 0) return fail(ctx, THK_ERR_STATE, "sequence %d: the lm-head launch's folded greedy pick gave up waiting for an arg-max key (a workgroup of the launch never delivered); tokens from that step on are not trustworthy", seq);
+    if (h.pad != 0) return report_pick_timeout(m, seq);
     return check_engine_error(m);
 }
 
@@ -486,7 +501,7 @@ extern "C" int thk_model_seq_last_token(thk_model* m, int32_t seq, int32_t* toke
     HIPCHK(ctx, hipMemcpyAsync(&h, m->seqs[seq].st, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     *token_out = h.token;
-    if (h.pad != 0) return fail(ctx, THK_ERR_STATE, "sequence %d: the folded greedy pick gave up waiting for an arg-max key", seq);
+    if (h.pad != 0) return report_pick_timeout(m, seq);
     return check_engine_error(m);
 }
 

@@ -334,6 +334,9 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
 #undef THK_PIN_ACC
 }
 
+static_assert(KernargLead<decltype(&gemm_prefill_v3_kernel<4, 2, true, kNST>)>::bytes() == kKernargPreloadBytes + 8,
+              "gemm_prefill_v3_kernel: ten scalars (14 dwords, preloaded) and the partial-tile pointer ahead of the plan");
+
 // ---- weight tile images ------------------------------------------------------------------------
 // A row-major f16 matrix [R][C] rewritten as the sequence of LDS images the GEMM loads: for row-block rb (tile_rows rows)
 // and K-chunk ch (32 columns) one contiguous block of tile_rows x 64 bytes, row r_in_tile at r_in_tile*64, its four
