@@ -298,7 +298,7 @@ def extra_decode_ctx2048(thk, ctx, stream, torch, kv_f16, steps=60, warmup=10):
                 "step_roofline": {"achieved": round(b_tok * tok_s / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b_tok * tok_s / 1e9 / HBM_PEAK_GBS, 4)},
                 "attention": {"alg_bytes": att.get("alg_bytes"), "eager_avg_us": att.get("eager_avg_us"), "eager_gbs": att.get("eager_gbs"),
                               "eager_frac_of_hbm_peak": round(att["eager_gbs"] / HBM_PEAK_GBS, 4) if att.get("eager_gbs") else None,
-                              "attn_splits": 8, "workgroups": shape.n_head * 8 * (2 if ctx.get_tunable("attn_vsplit") == 2 else 1),
+                              "attn_splits": 8, "workgroups": shape.n_head * 8,
                               "variant": "software-pipelined rounds (two K/V batches in flight per wave)"}}
     finally:
         m.close()
@@ -827,7 +827,7 @@ def main():
                        "n_ctx": shape.n_ctx, "T": T, "sequences": S, "parallelism": f"pp{N}" if N > 1 else "single", "transport": args.transport if PIPE else None,
                        "lmhead_mode": args.lmhead, "numerics": "f16 GGML weights x f32 activations, f32 accumulate, " + ("f32 KV cache (as the reference)" if kv_bytes == 4 else "binary16 KV cache (OPTION, not the reference's: s_kv = 2 in bytes/token)"),
                        "decode_path": "persistent engine (1 launch/step)" if model.uses_engine() else "5 fused launches per layer + lm-head (greedy pick folded in), kernel arguments preloaded into SGPRs, hipGraph replay (n-step graphs, n <= 32: 20 steps = one graph)",
-                       "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "attn_vsplit", "attn_tc_dyn", "attn_waves", "use_graph", "engine", "fold_embed", "fold_finish")}},
+                       "tunables": {k: ctx.get_tunable(k) for k in ("gemv_blocks_per_cu", "attn_splits", "attn_tc_dyn", "attn_waves", "use_graph", "engine", "fold_embed", "fold_finish")}},
             "bytes_per_token": b_tok,
             "step_roofline": {"achieved": round(step_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                               "frac_of_copy_rate": round(step_gbs / COPY_RATE_GBS, 4), "event_ms_per_step": round(ev_ms / args.steps, 4)},

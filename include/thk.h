@@ -338,14 +338,19 @@ int thk_peer_destroy(thk_peer* p);
  * rebuilding.  Decode knobs must be set before thk_model_finalize; prefill knobs are read
  * per call.  Unknown names return THK_ERR_NOTFOUND.
  *   decode : gemv_blocks_per_cu; gemv_bpc_{qkv,wo,w13,w2,head} and gemv_variant_{...}
- *            (-1 = per-shape default, 0 = generic, >0 explicit; variants 0-4 batch loops, 5-7 software-pipelined loops,
- *            1 | 6 = single rows - for qkv and w13 the RoPE / SwiGLU pair then meets in LDS -, w2 only: 8 | 9 = a workgroup
- *            per row with one | two rows in flight per wave); gemv_grid_{...} (> 0: that many workgroups, whatever
- *            gemv_bpc_* says); attn_splits (1|2|4|8);
+ *            (-1 = per-shape default; 0, 1, 2 batch loops - row pairs, single rows, row pairs in half batches -, 5, 6
+ *            software-pipelined loops - row pairs, single rows; for qkv and w13 single rows meet their RoPE / SwiGLU partner
+ *            in LDS -, w2 only: 8 = a workgroup per row, a wave per quarter of it; 3, 4, 7, 9 are retired numbers);
+ *            gemv_grid_{...} (> 0: that many workgroups, whatever gemv_bpc_* says); attn_splits (1|2|4|8);
  *            attn_waves (4|8); use_graph; kv_f16 (1 = K/V caches stored as binary16, rounded RNE at the append: half the
  *            KV bytes, thk_model_bytes_per_token then counts s_kv = 2; default 0 = f32 like the reference,
  *            th-llama-loader.cpp:335); engine (1 = persistent loader/consumer launch per step when the
- *            shape allows, 0 = launches); attn_vsplit, attn_tc_dyn, fold_finish, fold_embed;
+ *            shape allows, 0 = launches); attn_tc_dyn, fold_embed; fold_finish (1, default: the lm-head
+ *            launch's highest-numbered workgroup polls the other workgroups' arg-max key slots and finishes the token inside
+ *            the launch - this LEANS ON workgroups being dispatched in index order, which HIP does not promise: a workgroup
+ *            that never delivers is bounded by a 1 s device time-out -> SeqState error word -> THK_ERR_STATE from
+ *            thk_model_seq_get / seq_last_token, which also clear the key slots; 0 = the pick as a launch of its own, no
+ *            in-launch wait, kept tested);
  *            measure_skip_kernel (1..6: that kernel is not launched -- bench.py's marginal-cost
  *            measurement; results are garbage; REFUSED unless the environment has THK_MEASURE_HOOKS=1)
  *   prefill: prefill_blocks_{qkv,wo,w13,w2} (workgroups per GEMM launch, <= 256);

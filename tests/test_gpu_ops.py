@@ -35,10 +35,10 @@ def test_matvec_f16(ctx, orc, R, C):
     assert np.abs(got - exp).max() < TOL * max(1.0, np.abs(exp).max())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 5, 6])
 @pytest.mark.parametrize("bpc", [1, 4, 8])
 def test_matvec_variants_and_grids(ctx, orc, variant, bpc):
-    """Every (rows/iteration, slots/batch) variant - batch loops 0-4, software-pipelined loops 5-7 - and grid size gives the
+    """Every (rows/iteration, slots/batch) variant - batch loops 0-2, software-pipelined loops 5-6 - and grid size gives the
     same answer (a wave takes 1, 2 or more row groups depending on the grid, so the pipelined refill and its last-group
     epilogue are both exercised)."""
     rng = np.random.default_rng(variant * 7 + bpc)
@@ -134,21 +134,20 @@ def oracle_attention(orc, q, Kc, Vc, T, H, D):
     return orc.mat_mul(P, Vw, False, 1.0).reshape(H * D)
 
 
-@pytest.mark.parametrize("geom", [(2, 1), (1, 1), (2, 0), (1, 0)], ids=["vsplit2-dyn", "vsplit1-dyn", "vsplit2-static", "vsplit1-static"])
+@pytest.mark.parametrize("geom", [(1,), (0,)], ids=["dyn", "static"])
 @pytest.mark.parametrize("splits", [1, 2, 4, 8])
 @pytest.mark.parametrize("T,H,D,n_ctx", [(1, 32, 128, 512), (2, 32, 128, 512), (17, 8, 64, 64), (64, 8, 64, 64),
                                          (129, 32, 128, 512), (512, 32, 128, 512), (300, 40, 128, 512),
                                          (50, 12, 64, 64), (33, 4, 256, 64), (700, 32, 128, 2048)])
 def test_attn_decode(ctx, orc, splits, T, H, D, n_ctx, geom):
-    """K8+K9+K10+K9+K8 in one launch, in every launch geometry: `geom` = (workgroups per (head, split) - 2 halves the V columns
-    between a pair that shares the split's K rows -, splits follow the live context T | the cache capacity).  H = 12 / H = 4 make
-    H * splits a non-multiple of 8 (the pair then sits in adjacent workgroups), D = 256 is the widest head, T = 700 of 2048 leaves
-    most of the capacity unused (static splits: one workgroup per head gets everything)."""
+    """K8+K9+K10+K9+K8 in one launch, in every launch geometry: splits follow the live context T | the cache capacity.  H = 12 / H = 4
+    make H * splits a non-multiple of 8, D = 256 is the widest head, T = 700 of 2048 leaves most of the capacity unused (static
+    splits: one workgroup per head gets everything)."""
     rng = np.random.default_rng(T * 31 + H)
     E = H * D
     q, Kc, Vc = rnd(rng, E), rnd(rng, n_ctx, E), rnd(rng, n_ctx, E)
     Kc[T:] = 1e6; Vc[T:] = 1e6   # rows beyond T must never be read
-    names = ("attn_splits", "attn_vsplit", "attn_tc_dyn")
+    names = ("attn_splits", "attn_tc_dyn")
     old = {k: ctx.get_tunable(k) for k in names}
     try:
         for k, v in zip(names, (splits,) + geom):

@@ -32,9 +32,6 @@ void default_tunables(thk_ctx* ctx) {
         ctx->tun[std::string("gemv_variant_") + k] = -1;   // (rows/iteration, slots/batch) variant, see gemv_variant()
     }
     ctx->tun["attn_splits"] = 0;          // context splits per head: 0 = auto (4; 8 when n_ctx > 1024), or 1, 2, 4, 8
-    ctx->tun["attn_vsplit"] = 1;          // workgroups per (head, split): 2 = a pair shares the split's K rows and halves its V columns (256 workgroups for 7B);
-                                          // measured: no gain at T = 512 (5.13 vs 5.07 us - the launch is a latency chain, not bound by what one CU pulls), 50 % slower
-                                          // at T = 2048 (profiles/r04_attention_ctx2048.txt), so 1 is the default and 2 a parity-tested option
     ctx->tun["attn_tc_dyn"] = 1;          // 1 = the splits partition the live context T (tc computed on the device), 0 = the cache capacity n_ctx
     ctx->tun["fold_finish"] = 1;          // the lm-head launch's last workgroup reduces the arg-max keys and finishes the token (no launch of its own)
     ctx->tun["attn_waves"] = 8;           // waves per attention block (4 or 8)

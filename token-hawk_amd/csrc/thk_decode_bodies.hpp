@@ -342,8 +342,10 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
             // whole argument block moves to scratch memory - seen in the ISA)
             // (the distance in BYTES on integers: w1 and w3 may live in different allocations, where a typed pointer difference is undefined
             // and would drop an odd byte; advisor, round 4)
-            const uintptr_t to_w3 = (g & 1) ? reinterpret_cast<uintptr_t>(a.W[1]) - reinterpret_cast<uintptr_t>(a.W[0]) : (uintptr_t)0;
-            rp[0] = reinterpret_cast<const h8*>(reinterpret_cast<uintptr_t>(a.W[0]) + to_w3 + (uintptr_t)(g >> 1) * (uintptr_t)C * 2u);
+            // The address stays an offset from the kernel argument a.W[0] (a pointer rebuilt from an integer loses its address space: the
+            // weight stream turned into FLAT loads and the launch took 33.5 instead of 30.2 us, measured in round 5).
+            const ptrdiff_t to_w3 = (g & 1) ? (ptrdiff_t)(reinterpret_cast<uintptr_t>(a.W[1]) - reinterpret_cast<uintptr_t>(a.W[0])) : (ptrdiff_t)0;
+            rp[0] = reinterpret_cast<const h8*>(reinterpret_cast<const char*>(a.W[0]) + to_w3 + (size_t)(g >> 1) * C * 2);
         } else if (EPI == EPI_SWIGLU) {
             rp[0] = reinterpret_cast<const h8*>(a.W[0] + (size_t)g * C);
             rp[1 % NR] = reinterpret_cast<const h8*>(a.W[1] + (size_t)g * C);
@@ -740,25 +742,16 @@ __device__ __forceinline__ void gemv_quarter_body(const GemvArgs& a, const int b
     THK_STAMP(a.trace, bid, 3);
 }
 // ---------------------------------------------------------------- attention (decode)
-// grid = H * nsplit * VS blocks; block (h, s, vh) owns positions [s*tc, (s+1)*tc) of head h and, when VS == 2, half vh of the
-// head's V columns.
+// grid = H * nsplit blocks; block (h, s) owns positions [s*tc, (s+1)*tc) of head h.
 // A position's head slice is D contiguous floats; D/4 lanes x float4 cover it, so a wave-instruction fetches PPW = 64/(D/4)
-// positions of K.  Each wave runs an online softmax over its positions, the waves are merged through LDS, and the block writes
-// (m, l, o[D/VS]) for the split (or the normalised output when nsplit == 1).
+// positions of K (and of V).  Each wave runs an online softmax over its positions, the waves are merged through LDS, and the block
+// writes (m, l, o[D]) for the split (or the normalised output when nsplit == 1).
 // Scores: S = (q.k) * 1/sqrt(D) scaled after the sum (th.cpp:527-529, th-llama.cpp:518); softmax K10 th.cpp:1901-1957.
 // WAVES waves per block share one (head, split): more waves = fewer positions per wave, so every wave needs a single load batch
 // (one HBM round trip) at T = 512 with 4 splits.
-//
-// VS == 2 (round 4, an OPTION: tunable attn_vsplit): 7B has H * nsplit = 128 (head, split) pairs and the chip has 256 CUs.  Doubling
-// the splits doubles the partials every wo workgroup reads (measured -2 %); instead TWO workgroups share a (head, split): both read
-// its K slice and compute the same scores (bit-identical: same instructions on the same data), each takes half of the V columns
-// and writes half of o with the identical (m, l) - 96 KB per CU on 256 CUs and the consumer's prologue (ProAttn) reads exactly what
-// it read before.  The pair is workgroups b and b + 8 of a group of 16: workgroup i runs on XCD i % 8, so the pair shares an L2.
-// V lanes: D/(4 VS) lanes cover a position's half slice, PPW * VS positions per wave-instruction, UB / VS instructions.  The
-// position a lane takes in V instruction u' is the one its own K lane group handled in K instruction VS*u' + (its V lane group
-// & 1), so the softmax weight is already in the lane's registers (a bit-mask blend, no shuffle).
-// MEASURED: no gain at T = 512 (5.13 vs 5.07 us span) and 50 % slower at T = 2048 - the launch is a chain of dependent round trips
-// (position -> K/V batch -> softmax -> LDS merge), not bound by what one CU pulls - so VS = 1 is the default.
+// (Round 4 also had workgroup PAIRS that shared a split's K rows and halved its V columns - 256 workgroups for 7B without doubling
+// wo's partials: null at T = 512, 50 % slower at T = 2048, the launch is a chain of dependent round trips and not bound by what one
+// CU pulls; removed in round 5)
 //
 // tc_dyn (round 4): tc follows the LIVE context, tc = ceil(T / nsplit) rounded up to the wave batch (PPW * UB positions), computed
 // here from the device-resident position - every (head, split) has work at every T >= nsplit * PPW * UB instead of the splits
@@ -772,37 +765,26 @@ __device__ __forceinline__ f4 ld_kv4(const float* base, size_t elem_off) {
     }
     return __builtin_nontemporal_load(reinterpret_cast<const f4*>(base + elem_off));
 }
-template <int D, int WAVES, bool KVH, int VS = 1, bool PIPE = false>
+template <int D, int WAVES, bool KVH, bool PIPE = false>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
-    constexpr int LPP = D / 4;          // lanes per position (K)
-    constexpr int PPW = 64 / LPP;       // positions per wave-instruction (K)
-    constexpr int UB = 8;               // K wave-instructions per batch
-    constexpr int DV = D / VS;          // V columns of this block
-    constexpr int LPV = DV / 4, PPV = 64 / LPV, UBV = UB / VS;   // the same three for V
-    static_assert(VS == 1 || VS == 2, "V columns are whole or halved");
-    __shared__ float sm_o[WAVES][DV];
+    constexpr int LPP = D / 4;          // lanes per position
+    constexpr int PPW = 64 / LPP;       // positions per wave-instruction
+    constexpr int UB = 8;               // wave-instructions per batch (K and V each)
+    __shared__ float sm_o[WAVES][D];
     __shared__ float sm_ml[WAVES][2];
 
     const int pos0 = a.pos_ptr ? *a.pos_ptr : a.pos_val;        // requested first: a scalar load from memory whose latency the index arithmetic below hides
     __builtin_amdgcn_sched_barrier(0);
     // prefill: nq > 1 causal queries share one launch; query qi sits at position pos + qi
     const int hs = a.H * a.nsplit;
-    const int per_q = hs * VS;
-    const int qi = a.nq > 1 ? bid / per_q : 0;
-    const int r = bid - qi * per_q;
-    int hb = r, vh = 0;
-    if (VS == 2) {
-        if ((hs & 7) == 0) { vh = (r >> 3) & 1; hb = ((r >> 4) << 3) | (r & 7); }   // the pair = workgroups b, b + 8: same XCD
-        else { vh = r & 1; hb = r >> 1; }
-    }
+    const int qi = a.nq > 1 ? bid / hs : 0;
+    const int hb = bid - qi * hs;
     // x / nsplit by multiply-high (ns_magic = ceil(2^32 / nsplit); 0 = nsplit is 1): an integer division is ~40 instructions, and two
     // of them stood between the kernel's entry and the request for the position every K/V address depends on
     auto div_ns = [&](int x) -> int { return a.ns_magic ? (int)__umulhi((unsigned)x, a.ns_magic) : x; };
     const int h = div_ns(hb), s = hb - h * a.nsplit;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = lane / LPP, li = lane - grp * LPP;
-    const int grv = lane / LPV, lv = lane - grv * LPV;          // VS == 2: grp == grv >> 1
-    const int sel = (VS == 2) ? (grv & 1) : 0;
     THK_STAMP(a.trace, bid, 0);
     const int T = pos0 + qi + 1;
     const int E = a.H * D;
@@ -811,8 +793,7 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     const int t0 = s * tc, t1 = min(t0 + tc, T);
 
     const f4 q = *reinterpret_cast<const f4*>(a.q + qi * E + h * D + li * 4);
-    const size_t koff = (size_t)(h * D + li * 4);               // element offset of this lane's K slice inside a cache row
-    const size_t voff = (size_t)(h * D + vh * DV + lv * 4);     // ... and of its V slice
+    const size_t koff = (size_t)(h * D + li * 4);               // element offset of this lane's K (and V) slice inside a cache row
 
     float m = -INFINITY, l = 0.f;
     f4 o = {0.f, 0.f, 0.f, 0.f};
@@ -822,16 +803,16 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     // allocated - to take the position's round trip off the critical path: 0.6 us per launch SLOWER on MI355X, removed.)
     if constexpr (!PIPE) {
     for (int tb = t0 + wave * (PPW * UB); tb < t1; tb += WAVES * PPW * UB) {
-        f4 kv[UB], vv[UBV];
+        f4 kv[UB], vv[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int t = min(tb + u * PPW + grp, t1 - 1);
             kv[u] = ld_kv4<KVH>(a.kcache, (size_t)t * E + koff);
         }
 #pragma unroll
-        for (int u = 0; u < UBV; ++u) {
-            const int t = min(tb + (VS * u + sel) * PPW + grp, t1 - 1);
-            vv[u] = ld_kv4<KVH>(a.vcache, (size_t)t * E + voff);
+        for (int u = 0; u < UB; ++u) {
+            const int t = min(tb + u * PPW + grp, t1 - 1);
+            vv[u] = ld_kv4<KVH>(a.vcache, (size_t)t * E + koff);
         }
         __builtin_amdgcn_sched_barrier(0);
         float sc[UB];
@@ -851,16 +832,8 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
         float p[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) { p[u] = expf(sc[u] - mn); l += p[u]; }   // exp(-inf) == 0 for masked positions
-        // VS == 2: the lane's V position of instruction u is K position 2u + sel.  Blended with a bit mask, not with `sel ? a : b`:
-        // the compiler turns a select of two array elements into ONE dynamically indexed access and then moves the whole array
-        // into LDS (18 KB per workgroup, attention 6x slower - measured, round 4).
-        const unsigned selm = 0u - (unsigned)sel;
 #pragma unroll
-        for (int u = 0; u < UBV; ++u) {
-            float pv = p[u % UB];
-            if (VS == 2) pv = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, p[(2 * u + 1) % UB]) & selm) | (__builtin_bit_cast(unsigned, p[(2 * u) % UB]) & ~selm));
-            o += vv[u] * pv;
-        }
+        for (int u = 0; u < UB; ++u) o += vv[u] * p[u];
         m = mn;
         THK_STAMP(a.trace, bid, 1);
     }
@@ -869,24 +842,24 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     // pipelined - the next round's K/V batch is requested BEFORE this round's softmax arithmetic, so a wave has two batches in
     // flight and the rounds are not a chain of dependent HBM round trips.  A variant of its own: the same structure cost the
     // single-round case (T <= 512 with 4 splits, the headline) 1 us per launch (profiles/r04_attention_ctx2048.txt).
-    auto fetch = [&](int tb, f4 (&kv)[UB], f4 (&vv)[UBV]) {
+    auto fetch = [&](int tb, f4 (&kv)[UB], f4 (&vv)[UB]) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int t = min(tb + u * PPW + grp, t1 - 1);
             kv[u] = ld_kv4<KVH>(a.kcache, (size_t)t * E + koff);
         }
 #pragma unroll
-        for (int u = 0; u < UBV; ++u) {
-            const int t = min(tb + (VS * u + sel) * PPW + grp, t1 - 1);
-            vv[u] = ld_kv4<KVH>(a.vcache, (size_t)t * E + voff);
+        for (int u = 0; u < UB; ++u) {
+            const int t = min(tb + u * PPW + grp, t1 - 1);
+            vv[u] = ld_kv4<KVH>(a.vcache, (size_t)t * E + koff);
         }
     };
     constexpr int STRIDE = WAVES * PPW * UB;
     int tb = t0 + wave * (PPW * UB);
-    f4 kv[UB], vv[UBV];
+    f4 kv[UB], vv[UB];
     if (tb < t1) fetch(tb, kv, vv);
     while (tb < t1) {
-        f4 kvn[UB], vvn[UBV];
+        f4 kvn[UB], vvn[UB];
         const int tn = tb + STRIDE;
         const bool more = tn < t1;                  // wave-uniform
         if (more) fetch(tn, kvn, vvn);
@@ -908,37 +881,27 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
         float p[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) { p[u] = expf(sc[u] - mn); l += p[u]; }   // exp(-inf) == 0 for masked positions
-        // VS == 2: the lane's V position of instruction u is K position 2u + sel.  Blended with a bit mask, not with `sel ? a : b`:
-        // the compiler turns a select of two array elements into ONE dynamically indexed access and then moves the whole array
-        // into LDS (18 KB per workgroup, attention 6x slower - measured, round 4).
-        const unsigned selm = 0u - (unsigned)sel;
 #pragma unroll
-        for (int u = 0; u < UBV; ++u) {
-            float pv = p[u % UB];
-            if (VS == 2) pv = __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, p[(2 * u + 1) % UB]) & selm) | (__builtin_bit_cast(unsigned, p[(2 * u) % UB]) & ~selm));
-            o += vv[u] * pv;
-        }
+        for (int u = 0; u < UB; ++u) o += vv[u] * p[u];
         m = mn;
         THK_STAMP(a.trace, bid, 1);
         if (more) {
 #pragma unroll
             for (int u = 0; u < UB; ++u) kv[u] = kvn[u];
 #pragma unroll
-            for (int u = 0; u < UBV; ++u) vv[u] = vvn[u];
+            for (int u = 0; u < UB; ++u) vv[u] = vvn[u];
         }
         tb = tn;
     }
     }
-    // merge the lane groups of the wave (same m): l over the PPW K groups, o over the PPV V groups
+    // merge the lane groups of the wave (same m)
 #pragma unroll
-    for (int off = LPP; off < 64; off <<= 1) l += __shfl_xor(l, off);
-#pragma unroll
-    for (int off = LPV; off < 64; off <<= 1) { o.x += __shfl_xor(o.x, off); o.y += __shfl_xor(o.y, off); o.z += __shfl_xor(o.z, off); o.w += __shfl_xor(o.w, off); }
-    if (lane < LPV) *reinterpret_cast<f4*>(&sm_o[wave][lane * 4]) = o;
+    for (int off = LPP; off < 64; off <<= 1) { l += __shfl_xor(l, off); o.x += __shfl_xor(o.x, off); o.y += __shfl_xor(o.y, off); o.z += __shfl_xor(o.z, off); o.w += __shfl_xor(o.w, off); }
+    if (lane < LPP) *reinterpret_cast<f4*>(&sm_o[wave][lane * 4]) = o;
     if (lane == 0) { sm_ml[wave][0] = m; sm_ml[wave][1] = l; }
     __syncthreads();
     THK_STAMP(a.trace, bid, 2);
-    if (threadIdx.x < DV) {
+    if (threadIdx.x < D) {
         const int d = threadIdx.x;
         float M = -INFINITY;
         for (int w = 0; w < WAVES; ++w) M = fmaxf(M, sm_ml[w][0]);
@@ -949,10 +912,10 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
             L += sm_ml[w][1] * f; od += sm_o[w][d] * f;
         }
         if (a.out) {   // nsplit == 1: finished output, [H*D]
-            a.out[(size_t)qi * E + h * D + vh * DV + d] = od / L;
+            a.out[(size_t)qi * E + h * D + d] = od / L;
         } else {       // split partial: combined by the consumer's prologue (ProAttn) or by attn_combine_kernel
-            a.part_o[(size_t)(h * a.nsplit + s) * D + vh * DV + d] = od;
-            if (d == 0 && vh == 0) { a.part_ml[(h * a.nsplit + s) * 2] = M; a.part_ml[(h * a.nsplit + s) * 2 + 1] = L; }
+            a.part_o[(size_t)(h * a.nsplit + s) * D + d] = od;
+            if (d == 0) { a.part_ml[(h * a.nsplit + s) * 2] = M; a.part_ml[(h * a.nsplit + s) * 2 + 1] = L; }
         }
     }
     THK_STAMP(a.trace, bid, 3);

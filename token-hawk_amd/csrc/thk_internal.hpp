@@ -121,7 +121,6 @@ struct thk_model {
     unsigned long long* trace_buf = nullptr;   // development timeline of the launch path (thk_model_step_trace, THK_TRACE builds)
     bool trace_on = false;
     int fold_finish = 1;                 // tunable fold_finish: the lm-head launch's last workgroup picks the greedy token (no finish_token launch)
-    int attn_vsplit = 1;                 // tunable attn_vsplit: workgroups per (head, split) of the attention launch, each taking 1/vsplit of the V columns
     int attn_tc_dyn = 1;                 // tunable attn_tc_dyn: the context splits partition the LIVE context (computed on the device), not the cache capacity
 };
 

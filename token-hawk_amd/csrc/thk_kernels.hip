@@ -133,14 +133,15 @@ static int ns_class(int C) {
 }
 // (NR rows per wave iteration, U slots per load batch, pipelined loop) variants per class, selectable at run
 // time (tunable "gemv_variant_*") so launch geometry can be swept on the GPU without rebuilding.
-//   0-3  batch loop: NR*U loads, then their FMAs, per batch
-//   4    batch loop with four whole rows per wave in ONE batch (4096/5120 columns)
-//   5-7  software-pipelined loop (gemv_body PIPE): one whole row group in flight, slot c of the next group requested as soon as
-//        slot c of the current one is consumed.  5 = row pair (one row for 11008/13824 columns), 6 = one row, 7 = four rows
+//   0-2  batch loop: NR*U loads, then their FMAs, per batch (0 = row pairs, 1 = single rows, 2 = row pairs in half batches)
+//   5-6  software-pipelined loop (gemv_body PIPE): one whole row group in flight, slot c of the next group requested as soon as
+//        slot c of the current one is consumed.  5 = row pair (one row for 11008/13824 columns), 6 = one row
+//   3, 4, 7 (four rows per wave in flight) measured slower than their neighbours in rounds 3 and 4 and were retired in round 5:
+//        the numbers stay reserved and select 0 / 0 / 5
 void gemv_variant(int C, int epi, int nru, int* NR, int* U, int* pipe) {
     const bool pair = false;                   // EPI_ROPE_KV and EPI_SWIGLU take their two rows together (NR = 2) or as single rows (NR = 1, the pair meets in LDS)
-    static const int t8[8][3] = {{2, 8, 0}, {1, 8, 0}, {2, 4, 0}, {4, 4, 0}, {4, 8, 0}, {2, 8, 1}, {1, 8, 1}, {4, 8, 1}};
-    static const int t10[8][3] = {{2, 10, 0}, {1, 10, 0}, {2, 5, 0}, {4, 5, 0}, {4, 10, 0}, {2, 10, 1}, {1, 10, 1}, {4, 10, 1}};
+    static const int t8[8][3] = {{2, 8, 0}, {1, 8, 0}, {2, 4, 0}, {2, 8, 0}, {2, 8, 0}, {2, 8, 1}, {1, 8, 1}, {2, 8, 1}};
+    static const int t10[8][3] = {{2, 10, 0}, {1, 10, 0}, {2, 5, 0}, {2, 10, 0}, {2, 10, 0}, {2, 10, 1}, {1, 10, 1}, {2, 10, 1}};
     static const int t22[8][3] = {{2, 11, 0}, {1, 11, 0}, {1, 22, 0}, {2, 11, 0}, {2, 11, 0}, {1, 22, 1}, {1, 22, 1}, {1, 22, 1}};
     static const int t27[8][3] = {{2, 9, 0}, {1, 9, 0}, {1, 27, 0}, {2, 9, 0}, {2, 9, 0}, {1, 27, 1}, {1, 27, 1}, {1, 27, 1}};
     const int (*t)[3] = t8;
@@ -148,7 +149,6 @@ void gemv_variant(int C, int epi, int nru, int* NR, int* U, int* pipe) {
     switch (cls) { case 10: t = t10; break; case 22: t = t22; break; case 27: t = t27; break; default: break; }
     if (nru < 0 || nru > 7) nru = 0;
     if (cls == 0 && nru > 4) nru = 0;                  // the pipelined loop needs a compile-time slot count
-    if (cls == 0 && nru == 4) nru = 3;
     if ((pair && t[nru][0] != 2) || ((epi == EPI_ROPE_KV || epi == EPI_SWIGLU) && t[nru][0] > 2)) nru = t[nru][2] ? 5 : 0;
     *NR = t[nru][0]; *U = t[nru][1];
     if (pipe) *pipe = t[nru][2];
@@ -162,9 +162,9 @@ static hipError_t launch_gemv_ns(int NR, int U, int pipe, const GemvArgs& a, int
     if constexpr ((NS == 0 || NS % (u) == 0) && (!pair || (nr) == 2) && (!rope || (nr) <= 2) && (!(pp) || (NS != 0 && (u) == NS))) {   \
         if (NR == (nr) && U == (u) && pipe == (pp)) return launch_gemv_t<nr, u, NS, PRO, EPI, (pp) != 0>(a, grid, nt, st); \
     }
-    if constexpr (NS == 8 || NS == 0) { THK_TRY(2, 8, 0) THK_TRY(1, 8, 0) THK_TRY(2, 4, 0) THK_TRY(4, 4, 0) }
-    if constexpr (NS == 8) { THK_TRY(4, 8, 0) THK_TRY(2, 8, 1) THK_TRY(1, 8, 1) THK_TRY(4, 8, 1) }
-    if constexpr (NS == 10) { THK_TRY(2, 10, 0) THK_TRY(1, 10, 0) THK_TRY(2, 5, 0) THK_TRY(4, 5, 0) THK_TRY(4, 10, 0) THK_TRY(2, 10, 1) THK_TRY(1, 10, 1) THK_TRY(4, 10, 1) }
+    if constexpr (NS == 8 || NS == 0) { THK_TRY(2, 8, 0) THK_TRY(1, 8, 0) THK_TRY(2, 4, 0) }
+    if constexpr (NS == 8) { THK_TRY(2, 8, 1) THK_TRY(1, 8, 1) }
+    if constexpr (NS == 10) { THK_TRY(2, 10, 0) THK_TRY(1, 10, 0) THK_TRY(2, 5, 0) THK_TRY(2, 10, 1) THK_TRY(1, 10, 1) }
     if constexpr (NS == 22) { THK_TRY(2, 11, 0) THK_TRY(1, 11, 0) THK_TRY(1, 22, 0) THK_TRY(1, 22, 1) }
     if constexpr (NS == 27) { THK_TRY(2, 9, 0) THK_TRY(1, 9, 0) THK_TRY(1, 27, 0) THK_TRY(1, 27, 1) }
 #undef THK_TRY
@@ -183,7 +183,7 @@ static hipError_t launch_gemv_pe(int nru, const GemvArgs& a, int grid, bool nt, 
     }
 }
 
-// quarter-row form of y = resid + W x (gemv_quarter_body; tunable gemv_variant_w2 = 8 | 9: one | two rows in flight per wave)
+// quarter-row form of y = resid + W x (gemv_quarter_body; tunable gemv_variant_w2 = 8; two rows in flight per wave - 9 - measured slower, retired)
 template <int NS, int NR>
 __global__ __launch_bounds__(kWaves * 64) void gemv_quarter_kernel(const uint16_t* W0, const float* x, const float* resid, float* y, int C, int R, int nblk, const GemvArgs a) {
     GemvArgs b = a;
@@ -213,14 +213,13 @@ static hipError_t launch_gemv_quarter_k(const GemvArgs& a, int grid, hipStream_t
 bool gemv_quarter_ok(int C, int R, int grid) {
     return (C == 4096 || C == 5120 || C == 11008 || C == 13824) && grid > 0 && (long)grid * 32 >= R;
 }
-hipError_t launch_gemv_quarter(int rows_in_flight, const GemvArgs& a, int grid, hipStream_t st) {
+hipError_t launch_gemv_quarter(const GemvArgs& a, int grid, hipStream_t st) {
     if (!gemv_quarter_ok(a.C, a.R, grid) || !a.resid) return hipErrorInvalidValue;
-    const bool two = rows_in_flight >= 2;
     switch (a.C) {
-        case 4096: return two ? launch_gemv_quarter_k<8, 2>(a, grid, st) : launch_gemv_quarter_k<8, 1>(a, grid, st);
-        case 5120: return two ? launch_gemv_quarter_k<10, 2>(a, grid, st) : launch_gemv_quarter_k<10, 1>(a, grid, st);
-        case 11008: return two ? launch_gemv_quarter_k<22, 2>(a, grid, st) : launch_gemv_quarter_k<22, 1>(a, grid, st);
-        default: return two ? launch_gemv_quarter_k<27, 2>(a, grid, st) : launch_gemv_quarter_k<27, 1>(a, grid, st);
+        case 4096: return launch_gemv_quarter_k<8, 1>(a, grid, st);
+        case 5120: return launch_gemv_quarter_k<10, 1>(a, grid, st);
+        case 11008: return launch_gemv_quarter_k<22, 1>(a, grid, st);
+        default: return launch_gemv_quarter_k<27, 1>(a, grid, st);
     }
 }
 
@@ -249,32 +248,29 @@ static_assert(KernargLead<decltype(&gemv_kernel<1, 8, 8, 1, 3, true, 0, true, 4>
 
 // leading scalars: preloaded into SGPRs at wave launch (see gemv_kernel) - the position, q and the cache rows are what the chain
 // of dependent loads starts from
-template <int D, int WAVES, bool KVH, int VS, bool PIPE = false>
+template <int D, int WAVES, bool KVH, bool PIPE = false>
 __global__ __launch_bounds__(WAVES * 64) void attn_decode_kernel(const int32_t* pos_ptr, const float* q, const float* kcache, const float* vcache,
                                                                  int pos_val, int H, int nsplit, int tc_signed, unsigned ns_magic, int nq, const AttnArgs a) {
     AttnArgs b = a;
     b.pos_ptr = pos_ptr; b.q = q; b.kcache = kcache; b.vcache = vcache; b.pos_val = pos_val; b.H = H; b.nsplit = nsplit; b.nq = nq;
     b.tc = tc_signed < 0 ? -tc_signed : tc_signed; b.tc_dyn = tc_signed < 0; b.ns_magic = ns_magic;     // (tc_dyn travels as the sign of tc: its slot carries the magic number)
-    attn_body<D, WAVES, KVH, VS, PIPE>(b, blockIdx.x);
+    attn_body<D, WAVES, KVH, PIPE>(b, blockIdx.x);
 }
 
 template <int D, int WAVES>
 static void launch_attn_dw(const AttnArgs& a, int grid, hipStream_t st) {
-    const bool v2 = a.vsplit == 2;
     const unsigned ns_magic = (unsigned)(((1ull << 32) + (unsigned)a.nsplit - 1) / (unsigned)a.nsplit);     // nsplit == 1: 0 (2^32 truncated) - attn_body does not divide then
-#define THK_ATTN_GO(kvh, vs, pp) hipLaunchKernelGGL((attn_decode_kernel<D, WAVES, kvh, vs, pp>), dim3(grid), dim3(WAVES * 64), 0, st, a.pos_ptr, a.q, a.kcache, a.vcache, \
+#define THK_ATTN_GO(kvh, pp) hipLaunchKernelGGL((attn_decode_kernel<D, WAVES, kvh, pp>), dim3(grid), dim3(WAVES * 64), 0, st, a.pos_ptr, a.q, a.kcache, a.vcache, \
                                                     a.pos_val, a.H, a.nsplit, a.tc_dyn ? -a.tc : a.tc, ns_magic, a.nq, a)
     if constexpr (D == 128 && WAVES == 8) {       // the software-pipelined rounds (long caches) exist for the LLaMA head size, one workgroup per (head, split)
-        if (a.pipe && !v2) { if (a.kv_f16) THK_ATTN_GO(true, 1, true); else THK_ATTN_GO(false, 1, true); return; }
+        if (a.pipe) { if (a.kv_f16) THK_ATTN_GO(true, true); else THK_ATTN_GO(false, true); return; }
     }
-    if (a.kv_f16) { if (v2) THK_ATTN_GO(true, 2, false); else THK_ATTN_GO(true, 1, false); }
-    else { if (v2) THK_ATTN_GO(false, 2, false); else THK_ATTN_GO(false, 1, false); }
+    if (a.kv_f16) THK_ATTN_GO(true, false); else THK_ATTN_GO(false, false);
 #undef THK_ATTN_GO
 }
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
-    if (a.vsplit != 1 && a.vsplit != 2) return hipErrorInvalidValue;
     if (a.nsplit < 1 || a.nsplit > 4096 || a.tc <= 0) return hipErrorInvalidValue;
-    const int grid = a.H * a.nsplit * a.vsplit * (a.nq > 1 ? a.nq : 1);
+    const int grid = a.H * a.nsplit * (a.nq > 1 ? a.nq : 1);
     const bool w8 = a.waves == 8;
     switch (a.D) {
         case 64: if (w8) launch_attn_dw<64, 8>(a, grid, st); else launch_attn_dw<64, 4>(a, grid, st); break;
@@ -286,7 +282,7 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
 }
 
 // Stand-alone combine of split partials -> out[H*D] (used by thk_attn_decode when nsplit > 1).
-static_assert(KernargLead<decltype(&attn_decode_kernel<128, 8, false, 1, false>)>::bytes() == kKernargPreloadBytes,
+static_assert(KernargLead<decltype(&attn_decode_kernel<128, 8, false, false>)>::bytes() == kKernargPreloadBytes,
               "attn_decode_kernel: the explicit scalars ahead of AttnArgs must fill exactly the 14 preloaded dwords");
 __global__ void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, float* out,
                                     int H, int D, int nsplit) {

@@ -66,7 +66,6 @@ struct AttnArgs {
     int tc_dyn;                // ... or 1: tc = ceil(T / nsplit) rounded up to the wave batch, computed on the device from the live position
     unsigned ns_magic;         // ceil(2^32 / nsplit), set by launch_attn_decode: x / nsplit = __umulhi(x, ns_magic) for x * nsplit < 2^32 (no integer
                                // division between the kernel's entry and its K/V requests); reaches the kernel in the preloaded scalars
-    int vsplit;                // 1 | 2: workgroups per (head, split), each taking 1/vsplit of the V columns (attn_body)
     int pipe;                  // 1: a split may span several rounds of the workgroup (long caches): take the software-pipelined variant where it exists
     int waves;                 // waves per block of the stand-alone kernel (4 or 8)
     int nq;                    // causal queries in this launch (prefill); 0/1 = single decode query
@@ -84,9 +83,9 @@ int gemv_rows_per_group(int C, int epi, int nru);
 void gemv_variant(int C, int epi, int nru, int* NR, int* U, int* pipe);
 hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, bool nt, hipStream_t st);
 // y = resid + W x with a WORKGROUP per row (its four waves take a quarter of the columns each; round 4, thk_decode_bodies.hpp):
-// rows_in_flight 1 | 2 per wave; gemv_quarter_ok = the shape and workgroup count have this form (<= 32 rows per workgroup)
+// gemv_quarter_ok = the shape and workgroup count have this form (<= 32 rows per workgroup)
 bool gemv_quarter_ok(int C, int R, int grid);
-hipError_t launch_gemv_quarter(int rows_in_flight, const GemvArgs& a, int grid, hipStream_t st);
+hipError_t launch_gemv_quarter(const GemvArgs& a, int grid, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
 hipError_t launch_attn_combine(const float* part_o, const float* part_ml, float* out, int H, int D, int nsplit, hipStream_t st);
 hipError_t launch_rms_norm(float* x, int rows, int N, hipStream_t st);

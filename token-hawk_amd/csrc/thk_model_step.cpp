@@ -79,7 +79,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             // split combine -> wo -> + residual (steps 10-11, th-llama.cpp:401-413)
             AttnArgs t{};
             t.q = m->q; t.kcache = kc; t.vcache = vc; t.pos_ptr = &sb.st->pos; t.H = H; t.D = D; t.nsplit = m->nsplit; t.tc = m->tc;
-            t.tc_dyn = m->attn_tc_dyn; t.vsplit = m->attn_vsplit;
+            t.tc_dyn = m->attn_tc_dyn;
             t.pipe = (T + m->nsplit - 1) / m->nsplit > m->attn_waves * (64 / (D / 4)) * 8;      // a split of the full cache is longer than one round
             t.scale = 1.0f / sqrtf((float)D); t.waves = m->attn_waves; t.kv_f16 = m->kv_f16;
             t.out = m->nsplit == 1 ? m->attn_out : nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml;
@@ -115,7 +115,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             a.trace = trace_slab();
             MARK("w2_resid");
             if (m->skip_kernel != 5) {
-                if (m->var_w2 >= 8 && gemv_quarter_ok(F, E, m->grid_w2)) HIPCHK(ctx, launch_gemv_quarter(m->var_w2 - 7, a, m->grid_w2, st));     // a workgroup per row (variants 8, 9)
+                if (m->var_w2 >= 8 && gemv_quarter_ok(F, E, m->grid_w2)) HIPCHK(ctx, launch_gemv_quarter(a, m->grid_w2, st));     // a workgroup per row (variants 8, 9)
                 else HIPCHK(ctx, launch_gemv(GEMV_PRO_COPY, GEMV_EPI_RESID, m->var_w2, a, m->grid_w2, nt, st));
             }
         }

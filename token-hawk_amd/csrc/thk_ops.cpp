@@ -75,7 +75,7 @@ extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache
     a.q = q; a.kcache = kcache; a.vcache = vcache; a.pos_ptr = nullptr; a.pos_val = (int)T - 1;
     a.H = (int)H; a.D = (int)D; a.nsplit = nsplit; a.tc = (int)((T + nsplit - 1) / nsplit);
     a.scale = 1.0f / sqrtf((float)D); a.waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
-    a.tc_dyn = tun(ctx, "attn_tc_dyn") != 0; a.vsplit = tun(ctx, "attn_vsplit") == 2 ? 2 : 1;
+    a.tc_dyn = tun(ctx, "attn_tc_dyn") != 0;
     a.pipe = (T + nsplit - 1) / nsplit > a.waves * (64 / ((int)D / 4)) * 8;
     a.part_o = (float*)ctx->scratch; a.part_ml = a.part_o + (size_t)H * nsplit * D;
     a.out = nsplit == 1 ? out : nullptr;
@@ -89,7 +89,7 @@ hipError_t attn_prefill_dispatch(thk_ctx* ctx, const float* q, const float* kc, 
     AttnArgs a{};
     a.kv_f16 = kv_f16 ? 1 : 0;
     a.q = q; a.kcache = kc; a.vcache = vc; a.pos_ptr = nullptr; a.pos_val = n_past; a.H = H; a.D = D;
-    a.nsplit = 1; a.tc = n_past + M; a.vsplit = 1; a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = M; a.out = out;
+    a.nsplit = 1; a.tc = n_past + M; a.scale = 1.0f / sqrtf((float)D); a.waves = 4; a.nq = M; a.out = out;
     return launch_attn_decode(a, ctx->stream);
 }
 extern "C" int thk_attn_prefill(thk_ctx* ctx, const float* q, const float* kcache, const float* vcache, int64_t n_past, int64_t M, int64_t H, int64_t D, float* out) {
