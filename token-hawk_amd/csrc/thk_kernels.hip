@@ -474,91 +474,87 @@ hipError_t launch_argmax(const float* logits, int V, unsigned long long* block_b
 
 // ---------------------------------------------------------------- top-k of a logits vector (stochastic sampler, th-llama.cpp:814-907)
 // keys[j] = (order-preserving map of logits[i]) << 32 | ~i  for the k largest, sorted descending: value descending, ties by
-// ascending index - a total order, so the selection and its order are unique.  ONE workgroup of 1024 threads: every thread holds
-// up to kTopkPer keys in registers; the k-th largest key is found by bisection (below), the keys >= it are compacted into LDS
-// (exactly k: keys are unique) and sorted with a bitonic network.  V <= 1024 * kTopkPer = 32768, k <= 1024.
-constexpr int kTopkThreads = 1024, kTopkPer = 32, kTopkMax = 1024;     // 32 keys = 64 VGPRs per thread (16 waves per workgroup leave 128)
-// Round 5: the k-th largest key is found by BISECTION on the 64-bit key - per step every thread counts its keys >= the trial value,
-// the counts are summed with wave shuffles and one LDS hop across the 16 waves, no atomics - instead of an 8-pass radix select whose
-// first passes sent all 32000 LDS atomics to the two or three bins the logits' exponents share (the kernel took 4x as long).  The
-// search starts from the range [min key, max key] of the vector, so the shared high bits cost no steps.
-__global__ __launch_bounds__(kTopkThreads) void topk_kernel(const float* __restrict__ logits, int V, int k, unsigned long long* __restrict__ keys_out,
-                                                            unsigned long long* done /* host-mapped word or NULL */, unsigned long long epoch) {
-    __shared__ unsigned long long sel[kTopkMax];
-    __shared__ unsigned long long red_hi[16], red_lo[16];
-    __shared__ unsigned red_cnt[2][16];
-    __shared__ unsigned s_count;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long key[kTopkPer];
-    unsigned long long hi = 0ull, lo = ~0ull;
-#pragma unroll
-    for (int j = 0; j < kTopkPer; ++j) {
-        const int i = tid + j * kTopkThreads;
-        key[j] = i < V ? argmax_key(logits[i], (unsigned)i) : 0ull;      // 0 is below every real key (a real key has ~idx != 0 in its low word or a non-zero value word)
-        if (i < V) { hi = key[j] > hi ? key[j] : hi; lo = key[j] < lo ? key[j] : lo; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long h2 = __shfl_xor(hi, o, 64), l2 = __shfl_xor(lo, o, 64);
-        hi = h2 > hi ? h2 : hi; lo = l2 < lo ? l2 : lo;
-    }
-    if (lane == 0) { red_hi[wave] = hi; red_lo[wave] = lo; }
-    if (tid == 0) s_count = 0u;
-    __syncthreads();
-#pragma unroll
-    for (int w = 0; w < 16; ++w) { hi = red_hi[w] > hi ? red_hi[w] : hi; lo = red_lo[w] < lo ? red_lo[w] : lo; }
-    // invariant: count(keys >= lo) >= k  and  count(keys >= hi + 1) < k; the answer is the largest t with count(keys >= t) >= k
-    unsigned long long a = lo, b = hi;                                    // search t in [a, b]
-    int it = 0;
-    while (a < b) {
-        const unsigned long long mid = a + ((b - a) >> 1) + 1ull;          // upper middle: a < mid <= b
-        unsigned c = 0;
-#pragma unroll
-        for (int j = 0; j < kTopkPer; ++j) c += key[j] >= mid ? 1u : 0u;   // (padding keys are 0 < mid)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        unsigned* rc = red_cnt[it & 1];                                    // two buffers: one barrier per step
-        if (lane == 0) rc[wave] = c;
-        __syncthreads();
-        unsigned total = 0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) total += rc[w];
-        if (total >= (unsigned)k) a = mid; else b = mid - 1ull;
-        ++it;
-    }
-    const unsigned long long kth = a;                                       // the k-th largest key itself (keys are unique)
-#pragma unroll
-    for (int j = 0; j < kTopkPer; ++j) {
-        const int i = tid + j * kTopkThreads;
-        if (i < V && key[j] >= kth) { const unsigned at = atomicAdd(&s_count, 1u); if (at < (unsigned)kTopkMax) sel[at] = key[j]; }
-    }
-    __syncthreads();
-    int n = 1;
-    while (n < k) n <<= 1;                                                   // bitonic sort of n >= k slots, descending; empty slots are 0
-    for (int i = tid; i < n; i += kTopkThreads) if (i >= k) sel[i] = 0ull;
-    __syncthreads();
-    for (int size = 2; size <= n; size <<= 1)
+// ascending index - a total order, so the selection and its order are unique.  V <= 32768, k <= 1024.
+constexpr int kTopkThreads = 1024, kTopkPer = 32, kTopkMax = 1024, kTopkChunk = 16384;     // a merge workgroup sorts <= 16384 keys (128 KiB of LDS)
+// Round 5, two launches of one bitonic network.  (1) topk_local_kernel: every workgroup sorts 1024 keys in LDS (descending) and keeps its min(k, 1024)
+// largest - the global top k is a subset of the union of the local ones - so 32 compute units share the work and the second launch sees 32 x k candidates;
+// (2) topk_merge_kernel, ONE workgroup: sorts the candidates (<= 2048 for k <= 64; larger k: up to 32768 keys, several elements per thread) and writes the
+// first k.  History of this kernel, each version slower than the 128 KB logits read-back it was meant to replace (46 us per token, tools/step_paths_probe.py):
+// an 8-pass radix select whose first passes sent all 32000 LDS atomics to the two or three bins the logits' exponents share; a bisection on the key (64
+// barrier steps, 65 us); a 16-ary search with all 32000 keys in ONE workgroup (114 us), then on 5000 pre-selected candidates (52-80 us) - a workgroup is one
+// compute unit, 64 lanes per clock: 1024 threads x 600 instructions x 16 steps is 10 k cycles per step whatever the algorithm's elegance.
+constexpr int kTopkLocal = 1024;
+// descending bitonic sort of N keys (a power of two) in LDS by THREADS threads; ends with a barrier
+template <int THREADS>
+__device__ __forceinline__ void bitonic_desc(unsigned long long* sk, int N, int tid) {
+    for (int size = 2; size <= N; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = tid; i < n; i += kTopkThreads) {
-                const int p = i ^ stride;
-                if (p > i) {
-                    const bool desc = (i & size) == 0;
-                    const unsigned long long x = sel[i], y = sel[p];
-                    if ((x < y) == desc) { sel[i] = y; sel[p] = x; }
-                }
+            for (int t = tid; t < (N >> 1); t += THREADS) {             // compare-exchange number t of this step: elements i < p = i + stride
+                const int i = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), p = i + stride;     // stride is a power of two: no division
+                const bool desc = (i & size) == 0;
+                const unsigned long long x = sk[i], y = sk[p];
+                if ((x < y) == desc) { sk[i] = y; sk[p] = x; }
             }
             __syncthreads();
         }
-    for (int i = tid; i < k; i += kTopkThreads) keys_out[i] = sel[i];
-    if (done) {                                   // keys_out is host-mapped: tell the polling host thread (every storing thread fences, then one publishes)
+}
+__global__ __launch_bounds__(256) void topk_local_kernel(const float* __restrict__ logits, int V, int kk /* min(k, 1024) */, unsigned long long* __restrict__ cand) {
+    __shared__ unsigned long long sk[kTopkLocal];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < kTopkLocal / 256; ++j) {
+        const int i = blockIdx.x * kTopkLocal + j * 256 + tid;
+        sk[j * 256 + tid] = i < V ? argmax_key(logits[i], (unsigned)i) : 0ull;     // 0 is below every real key
+    }
+    __syncthreads();
+    bitonic_desc<256>(sk, kTopkLocal, tid);
+    for (int i = tid; i < kk; i += 256) cand[(size_t)blockIdx.x * kk + i] = sk[i];
+}
+// workgroup g sorts candidates [g * chunk, min(n_in, (g + 1) * chunk)) and writes its first k to out + g * k (one workgroup: the final keys, then `done`)
+__global__ __launch_bounds__(kTopkThreads) void topk_merge_kernel(const unsigned long long* __restrict__ cand, int n_in, int chunk, int n_pow2 /* >= chunk */, int k,
+                                                                  unsigned long long* __restrict__ out, unsigned long long* done /* host-mapped word or NULL */,
+                                                                  unsigned long long epoch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];           // n_pow2 keys
+    const int tid = threadIdx.x, i0 = blockIdx.x * chunk, n = min(chunk, n_in - i0);
+    for (int i = tid; i < n_pow2; i += kTopkThreads) sm[i] = i < n ? cand[i0 + i] : 0ull;
+    __syncthreads();
+    bitonic_desc<kTopkThreads>(sm, n_pow2, tid);
+    for (int i = tid; i < k; i += kTopkThreads) out[(size_t)blockIdx.x * k + i] = sm[i];
+    if (done) {                                   // out is host-mapped: tell the polling host thread (every storing thread fences, then one publishes)
         __threadfence_system();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(done, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-hipError_t launch_topk(const float* logits, int V, int k, unsigned long long* keys_out, hipStream_t st, unsigned long long* done, unsigned long long epoch) {
-    if (V < 1 || V > kTopkThreads * kTopkPer || k < 1 || k > kTopkMax || k > V) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(topk_kernel, dim3(1), dim3(kTopkThreads), 0, st, logits, V, k, keys_out, done, epoch);
+// candidates of the local sorts + the intermediate level a large k needs (k > 512 at V = 32000: two merge levels)
+size_t topk_scratch_bytes(int V, int k) {
+    const size_t n_in = (size_t)((V + kTopkLocal - 1) / kTopkLocal) * (k < kTopkLocal ? k : kTopkLocal);
+    return (n_in + ((n_in + kTopkChunk - 1) / kTopkChunk) * (size_t)k) * 8;
+}
+hipError_t launch_topk(const float* logits, int V, int k, unsigned long long* keys_out, unsigned long long* cand /* topk_scratch_bytes(V, k) */, hipStream_t st,
+                       unsigned long long* done, unsigned long long epoch) {
+    if (V < 1 || V > kTopkThreads * kTopkPer || k < 1 || k > kTopkMax || k > V || !cand) return hipErrorInvalidValue;
+    const int kk = k < kTopkLocal ? k : kTopkLocal, nwg = (V + kTopkLocal - 1) / kTopkLocal;
+    int n_in = nwg * kk;
+    hipLaunchKernelGGL(topk_local_kernel, dim3(nwg), dim3(256), 0, st, logits, V, kk, cand);
+    static bool attr_done[kMaxDevices] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < kMaxDevices && !attr_done[dev]) {
+        const hipError_t e = hipFuncSetAttribute((const void*)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTopkChunk * 8);
+        if (e != hipSuccess) return e;
+        attr_done[dev] = true;
+    }
+    unsigned long long* src = cand;
+    unsigned long long* mid = cand + n_in;                                // one intermediate level at most: ceil(32768 / 16384) * 1024 = 2048 candidates
+    for (;;) {
+        const int groups = (n_in + kTopkChunk - 1) / kTopkChunk, chunk = groups == 1 ? n_in : kTopkChunk;
+        int n2 = 64;
+        while (n2 < chunk) n2 <<= 1;
+        const bool last = groups == 1;
+        hipLaunchKernelGGL(topk_merge_kernel, dim3(groups), dim3(kTopkThreads), (size_t)n2 * 8, st, src, n_in, chunk, n2, k, last ? keys_out : mid, last ? done : nullptr, epoch);
+        if (last) break;
+        src = mid; n_in = groups * k;
+    }
     return hipGetLastError();
 }
 

@@ -109,7 +109,9 @@ hipError_t launch_advance_pos(SeqState* st_dev, const int* advance_ptr, int n_ct
 hipError_t launch_argmax(const float* logits, int V, unsigned long long* block_best, int nblocks, hipStream_t st);
 // the k largest logits as sorted keys ((ordered value << 32) | ~index, descending); V <= 32768, k <= 1024
 // done != NULL: keys_out (and done) are host-mapped; the kernel stores `epoch` there, system scope, after its keys (a host thread polls it)
-hipError_t launch_topk(const float* logits, int V, int k, unsigned long long* keys_out, hipStream_t st, unsigned long long* done = nullptr, unsigned long long epoch = 0);
+hipError_t launch_topk(const float* logits, int V, int k, unsigned long long* keys_out, unsigned long long* cand_scratch /* topk_scratch_bytes(V, k) device bytes */, hipStream_t st,
+                       unsigned long long* done = nullptr, unsigned long long epoch = 0);
+size_t topk_scratch_bytes(int V, int k);
 hipError_t launch_synth_f16(uint64_t key, float scale, size_t n, void* out, hipStream_t st);
 hipError_t launch_synth_gain(uint64_t key, float scale, size_t n, float* out, hipStream_t st);
 

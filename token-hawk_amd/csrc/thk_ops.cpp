@@ -161,8 +161,8 @@ int topk_to_host(thk_ctx* ctx, const float* logits_dev, int64_t V, int32_t k, fl
     REQUIRE(ctx, V >= 1 && V <= 32768 && k >= 1 && k <= 1024 && k <= V, "top-k: V=%lld k=%d outside the device kernel's range (V <= 32768, k <= 1024)", (long long)V, k);
     int rc = ensure_scratch(ctx, 1u << 20);
     if (rc != THK_OK) return rc;
-    unsigned long long* keys_dev = (unsigned long long*)ctx->scratch;
-    HIPCHK(ctx, launch_topk(logits_dev, (int)V, k, keys_dev, ctx->stream));
+    unsigned long long* keys_dev = (unsigned long long*)ctx->scratch;             // [0, 8 KiB): the k keys; behind them the local candidates (<= 256 KiB)
+    HIPCHK(ctx, launch_topk(logits_dev, (int)V, k, keys_dev, keys_dev + 1024, ctx->stream));
     std::vector<unsigned long long> keys((size_t)k);
     HIPCHK(ctx, hipMemcpyAsync(keys.data(), keys_dev, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -186,7 +186,9 @@ int topk_enqueue_pinned(thk_ctx* ctx, const float* logits_dev, int64_t V, int32_
         HIPCHK(ctx, hipHostGetDevicePointer((void**)&ctx->pinned_keys_dev, ctx->pinned_keys, 0));
         ctx->pinned_keys[1024] = 0;
     }
-    HIPCHK(ctx, launch_topk(logits_dev, (int)V, k, ctx->pinned_keys_dev, ctx->stream, ctx->pinned_keys_dev + 1024, ++ctx->topk_epoch));
+    const int rc = ensure_scratch(ctx, 1u << 20);
+    if (rc != THK_OK) return rc;
+    HIPCHK(ctx, launch_topk(logits_dev, (int)V, k, ctx->pinned_keys_dev, (unsigned long long*)ctx->scratch + 1024, ctx->stream, ctx->pinned_keys_dev + 1024, ++ctx->topk_epoch));
     return THK_OK;
 }
 // The kernel's last act is a system-scope store of this call's epoch behind its keys: the host thread polls that word in its own memory
