@@ -542,6 +542,42 @@ def test_prefill_tile_images_follow_weight_updates(thk, ctx):
     m.close()
 
 
+@pytest.mark.parametrize("dims", [(512, 8), (4096, 32), (5120, 40)], ids=["tiny-width", "7B-width", "13B-width"])
+@pytest.mark.parametrize("M,n_past", [(129, 0), (200, 5), (256, 0), (300, 0)])
+def test_prefill_256_token_slabs_equal_128_token_slabs(thk, dims, M, n_past):
+    """Round 5: a slab is up to 256 tokens (eight token tiles; the GEMM multiplies every weight chunk against two token halves: gemm_prefill_v3h_kernel,
+    accumulators = all 256 AccVGPRs), so a long prompt makes half the weight passes; `prefill_slab_tokens = 128` is the rounds-1-4 form.  Same arithmetic per
+    token (each token is its own MFMA column; the K cut of the stream-K shares is the same): logits within 5e-5 of the 128-token slabs, within 2e-4 of the
+    decode path, bit-identical over repeats; 129 / 200 tokens = one eight-tile pass with pad tiles, 300 = 256 + 44, n_past > 0 = attention over earlier rows
+    (the slab's two attention launches of 128 queries write one image)."""
+    E, H = dims
+    shape = thk.ModelShape(n_vocab=2048, n_embd=E, n_mult=256, n_head=H, n_layer=2, n_ctx=320)
+    rng = np.random.default_rng(M + E)
+    toks = np.concatenate([[1], rng.integers(3, 2048, n_past + M)]).astype(np.int32)
+    out, nxt = {}, {}
+    for sl in (128, 256):
+        with thk.Context(0) as c:
+            c.set_tunable("prefill_slab_tokens", sl)
+            m = thk.Model(c, shape); m.fill_synthetic(); m.finalize()
+            if n_past:
+                m.eval(toks[:n_past], 0, want_logits=False)
+            first = m.prefill(toks[n_past:n_past + M], n_past).copy()
+            for _ in range(3):
+                m.reset_kv(0)
+                if n_past:
+                    m.eval(toks[:n_past], 0, want_logits=False)
+                assert np.array_equal(first.view(np.uint32), m.prefill(toks[n_past:n_past + M], n_past).view(np.uint32))
+            nxt[sl], _ = m.eval([int(toks[n_past + M])], n_past + M)
+            if sl == 256:
+                m.reset_kv(0)
+                ld, _ = m.eval(toks[:n_past + M], 0)
+                assert np.abs(first - ld).max() < 2e-4            # vs the decode path, token by token
+            out[sl] = first
+            m.close()
+    assert np.abs(out[256] - out[128]).max() < 5e-5 and int(out[256].argmax()) == int(out[128].argmax())
+    assert np.abs(nxt[256] - nxt[128]).max() < 5e-5
+
+
 def test_prefill_into_second_sequence_and_faithful_head(thk, orc, ctx):
     """Prefill writes the KV rows of the sequence it is given (not sequence 0) and honours the lm-head mode."""
     m, om = make_pair(thk, orc, ctx, "TINY_Q1", n_seq=2, lm_mode=1)     # 1 = THK_LMHEAD_FAITHFUL (defect Q1 reproduced)

@@ -21,6 +21,7 @@ void default_tunables(thk_ctx* ctx) {
     // workgroups per prefill GEMM launch (<= 256): fewer = fewer K-splits = less partial-tile traffic, but fewer CUs streaming
     for (const char* k : {"qkv", "wo", "w13", "w2"}) { ctx->tun[std::string("prefill_blocks_") + k] = 0; ctx->tun[std::string("prefill_tile_") + k] = 256; }   // blocks: 0 = auto (row-block-aligned shares where >= 192 workgroups remain, else 256); tile rows: 128 | 256
     ctx->tun["prefill_attn_mfma"] = 1;
+    ctx->tun["prefill_slab_tokens"] = 256;   // prompt tokens per weight pass: 256 (eight token tiles, two half-steps per weight chunk) or 128 (rounds 1-4)
     ctx->tun["prefill_deferred_norm"] = 1;   // RMSNorm's per-token scalar is applied on the output side of the GEMM, so the residual reducers write the next
                                              // GEMM's image themselves: 9 launches per layer instead of 11 (thk_model_prefill.cpp)
     ctx->tun["prefill_packed"] = 1;       // prefill GEMMs stream tile images of the layer matrices (a second copy of the layer weights in HBM, built on

@@ -200,7 +200,10 @@ hipError_t launch_prefill_reduce_qkv(const float* part, const PrefillPlan& p, co
                                      const unsigned long long* ssq = nullptr, const unsigned long long* ssq_scale = nullptr);
 // causal attention for the M queries of a slab (D = 64 | 128), f32-class accuracy on MFMA
 hipError_t launch_attn_prefill_mfma(const float* Q, const void* Kc, const void* Vc, bool kv_f16, int n_past, int M, int H, int D, float* out /* [M,H*D] or null */,
-                                    void* ximg /* if out is null: the X image of the consuming GEMM */, hipStream_t st);
+                                    void* ximg /* if out is null: the X image of the consuming GEMM */, hipStream_t st,
+                                    int img_MT = 0 /* token tiles of that image (0: those of M) */, int img_tok0 = 0 /* image row of query 0 */,
+                                    int q_tiles = 0 /* > the queries' own tiles: the extra 32-query tiles are written as zero rows */);
+int prefill_token_tiles(int M);     // token tiles of a slab of M tokens: 1..4 up to 128 tokens, 8 for 129..256
 hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p, void* ximg_out, hipStream_t st, const unsigned long long* ssq = nullptr,
                                         const unsigned long long* ssq_scale = nullptr);
 

@@ -38,14 +38,17 @@ static int slab_plans(thk_model* m, int M, PrefillPlan out[4]) {
 }
 struct PrefillBufs { float *X, *Q, *ATT; int32_t* tok; char *imgE, *imgF; float* part; unsigned long long* ssq; size_t ssq_bytes; };
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+// tokens per slab = tokens per weight pass: 256 (round 5: gemm_prefill_v3h_kernel, eight token tiles) or 128 (tunable prefill_slab_tokens)
+static int slab_tokens(thk_model* m) { return tun(m->ctx, "prefill_slab_tokens") == 128 ? 128 : 256; }
 static int prefill_workspace(thk_model* m, PrefillBufs* b) {
     thk_ctx* ctx = m->ctx;
     const int E = m->hp.n_embd;
-    const size_t per = align256((size_t)128 * E * 4);
+    const int SL = slab_tokens(m);
+    const size_t per = align256((size_t)SL * E * 4);
     // sized from the SAME plans prefill_slab builds (the prefill_blocks_* / prefill_tile_* tunables are read per call, and
     // part_floats = G * maxseg * slot_floats is not monotonic in G, so a fixed G = 256 bound could be exceeded)
     size_t part_floats = 0, img_e = 0, img_f = 0;
-    for (int M : {128}) {
+    for (int M : {128, SL}) {
         PrefillPlan pl[4];
         const int rc = slab_plans(m, M, pl);
         if (rc != THK_OK) return rc;
@@ -54,7 +57,7 @@ static int prefill_workspace(thk_model* m, PrefillBufs* b) {
         img_f = std::max(img_f, pl[3].ximg_bytes);
     }
     const size_t imgE = align256(img_e), imgF = align256(img_f), part = align256(4 * part_floats);
-    const size_t ssq_bytes = align256((size_t)(m->l1 - m->l0) * 2 * 128 * 8);      // deferred norm: sum of squares per (layer, norm, token), 2^-32 fixed point
+    const size_t ssq_bytes = align256((size_t)(m->l1 - m->l0) * 2 * 256 * 8);      // deferred norm: sum of squares per (layer, norm, token of the slab), 2^-32 fixed point
     const size_t bytes = 3 * per + 1024 + imgE + imgF + part + ssq_bytes;
     if (m->prefill_ws_bytes < bytes) {
         if (m->prefill_ws) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); HIPCHK(ctx, hipFree(m->prefill_ws)); m->prefill_ws = nullptr; }
@@ -134,7 +137,7 @@ extern "C" int thk_model_prepare_prefill(thk_model* m) {
 // 1: the next thk_model_prefill streams tile images; 0: row-major matrices (not prepared yet, prefill_packed = 0, or the slab did not fit)
 extern "C" int thk_model_prefill_uses_tile_images(const thk_model* m) { return (m && m->prefill_pk && !m->pk_w.empty() && !m->pk_failed) ? 1 : 0; }
 
-// one slab of M <= 128 prompt tokens at positions [n_past, n_past + M) through every layer
+// one slab of M <= 256 prompt tokens at positions [n_past, n_past + M) through every layer
 static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const int32_t* tokens, int M, int n_past) {
     thk_ctx* ctx = m->ctx;
     hipStream_t st = ctx->stream;
@@ -153,7 +156,7 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
     const int nl = m->l1 - m->l0;
     const bool defer = tun(ctx, "prefill_deferred_norm") != 0;
     if (defer) HIPCHK(ctx, hipMemsetAsync(b.ssq, 0, b.ssq_bytes, st));
-    auto ssq_of = [&](int layer, int which) { return b.ssq + ((size_t)layer * 2 + which) * 128; };      // which: 0 attention norm, 1 ffn norm
+    auto ssq_of = [&](int layer, int which) { return b.ssq + ((size_t)layer * 2 + which) * 256; };      // which: 0 attention norm, 1 ffn norm
     for (int i = 0; i < nl; ++i) {
         const LayerW& L = m->layers[i];
         float* kc = kcache_of(m, sb, i);
@@ -169,7 +172,12 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
         HIPCHK(ctx, launch_prefill_reduce_qkv(b.part, pq, m->rope_tab, n_past, D, b.Q, kc, vc, m->kv_f16 != 0, st, defer ? ssq_of(i, 0) : nullptr,
                                               defer ? (i == 0 ? ssq_of(0, 0) : ssq_of(i - 1, 1)) : nullptr));
         if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) {
-            HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, m->kv_f16 != 0, n_past, M, H, D, nullptr, b.imgE, st));   // writes wo's X image directly
+            if (M <= 128) {
+                HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, m->kv_f16 != 0, n_past, M, H, D, nullptr, b.imgE, st));   // writes wo's X image directly
+            } else {      // a 256-token slab: the attention kernel takes 128 queries per launch; both halves write the slab's eight-tile image (pad tiles as zero rows)
+                HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, m->kv_f16 != 0, n_past, 128, H, D, nullptr, b.imgE, st, 8, 0, 4));
+                HIPCHK(ctx, launch_attn_prefill_mfma(b.Q + (size_t)128 * E, kc, vc, m->kv_f16 != 0, n_past + 128, M - 128, H, D, nullptr, b.imgE, st, 8, 128, 4));
+            }
         } else {
             HIPCHK(ctx, attn_prefill_dispatch(ctx, b.Q, kc, vc, n_past, M, H, D, b.ATT, m->kv_f16 != 0));
             HIPCHK(ctx, launch_prefill_ximg(b.ATT, nullptr, M, E, b.imgE, st));
@@ -208,8 +216,10 @@ extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* token
     SeqBuf& sb = m->seqs[seq];
     const int E = m->hp.n_embd, V = m->hp.n_vocab, M = n_tokens;
     int last = 0;
-    for (int m0 = 0; m0 < M; m0 += 128) {     // slabs of <= 128 tokens; later slabs attend to the rows earlier ones cached
-        last = std::min(128, M - m0);
+    const int SL = slab_tokens(m);
+    for (int m0 = 0; m0 < M; m0 += last) {    // slabs of <= 256 tokens (one weight pass each); later slabs attend to the rows earlier ones cached
+        const int left = M - m0;
+        last = left > 128 ? std::min(SL, left) : left;       // 129 .. 256 tokens left: ONE eight-tile pass (pad tiles are cheaper than a second weight pass)
         if ((rc = prefill_slab(m, sb, b, tokens + m0, last, n_past + m0)) != THK_OK) return rc;
     }
     {   // final norm + lm-head on the last token only (th-llama.cpp:253-262, aOffset = (r-1)*c)

@@ -73,13 +73,15 @@ constexpr int kNST = 4;            // LDS stages
 constexpr int kG = 256;            // default workgroups per launch: a constant, so results do not depend on the CU count
 
 static __host__ __device__ inline size_t ximg_stage_bytes(int MT) { return (size_t)MT * 32 * 64 * 2; }
+// token tiles of a slab: 1 .. 4 for up to 128 tokens, EIGHT for 129 .. 256 (gemm_prefill_v3h_kernel: two halves of four tiles; pad tiles are zero rows)
+int prefill_token_tiles(int M) { return M > 128 ? 8 : (M + 31) / 32; }
 
 PrefillPlan prefill_plan(int M, int R, int nmat, int C, int G, int tile_rows) {
     PrefillPlan p{};
     if (G <= 0) G = kG;
     p.G = G;
     p.tile_rows = tile_rows == 128 ? 128 : kV3Rows;
-    p.M = M; p.MT = (M + 31) / 32; p.Mpad = p.MT * 32; p.R = R; p.nmat = nmat; p.C = C;
+    p.M = M; p.MT = prefill_token_tiles(M); p.Mpad = p.MT * 32; p.R = R; p.nmat = nmat; p.C = C;
     p.nchunks = C / kKC;
     p.rb_per_mat = (R + p.tile_rows - 1) / p.tile_rows; p.Rpad = p.rb_per_mat * p.tile_rows; p.rb_total = p.rb_per_mat * nmat;
     const long total = (long)p.rb_total * p.nchunks;
@@ -334,6 +336,194 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
 #undef THK_PIN_ACC
 }
 
+// ---------------------------------------------------------------- 129 .. 256 tokens per weight pass (round 5)
+// The same kernel for a slab of EIGHT token tiles: every weight chunk that reaches LDS is multiplied against 256 tokens instead of 128, so a long prompt
+// pays half the weight passes, pipeline fills, tile spills and reducer launches per token (prompt time = 3.7 ms + 0.023 ms x tokens per 128-token slab,
+// section 4.3: the fixed part is what a second token half rides on).  All 256 AccVGPRs hold the tile (NF = 2), so the fragment sets stay those of FOUR token
+// tiles and a chunk becomes two half-steps of 32 MFMAs:
+//   step A  tiles 0-3 from set 0;  between its MFMAs: the pending half of the previous refill's DMA, and the chunk's tiles 4-7 -> set 1 (same stage: no wait)
+//   step B  tiles 4-7 from set 1;  wait + the one barrier per chunk, the NEXT chunk's tiles 0-3 -> set 0, the DMA of chunk g + NST into the vacated stage
+// Stage = 32 KB of X image + 16 KB of W: three stages (148 KB of LDS).  Loads per chunk and every vmcnt count are constants, as in the 128-token kernel.
+constexpr int kNSTH = 3;
+template <int NF, bool PK, int NST = kNSTH>
+__global__ __launch_bounds__(256, 1) void gemm_prefill_v3h_kernel(const _Float16* __restrict__ w0, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
+                                                                  const char* __restrict__ ximg, const int nchunks, const int per, const int rb_per_mat, const int rb_total,
+                                                                  const int R, const int C, float* __restrict__ part, const PrefillPlan plan) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    constexpr int MT = 8, MTH = 4;
+    constexpr int XI = MT * 32 * 64 * 2;               // X image bytes per stage (hi rows of the 256 tokens, then lo rows)
+    constexpr int TR = 128 * NF;
+    constexpr int WI = TR * 64;
+    constexpr int ST = XI + WI;
+    constexpr int LPS = MT + 2 * NF;                   // loads per wave per stage
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31;
+    const int maxseg = plan.maxseg;
+    const size_t slot_floats = plan.slot_floats;
+    const int total = rb_total * nchunks;
+    const int g0 = blockIdx.x * per;
+    const int g1 = g0 + per < total ? g0 + per : total;
+    if (g0 >= g1) return;
+    const int ld_piece = swz_pos(lane >> 2, lane & 3);
+    const int rd0 = li * 64 + swz_pos(li, lane >> 5) * 16, rd1 = li * 64 + swz_pos(li, 2 + (lane >> 5)) * 16;
+    const int rbk_first = g0 / nchunks;
+    int i_mat = rbk_first / rb_per_mat, i_rbl = rbk_first % rb_per_mat, i_ch = g0 % nchunks, i_buf = 0;
+    auto flush = [&](f16v (&acc)[NF][MT], int seg) __attribute__((always_inline)) {    // accumulators -> partial slot, fragment order (frag_decode with MT = 8)
+        float* slot = part + ((size_t)blockIdx.x * maxseg + seg) * slot_floats;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f4*>(slot + (size_t)(((((wave * NF + f) * MT + t) * 4 + g) * 64 + lane) * 4)) =
+                        f4{acc[f][t][4 * g], acc[f][t][4 * g + 1], acc[f][t][4 * g + 2], acc[f][t][4 * g + 3]};
+    };
+    char* const scratch = lds + NST * ST + wave * 1024;   // where dummy loads land
+    int issued = g0;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {                      // the first NST chunks (dummy loads where the share is shorter: constant counts)
+        const bool more = issued < g1;
+        const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);
+        const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;
+        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16
+                                    : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);
+#pragma unroll
+        for (int k = 0; k < LPS; ++k) v3_issue_one<MT, NF, PK>(k, more, ximg, scratch, lds + s * ST, nx_xs, nx_w, i_rbl * TR + wave * 32 * NF + (lane >> 2), R, C, wave);
+        if (more) {
+            ++issued;
+            if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }
+        }
+    }
+    i_buf = 0;
+    h8 fa[2][2][NF], fbh[2][2][MTH], fbl[2][2][MTH];     // two sets: one per token HALF (set 0 = tiles 0-3, set 1 = tiles 4-7)
+    constexpr int NM = 4 * NF * MTH;                     // MFMAs per half-step per wave
+    constexpr int NRH = 2 * (NF + 2 * MTH);              // fragment reads per half-step per wave
+    constexpr int SYNC_AT = NM / 4 - 1;                  // step B: the wait + barrier sit behind this MFMA
+    constexpr int SLOTS = NM - 1 - SYNC_AT;
+    constexpr int RSLOTS = SLOTS * 5 / 8 > 0 ? SLOTS * 5 / 8 : 1;
+    constexpr int TSLOTS = SLOTS - RSLOTS;
+    constexpr int LT = LPS / 2, LH = LPS - LT;           // a refill: LT loads in step B's tail, LH in the next step A's head
+    constexpr int AL = NM / 4;                           // step A: slots that carry the pending LH loads ...
+    constexpr int ARS = NM - AL - NM / 8;                // ... and the slots behind them that carry the reads of tiles 4-7 (back before step B's first MFMA)
+    bool pend_more = false;
+    char* pend_sb = lds;
+    const char *pend_xs = ximg, *pend_w = ximg;
+    int pend_row0 = 0;
+    f16v acc[NF][MT];
+#define THK_PIN_ACC()                                                      \
+    _Pragma("unroll") for (int f = 0; f < NF; ++f)                         \
+    _Pragma("unroll") for (int t = 0; t < MT; ++t) asm volatile("" : "+a"(acc[f][t]));
+#define THK_ZERO_ACC()                                                     \
+    _Pragma("unroll") for (int f = 0; f < NF; ++f)                         \
+    _Pragma("unroll") for (int t = 0; t < MT; ++t)                         \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[f][t][i] = 0.f;     \
+    THK_PIN_ACC()
+    int buf = 0;
+    // fragment read number RR of a half-step (k-step, then the NF row fragments, then hi/lo of the half's four token tiles) into set S; H = token half
+#define THK_READ_ONE(SB, S, RR, H)                                                                                     \
+    {                                                                                                                  \
+        const int ks_ = (RR) / (NF + 2 * MTH), q_ = (RR) % (NF + 2 * MTH);                                             \
+        const char* rp_ = (SB) + (ks_ == 0 ? rd0 : rd1);                                                               \
+        if (q_ < NF) fa[S][ks_][q_ < NF ? q_ : 0] = *reinterpret_cast<const h8*>(rp_ + XI + (wave * NF + q_) * 2048);  \
+        else if (((q_ - NF) & 1) == 0) fbh[S][ks_][q_ >= NF ? (q_ - NF) >> 1 : 0] = *reinterpret_cast<const h8*>(rp_ + (4 * (H) + ((q_ - NF) >> 1)) * 2048); \
+        else fbl[S][ks_][q_ >= NF ? (q_ - NF) >> 1 : 0] = *reinterpret_cast<const h8*>(rp_ + XI / 2 + (4 * (H) + ((q_ - NF) >> 1)) * 2048); \
+    }
+#define THK_MFMA_ONE(S, I, TOFF)                                                                                       \
+    {                                                                                                                  \
+        const int ks = (I) / (2 * NF * MTH), j = (I) % (2 * NF * MTH), hl = j / (NF * MTH), t = (j % (NF * MTH)) / NF, f = j % NF; \
+        if (hl == 0) acc[f][(TOFF) + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][f], fbh[S][ks][t], acc[f][(TOFF) + t], 0, 0, 0); \
+        else acc[f][(TOFF) + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][f], fbl[S][ks][t], acc[f][(TOFF) + t], 0, 0, 0); \
+    }
+    // step A: tiles 0-3 from set 0; pending DMA half; this chunk's tiles 4-7 -> set 1
+#define THK_STEP_A()                                                                                                   \
+    {                                                                                                                  \
+        const char* const sbc = lds + buf * ST;                                                                        \
+        THK_PIN_ACC()                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                               \
+            THK_MFMA_ONE(0, i, 0)                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            if (i < AL) {                                                                                              \
+                _Pragma("unroll") for (int k = LT + i * LH / AL; k < LT + (i + 1) * LH / AL; ++k)                      \
+                    v3_issue_one<MT, NF, PK>(k, pend_more, ximg, scratch, pend_sb, pend_xs, pend_w, pend_row0, R, C, wave); \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            } else if (i < AL + ARS) {                                                                                 \
+                _Pragma("unroll") for (int rr = (i - AL) * NRH / ARS; rr < (i - AL + 1) * NRH / ARS; ++rr) THK_READ_ONE(sbc, 1, rr, 1) \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+        }                                                                                                              \
+        THK_PIN_ACC()                                                                                                  \
+    }
+    // step B: tiles 4-7 from set 1; wait + barrier; the next chunk's tiles 0-3 -> set 0; refill the vacated stage
+#define THK_STEP_B()                                                                                                   \
+    {                                                                                                                  \
+        const bool more = issued < g1;                                 /* uniform */                                   \
+        const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);                                              \
+        char* const nx_sb = lds + i_buf * ST;                                                                          \
+        const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;                                                \
+        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16 \
+                                    : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);        \
+        const int nx_row0 = i_rbl * TR + wave * 32 * NF + (lane >> 2);                                                 \
+        i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;                                                                      \
+        if (more) {                                                                                                    \
+            ++issued;                                                                                                  \
+            if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }                    \
+        }                                                                                                              \
+        const int nbuf = buf + 1 == NST ? 0 : buf + 1;                                                                 \
+        const char* const sbn = lds + nbuf * ST;                                                                       \
+        THK_PIN_ACC()                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                               \
+            THK_MFMA_ONE(1, i, MTH)                                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            if (i == SYNC_AT) {                                                                                        \
+                wait_vmcnt<(NST - 2) * LPS>();                 /* this wave's loads of chunk g+1 have landed ... */    \
+                __builtin_amdgcn_s_barrier();                  /* ... and everybody's; every wave holds chunk g's second half in registers: its stage is free */ \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+            if (i >= SYNC_AT && i < NM - 1) {                                                                          \
+                const int sl = i - SYNC_AT;                    /* behind the last chunk these reads fetch stale bytes nobody uses */ \
+                if (sl < RSLOTS) { _Pragma("unroll") for (int rr = sl * NRH / RSLOTS; rr < (sl + 1) * NRH / RSLOTS; ++rr) THK_READ_ONE(sbn, 0, rr, 0) } \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+                if (sl >= RSLOTS) {                                                                                    \
+                    _Pragma("unroll") for (int k = (sl - RSLOTS) * LT / TSLOTS; k < (sl - RSLOTS + 1) * LT / TSLOTS; ++k) \
+                        v3_issue_one<MT, NF, PK>(k, more, ximg, scratch, nx_sb, nx_xs, nx_w, nx_row0, R, C, wave);     \
+                }                                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+        }                                                                                                              \
+        buf = nbuf;                                                                                                    \
+        pend_more = more; pend_sb = nx_sb; pend_xs = nx_xs; pend_w = nx_w; pend_row0 = nx_row0;                         \
+        THK_PIN_ACC()                                                                                                  \
+        if (g + 1 == seg_end) {                            /* end of a row-block (or of the share): spill the tile */   \
+            flush(acc, seg);                                                                                           \
+            wait_vmcnt<0>();                               /* stores share the counter with the DMA queue: drain, then count afresh */ \
+            THK_ZERO_ACC()                                                                                             \
+            ++seg;                                                                                                     \
+            seg_end = seg_end + nchunks < g1 ? seg_end + nchunks : g1;                                                 \
+        }                                                                                                              \
+    }
+    int seg = 0, seg_end = (rbk_first + 1) * nchunks < g1 ? (rbk_first + 1) * nchunks : g1;
+    THK_ZERO_ACC()
+    wait_vmcnt<(NST - 1) * LPS>();                       // chunk g0 is in
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int rr = 0; rr < NRH; ++rr) THK_READ_ONE(lds, 0, rr, 0)
+    for (int g = g0;;) {
+        THK_STEP_A()
+        THK_STEP_B()
+        if (++g >= g1) break;
+    }
+#undef THK_STEP_A
+#undef THK_STEP_B
+#undef THK_MFMA_ONE
+#undef THK_READ_ONE
+#undef THK_ZERO_ACC
+#undef THK_PIN_ACC
+}
+
 static_assert(KernargLead<decltype(&gemm_prefill_v3_kernel<4, 2, true, kNST>)>::bytes() == kKernargPreloadBytes + 8,
               "gemm_prefill_v3_kernel: ten scalars (14 dwords, preloaded) and the partial-tile pointer ahead of the plan");
 
@@ -575,8 +765,8 @@ extern "C" __attribute__((visibility("default"))) int thk_debug_prefill_trace(un
 }
 #endif
 hipError_t launch_prefill_ximg(const float* X, const float* gain, int M, int C, void* ximg, hipStream_t st, unsigned long long* ssq) {
-    const int MT = (M + 31) / 32;
-    if (M < 1 || M > 128 || C % kKC != 0 || (ssq && !gain)) return hipErrorInvalidValue;
+    const int MT = prefill_token_tiles(M);
+    if (M < 1 || M > 256 || C % kKC != 0 || (ssq && !gain)) return hipErrorInvalidValue;
     if (gain && ssq) hipLaunchKernelGGL(ximg_from_rows_kernel<2>, dim3(MT * 32), dim3(256), 0, st, X, gain, M, MT, C, (char*)ximg, ssq);
     else if (gain) hipLaunchKernelGGL(ximg_from_rows_kernel<1>, dim3(MT * 32), dim3(256), 0, st, X, gain, M, MT, C, (char*)ximg, ssq);
     else hipLaunchKernelGGL(ximg_from_rows_kernel<0>, dim3(MT * 32), dim3(256), 0, st, X, gain, M, MT, C, (char*)ximg, ssq);
@@ -593,7 +783,7 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& plan
 #ifdef THK_PREFILL_TRACE
     { static int n_launch = 0; p.packed = (p.packed & 1) | ((n_launch++ & 3) << 8); }
 #endif
-    if (p.M < 1 || p.M > 128 || p.C % kKC != 0 || p.R % 4 != 0 || p.nmat < 1 || p.nmat > 3) return hipErrorInvalidValue;
+    if (p.M < 1 || p.M > 256 || p.MT != prefill_token_tiles(p.M) || p.C % kKC != 0 || p.R % 4 != 0 || p.nmat < 1 || p.nmat > 3) return hipErrorInvalidValue;
     const _Float16* w0 = reinterpret_cast<const _Float16*>(W[0]);
     const _Float16* w1 = reinterpret_cast<const _Float16*>(W[p.nmat > 1 ? 1 : 0]);
     const _Float16* w2 = reinterpret_cast<const _Float16*>(W[p.nmat > 2 ? 2 : 0]);
@@ -608,6 +798,20 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& plan
                                                 p.nchunks, p.per, p.rb_per_mat, p.rb_total, p.R, p.C, part, p); \
     }
 #define THK_V3(MTV, NFV) { if (p.packed & 1) THK_V3K(MTV, NFV, true) else THK_V3K(MTV, NFV, false) }
+#define THK_V3HK(NFV, PKV)                                                                                               \
+    {                                                                                                                    \
+        const size_t lds = (ximg_stage_bytes(8) + (size_t)NFV * 8192) * kNSTH + 4096;                                    \
+        static bool attr_done[kMaxDevices] = {};                                                                         \
+        const int dev = current_device();                                                                                \
+        if (!attr_done[dev]) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3h_kernel<NFV, PKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[dev] = (e == hipSuccess); } \
+        if (e == hipSuccess) hipLaunchKernelGGL((gemm_prefill_v3h_kernel<NFV, PKV>), dim3(p.G), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, \
+                                                p.nchunks, p.per, p.rb_per_mat, p.rb_total, p.R, p.C, part, p);         \
+    }
+    if (p.MT == 8) {                       // 129 .. 256 tokens: the two-half kernel
+        if (p.tile_rows == 128) { if (p.packed & 1) THK_V3HK(1, true) else THK_V3HK(1, false) }
+        else { if (p.packed & 1) THK_V3HK(2, true) else THK_V3HK(2, false) }
+        return e != hipSuccess ? e : hipGetLastError();
+    }
     if (p.tile_rows == 128) switch (p.MT) {
         case 1: THK_V3(1, 1) break;
         case 2: THK_V3(2, 1) break;
@@ -621,6 +825,7 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& plan
     }
 #undef THK_V3
 #undef THK_V3K
+#undef THK_V3HK
     return e != hipSuccess ? e : hipGetLastError();
 }
 hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st) {
@@ -695,7 +900,8 @@ __device__ __forceinline__ void attn_store_tile(const AttnTileRegs<D>& r, int la
 // IMG: instead of out[M, E] f32, write the hi/lo X image of the wo GEMM directly (one launch and one 2 MB round trip less)
 template <int D, bool IMG, bool KVH>
 __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __restrict__ Q, const void* __restrict__ Kc, const void* __restrict__ Vc,
-                                                                int n_past, int M, int H, float scale, float* __restrict__ out, char* __restrict__ img) {
+                                                                int n_past, int M, int H, float scale, float* __restrict__ out, char* __restrict__ img,
+                                                                int img_MT, int img_tok0 /* IMG: token tiles of the image, and the image row of query 0 */) {
     constexpr int KS = D / 16, DB = D / 32;
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];      // 4 waves x {hi, lo} x 32 x D halfs; reused for the merge
     __shared__ float sm_m[4][32], sm_l[4][32], sm_f[4][32];
@@ -818,10 +1024,10 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
         for (int w = 0; w < 4; ++w) acc += sm_o[((size_t)w * D + d) * 32 + q] * sm_f[w][q];
         if (IMG) {                                      // pad rows (tok >= M) of the image are zeros
             if (q0 + q >= M) acc = 0.f;
-            const int MT = (M + 31) / 32, col = hcol + d;
+            const int col = hcol + d;
             const _Float16 hi = (_Float16)acc;
-            *reinterpret_cast<_Float16*>(img + ximg_off(MT, 0, q0 + q, col) + (col & 7) * 2) = hi;
-            *reinterpret_cast<_Float16*>(img + ximg_off(MT, 1, q0 + q, col) + (col & 7) * 2) = (_Float16)(acc - (float)hi);
+            *reinterpret_cast<_Float16*>(img + ximg_off(img_MT, 0, img_tok0 + q0 + q, col) + (col & 7) * 2) = hi;
+            *reinterpret_cast<_Float16*>(img + ximg_off(img_MT, 1, img_tok0 + q0 + q, col) + (col & 7) * 2) = (_Float16)(acc - (float)hi);
         } else {
             out[(size_t)(q0 + q) * E + hcol + d] = acc;
         }
@@ -829,26 +1035,28 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
 }
 
 template <int D, bool IMG, bool KVH>
-static hipError_t launch_attn_prefill_t(const float* Q, const void* Kc, const void* Vc, int n_past, int M, int H, float* out, char* img, hipStream_t st) {
-    const int grid = H * ((M + 31) / 32);
+static hipError_t launch_attn_prefill_t(const float* Q, const void* Kc, const void* Vc, int n_past, int M, int H, float* out, char* img, hipStream_t st, int img_MT, int img_tok0, int q_tiles) {
+    const int grid = H * (q_tiles > 0 ? q_tiles : (M + 31) / 32);     // q_tiles > the queries' own tiles: the extra workgroups write the image's zero rows
     const size_t lds = (size_t)4 * 2 * 32 * D * 2;
     hipError_t e = hipSuccess;
     static bool done[kMaxDevices] = {};                 // the attribute is per device (64 KB dynamic + the static arrays)
     const int dev = current_device();
     if (!done[dev]) { e = hipFuncSetAttribute((const void*)attn_prefill_mfma_kernel<D, IMG, KVH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); done[dev] = (e == hipSuccess); }
-    if (e == hipSuccess) hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, IMG, KVH>), dim3(grid), dim3(256), lds, st, Q, Kc, Vc, n_past, M, H, 1.0f / sqrtf((float)D), out, img);
+    if (e == hipSuccess) hipLaunchKernelGGL((attn_prefill_mfma_kernel<D, IMG, KVH>), dim3(grid), dim3(256), lds, st, Q, Kc, Vc, n_past, M, H, 1.0f / sqrtf((float)D), out, img, img_MT > 0 ? img_MT : (M + 31) / 32, img_tok0);
     return e != hipSuccess ? e : hipGetLastError();
 }
 template <int D, bool KVH>
-static hipError_t launch_attn_prefill_d(const float* Q, const void* Kc, const void* Vc, int n_past, int M, int H, float* out, void* ximg, hipStream_t st) {
-    return out ? launch_attn_prefill_t<D, false, KVH>(Q, Kc, Vc, n_past, M, H, out, nullptr, st) : launch_attn_prefill_t<D, true, KVH>(Q, Kc, Vc, n_past, M, H, nullptr, (char*)ximg, st);
+static hipError_t launch_attn_prefill_d(const float* Q, const void* Kc, const void* Vc, int n_past, int M, int H, float* out, void* ximg, hipStream_t st, int img_MT, int img_tok0, int q_tiles) {
+    return out ? launch_attn_prefill_t<D, false, KVH>(Q, Kc, Vc, n_past, M, H, out, nullptr, st, 0, 0, 0) : launch_attn_prefill_t<D, true, KVH>(Q, Kc, Vc, n_past, M, H, nullptr, (char*)ximg, st, img_MT, img_tok0, q_tiles);
 }
 // out != null: out[M, H*D] f32;  otherwise ximg = the hi/lo X image (C = H*D, M <= 128) of the GEMM that consumes the attention output.
 // kv_f16: the caches hold binary16 rows (optional f16 KV cache); the tiles are widened to f32 as they are loaded.
-hipError_t launch_attn_prefill_mfma(const float* Q, const void* Kc, const void* Vc, bool kv_f16, int n_past, int M, int H, int D, float* out, void* ximg, hipStream_t st) {
+hipError_t launch_attn_prefill_mfma(const float* Q, const void* Kc, const void* Vc, bool kv_f16, int n_past, int M, int H, int D, float* out, void* ximg, hipStream_t st,
+                                    int img_MT, int img_tok0, int q_tiles) {
     if ((D != 64 && D != 128) || (!out && (!ximg || M > 128 || (H * D) % kKC != 0))) return hipErrorInvalidValue;
-    if (D == 128) return kv_f16 ? launch_attn_prefill_d<128, true>(Q, Kc, Vc, n_past, M, H, out, ximg, st) : launch_attn_prefill_d<128, false>(Q, Kc, Vc, n_past, M, H, out, ximg, st);
-    return kv_f16 ? launch_attn_prefill_d<64, true>(Q, Kc, Vc, n_past, M, H, out, ximg, st) : launch_attn_prefill_d<64, false>(Q, Kc, Vc, n_past, M, H, out, ximg, st);
+    if (img_MT < 0 || img_MT > 8 || img_tok0 < 0 || q_tiles < 0 || q_tiles > 4) return hipErrorInvalidValue;
+    if (D == 128) return kv_f16 ? launch_attn_prefill_d<128, true>(Q, Kc, Vc, n_past, M, H, out, ximg, st, img_MT, img_tok0, q_tiles) : launch_attn_prefill_d<128, false>(Q, Kc, Vc, n_past, M, H, out, ximg, st, img_MT, img_tok0, q_tiles);
+    return kv_f16 ? launch_attn_prefill_d<64, true>(Q, Kc, Vc, n_past, M, H, out, ximg, st, img_MT, img_tok0, q_tiles) : launch_attn_prefill_d<64, false>(Q, Kc, Vc, n_past, M, H, out, ximg, st, img_MT, img_tok0, q_tiles);
 }
 
 size_t gemm_prefill_workspace_bytes(int M, int R, int C) {
