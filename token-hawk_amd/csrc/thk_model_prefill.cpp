@@ -174,9 +174,8 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
         if ((D == 64 || D == 128) && tun(ctx, "prefill_attn_mfma") != 0) {
             if (M <= 128) {
                 HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, m->kv_f16 != 0, n_past, M, H, D, nullptr, b.imgE, st));   // writes wo's X image directly
-            } else {      // a 256-token slab: the attention kernel takes 128 queries per launch; both halves write the slab's eight-tile image (pad tiles as zero rows)
-                HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, m->kv_f16 != 0, n_past, 128, H, D, nullptr, b.imgE, st, 8, 0, 4));
-                HIPCHK(ctx, launch_attn_prefill_mfma(b.Q + (size_t)128 * E, kc, vc, m->kv_f16 != 0, n_past + 128, M - 128, H, D, nullptr, b.imgE, st, 8, 128, 4));
+            } else {      // a 256-token slab: one launch, eight 32-query tiles per head (256 workgroups for 7B), the slab's eight-tile image (pad tiles as zero rows)
+                HIPCHK(ctx, launch_attn_prefill_mfma(b.Q, kc, vc, m->kv_f16 != 0, n_past, M, H, D, nullptr, b.imgE, st, 8, 0, 8));
             }
         } else {
             HIPCHK(ctx, attn_prefill_dispatch(ctx, b.Q, kc, vc, n_past, M, H, D, b.ATT, m->kv_f16 != 0));

@@ -935,10 +935,13 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
     const int p_last = n_past + M - 1;                  // last cached row
     const int ntiles = (n_past + q_last) / 32 + 1;      // tiles that hold a position some query of this tile may see
     const int qabs = n_past + q0 + qn;                  // this lane's query position
+    // The K tile of a wave's NEXT round is requested under the current round's P V phase (the registers are free once V is in LDS), the first one next to
+    // the Q rows above: a wave with several tiles (a slab behind cached rows, the later query tiles of a 256-token slab) no longer pays a memory round trip
+    // per tile.  Branch-free: past the last tile the request repeats it (a load behind a branch is waited for at the join).
+    AttnTileRegs<D> tr;
+    attn_load_tile<D, KVH>(tr, Kc, (wave < ntiles ? wave : ntiles - 1) * 32, p_last, E, hcol, lane);
     for (int t = wave; t < ntiles; t += 4) {
         const int p0 = t * 32;
-        AttnTileRegs<D> tr;
-        attn_load_tile<D, KVH>(tr, Kc, p0, p_last, E, hcol, lane);
         __builtin_amdgcn_sched_barrier(0);
         attn_store_tile<D, true>(tr, lane, t_hi, t_lo);
         __builtin_amdgcn_sched_barrier(0);
@@ -983,6 +986,9 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
             for (int i = 0; i < 16; ++i) o[b][i] *= alpha;
         __builtin_amdgcn_sched_barrier(0);
         attn_store_tile<D, false>(tr, lane, t_hi, t_lo);                 // same LDS region: K is consumed
+        __builtin_amdgcn_sched_barrier(0);
+        attn_load_tile<D, KVH>(tr, Kc, (t + 4 < ntiles ? t + 4 : ntiles - 1) * 32, p_last, E, hcol, lane);     // next round's K, in flight under P V
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int b = 0; b < DB; ++b)
 #pragma unroll
@@ -1053,8 +1059,8 @@ static hipError_t launch_attn_prefill_d(const float* Q, const void* Kc, const vo
 // kv_f16: the caches hold binary16 rows (optional f16 KV cache); the tiles are widened to f32 as they are loaded.
 hipError_t launch_attn_prefill_mfma(const float* Q, const void* Kc, const void* Vc, bool kv_f16, int n_past, int M, int H, int D, float* out, void* ximg, hipStream_t st,
                                     int img_MT, int img_tok0, int q_tiles) {
-    if ((D != 64 && D != 128) || (!out && (!ximg || M > 128 || (H * D) % kKC != 0))) return hipErrorInvalidValue;
-    if (img_MT < 0 || img_MT > 8 || img_tok0 < 0 || q_tiles < 0 || q_tiles > 4) return hipErrorInvalidValue;
+    if ((D != 64 && D != 128) || (!out && (!ximg || M > 256 || (H * D) % kKC != 0))) return hipErrorInvalidValue;
+    if (img_MT < 0 || img_MT > 8 || img_tok0 < 0 || q_tiles < 0 || q_tiles > 8 || (!out && M > 128 && img_MT != 8)) return hipErrorInvalidValue;
     if (D == 128) return kv_f16 ? launch_attn_prefill_d<128, true>(Q, Kc, Vc, n_past, M, H, out, ximg, st, img_MT, img_tok0, q_tiles) : launch_attn_prefill_d<128, false>(Q, Kc, Vc, n_past, M, H, out, ximg, st, img_MT, img_tok0, q_tiles);
     return kv_f16 ? launch_attn_prefill_d<64, true>(Q, Kc, Vc, n_past, M, H, out, ximg, st, img_MT, img_tok0, q_tiles) : launch_attn_prefill_d<64, false>(Q, Kc, Vc, n_past, M, H, out, ximg, st, img_MT, img_tok0, q_tiles);
 }
