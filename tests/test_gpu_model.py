@@ -578,6 +578,27 @@ def test_prefill_256_token_slabs_equal_128_token_slabs(thk, dims, M, n_past):
     assert np.abs(nxt[256] - nxt[128]).max() < 5e-5
 
 
+def test_prefill_256_token_slab_with_f16_kv_cache_and_generic_attention(thk):
+    """The eight-tile slab with the binary16 K/V cache option (the reducer rounds the rows it appends, attention widens them) and with the generic causal
+    attention (`prefill_attn_mfma = 0`: attn_body with 200 queries, then an image launch of eight tiles): both against 128-token slabs."""
+    shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=320)
+    toks = np.concatenate([[1], np.random.default_rng(77).integers(3, 2048, 210)]).astype(np.int32)
+    for tun in ({"kv_f16": 1}, {"prefill_attn_mfma": 0}, {"kv_f16": 1, "prefill_attn_mfma": 0}):
+        out = {}
+        for sl in (128, 256):
+            with thk.Context(0) as c:
+                for k, v in tun.items():
+                    c.set_tunable(k, v)
+                c.set_tunable("prefill_slab_tokens", sl)
+                m = thk.Model(c, shape); m.fill_synthetic(); m.finalize()
+                m.eval(toks[:7], 0, want_logits=False)
+                lp = m.prefill(toks[7:207], 7).copy()
+                ln, _ = m.eval([int(toks[207])], 207)
+                out[sl] = (lp, ln)
+                m.close()
+        assert np.abs(out[256][0] - out[128][0]).max() < 5e-5 and np.abs(out[256][1] - out[128][1]).max() < 5e-5, tun
+
+
 def test_prefill_into_second_sequence_and_faithful_head(thk, orc, ctx):
     """Prefill writes the KV rows of the sequence it is given (not sequence 0) and honours the lm-head mode."""
     m, om = make_pair(thk, orc, ctx, "TINY_Q1", n_seq=2, lm_mode=1)     # 1 = THK_LMHEAD_FAITHFUL (defect Q1 reproduced)
