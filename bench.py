@@ -281,7 +281,9 @@ def extra_prefill_128(thk, model, shape, ctx):
     return {"workload": f"LLaMA-7B f16, {M}-token prompt prefill (n_past=0), 1 GPU, logits of the last token read back", "ms": round(t * 1e3, 3), "roofline": roof, "prompt_512_tokens_ms": long_ms,
             "ms_min": round(min(ts) * 1e3, 3), "tok_s": round(M / t, 1), "tflops": round(flops / t / 1e12, 2), "mfma_peak_tflops_f16_dense": 2500,
             "frac_of_mfma_peak": round(flops / t / 2.5e15, 4), "weight_pass_hbm_ms": round(shape.weight_bytes() / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
-            "first_call_ms": round(t_first * 1e3, 1), "timing": "host wall time around thk_model_prefill (host-to-device token copy and 128 KB logits read-back included), median of 5"}
+            "first_call_ms": round(t_first * 1e3, 1), "timing": "host wall time around thk_model_prefill (host-to-device token copy and 128 KB logits read-back included), median of 5",
+            "prefill_slab_tokens": int(ctx.get_tunable("prefill_slab_tokens")),
+            "prompt_512_note": "four 128-token slabs in rounds 1-4 (24.4-25.0 ms); since round 5 two slabs of 256 tokens = two weight passes (gemm_prefill_v3h_kernel)"}
 
 
 def extra_decode_ctx2048(thk, ctx, stream, torch, kv_f16, steps=60, warmup=10):
