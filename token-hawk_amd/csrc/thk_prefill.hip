@@ -860,6 +860,15 @@ hipError_t launch_prefill_reduce_swiglu(const float* part, const PrefillPlan& p,
 // Replaces one workgroup per (head, query) re-reading that head's K/V from L2: 17 -> 105 us per slab-layer as the
 // context grew from 128 to 512 positions.
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+#ifdef THK_ATTN_TRACE      // development build only (tools/dev/attn_trace.py): 100 MHz wall-clock stamps of one wave per workgroup at the kernel's phase edges
+__device__ unsigned long long g_at_trace[1024 * 4 * 12];
+#define AT_T(i) { if (lane == 0) g_at_trace[((blockIdx.x & 1023) * 4 + wave) * 12 + (i)] = wall_clock64(); }
+extern "C" __attribute__((visibility("default"))) int thk_debug_attn_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_at_trace), sizeof(unsigned long long) * 1024 * 4 * 12);
+}
+#else
+#define AT_T(i)
+#endif
 __device__ __forceinline__ void split4(const f4 v, h4v& hi, h4v& lo) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { hi[e] = (_Float16)v[e]; lo[e] = (_Float16)(v[e] - (float)hi[e]); }
@@ -912,6 +921,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
     _Float16* t_hi = reinterpret_cast<_Float16*>(lds_raw) + (size_t)wave * 2 * 32 * D;
     _Float16* t_lo = t_hi + 32 * D;
 
+    AT_T(0)
     h8 qh[KS], ql[KS];                                  // B fragments of Q^T: lane (q, half) holds d = 16 ks + 8 half + e
     {
         const int qrow = q0 + qn < M ? q0 + qn : M - 1;
@@ -938,12 +948,14 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
     // The K tile of a wave's NEXT round is requested under the current round's P V phase (the registers are free once V is in LDS), the first one next to
     // the Q rows above: a wave with several tiles (a slab behind cached rows, the later query tiles of a 256-token slab) no longer pays a memory round trip
     // per tile.  Branch-free: past the last tile the request repeats it (a load behind a branch is waited for at the join).
+    AT_T(1)
     AttnTileRegs<D> tr;
     attn_load_tile<D, KVH>(tr, Kc, (wave < ntiles ? wave : ntiles - 1) * 32, p_last, E, hcol, lane);
     for (int t = wave; t < ntiles; t += 4) {
         const int p0 = t * 32;
         __builtin_amdgcn_sched_barrier(0);
         attn_store_tile<D, true>(tr, lane, t_hi, t_lo);
+        AT_T(2)
         __builtin_amdgcn_sched_barrier(0);
         attn_load_tile<D, KVH>(tr, Vc, p0, p_last, E, hcol, lane);           // V's round trip runs under the S^T / softmax phase
         __builtin_amdgcn_sched_barrier(0);
@@ -958,6 +970,7 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
         }
+        AT_T(3)
         // s[r] = S[pos = p0 + (r&3) + 8 (r>>2) + 4 half][this lane's query]; scale after the sum (th.cpp:527-529), causal mask
         float bm = -INFINITY;
 #pragma unroll
@@ -985,7 +998,9 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
 #pragma unroll
             for (int i = 0; i < 16; ++i) o[b][i] *= alpha;
         __builtin_amdgcn_sched_barrier(0);
+        AT_T(4)
         attn_store_tile<D, false>(tr, lane, t_hi, t_lo);                 // same LDS region: K is consumed
+        AT_T(5)
         __builtin_amdgcn_sched_barrier(0);
         attn_load_tile<D, KVH>(tr, Kc, (t + 4 < ntiles ? t + 4 : ntiles - 1) * 32, p_last, E, hcol, lane);     // next round's K, in flight under P V
         __builtin_amdgcn_sched_barrier(0);
@@ -1004,8 +1019,10 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
                 o[b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, ph[s2], o[b], 0, 0, 0);
             }
     }
+    AT_T(6)
     // merge the four waves: o[b][r] = O^T[d = 32 b + (r&3) + 8 (r>>2) + 4 half][q = qn]
     __syncthreads();                                    // every wave is done with its tile region
+    AT_T(7)
     float* sm_o = reinterpret_cast<float*>(lds_raw);    // [wave][d][32]
     if (half == 0) { sm_m[wave][qn] = m; sm_l[wave][qn] = l; }
 #pragma unroll
@@ -1022,22 +1039,37 @@ __global__ __launch_bounds__(256) void attn_prefill_mfma_kernel(const float* __r
         sm_f[w][q] = (sm_m[w][q] == -INFINITY) ? 0.f : expf(sm_m[w][q] - mm) / den;
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < 32 * D; idx += 256) {
-        const int q = idx / D, d = idx % D;
-        if (!IMG && q0 + q >= M) break;
-        float acc = 0.f;
+    AT_T(8)
+    // A thread finishes 8 consecutive columns of one query = one 16-byte piece of the image (hi) and one of its lo half - or two float4 of `out`.  (Round 5:
+    // the first version stored the image's halfs one by one, 32 two-byte stores per thread: 7.3 of the launch's 16 us, tools/dev/attn_trace.py.)
+    for (int idx = threadIdx.x; idx < 32 * (D / 8); idx += 256) {
+        const int q = idx & 31, d0 = (idx >> 5) * 8;                    // consecutive lanes = consecutive queries: conflict-free LDS reads
+        if (!IMG && q0 + q >= M) continue;
+        float acc[8];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) acc += sm_o[((size_t)w * D + d) * 32 + q] * sm_f[w][q];
+        for (int e = 0; e < 8; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += sm_o[((size_t)w * D + d0 + e) * 32 + q] * sm_f[w][q];
+            acc[e] = a;
+        }
         if (IMG) {                                      // pad rows (tok >= M) of the image are zeros
-            if (q0 + q >= M) acc = 0.f;
-            const int col = hcol + d;
-            const _Float16 hi = (_Float16)acc;
-            *reinterpret_cast<_Float16*>(img + ximg_off(img_MT, 0, img_tok0 + q0 + q, col) + (col & 7) * 2) = hi;
-            *reinterpret_cast<_Float16*>(img + ximg_off(img_MT, 1, img_tok0 + q0 + q, col) + (col & 7) * 2) = (_Float16)(acc - (float)hi);
+            h8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = q0 + q >= M ? 0.f : acc[e];
+                hi[e] = (_Float16)a; lo[e] = (_Float16)(a - (float)hi[e]);
+            }
+            const int col = hcol + d0;
+            *reinterpret_cast<h8*>(img + ximg_off(img_MT, 0, img_tok0 + q0 + q, col)) = hi;
+            *reinterpret_cast<h8*>(img + ximg_off(img_MT, 1, img_tok0 + q0 + q, col)) = lo;
         } else {
-            out[(size_t)(q0 + q) * E + hcol + d] = acc;
+            float* dst = out + (size_t)(q0 + q) * E + hcol + d0;
+            *reinterpret_cast<f4*>(dst) = f4{acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f4*>(dst + 4) = f4{acc[4], acc[5], acc[6], acc[7]};
         }
     }
+    AT_T(9)
 }
 
 template <int D, bool IMG, bool KVH>
