@@ -629,6 +629,15 @@ __global__ __launch_bounds__(256) void ximg_from_rows_kernel(const float* __rest
     }
 }
 
+#ifdef THK_ATTN_TRACE      // the same development build also stamps the reducers (tools/dev/attn_trace.py reducers): [kernel 0..2][workgroup][stamp]
+__device__ unsigned long long g_rd_trace[3 * 4096 * 4];
+#define RD_T(k, i) { if (threadIdx.x == 0) g_rd_trace[(((k) * 4096 + ((blockIdx.y * gridDim.x + blockIdx.x) & 4095)) * 4) + (i)] = wall_clock64(); }
+extern "C" __attribute__((visibility("default"))) int thk_debug_reduce_trace(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rd_trace), sizeof(unsigned long long) * 3 * 4096 * 4);
+}
+#else
+#define RD_T(k, i)
+#endif
 // ---- reducers ----------------------------------------------------------------------------------
 // A partial slot holds one 256-row x Mpad-token tile in the MFMA accumulator's own order ("fragment order"), so the
 // GEMM's spill is a sequence of contiguous 1 KiB stores and the reducers' reads are contiguous too: float4 number
@@ -675,6 +684,7 @@ __global__ __launch_bounds__(256) void reduce_store_kernel(const float* __restri
 __global__ __launch_bounds__(256) void reduce_resid_ximg_kernel(const float* __restrict__ part, PrefillPlan p, float* __restrict__ X, const float* __restrict__ gain,
                                                                 char* __restrict__ img, unsigned long long* __restrict__ ssq, const unsigned long long* __restrict__ ssq_scale) {
     __shared__ float red[4][32];
+    RD_T(0, 0)
     const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;
     const FragPos fp = frag_decode(q, p.MT);
     const int r = rbk * p.tile_rows + fp.row, tok = fp.tok;
@@ -685,6 +695,7 @@ __global__ __launch_bounds__(256) void reduce_resid_ximg_kernel(const float* __r
     if (live) {
         f4* dst = reinterpret_cast<f4*>(X + (size_t)tok * p.R + r);
         const f4 x = *dst + sum_partials(part, p, rbk, q);
+        RD_T(0, 1)
         *dst = x;
         const f4 g = *reinterpret_cast<const f4*>(gain + r);
         const float sc = ssq_pow2(ssq_scale, tok, p.R);          // power of two near this token's 1/rms (from its previous norm input)
@@ -701,6 +712,7 @@ __global__ __launch_bounds__(256) void reduce_resid_ximg_kernel(const float* __r
         *reinterpret_cast<h4*>(img + ximg_off(p.MT, 1, tok, r) + sub) = lo;
     }
     // the token's 32 rows of this workgroup: lanes l, l + 32 (row halves), then the four waves (g)
+    RD_T(0, 2)
     ss += __shfl_xor(ss, 32, 64);
     if ((threadIdx.x & 63) < 32) red[threadIdx.x >> 6][threadIdx.x & 31] = ss;
     __syncthreads();
@@ -708,6 +720,7 @@ __global__ __launch_bounds__(256) void reduce_resid_ximg_kernel(const float* __r
         const int t2 = fp.tok;                      // thread l < 32: lane l of wave 0 -> token (tile) * 32 + l
         if (t2 < p.M) ssq_add(ssq, t2, (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
     }
+    RD_T(0, 3)
 }
 // q -> RoPE -> Q[tok];  k -> RoPE -> K-cache row n_past+tok;  v -> V-cache row  (K6, th-llama.cpp:318-339)
 // ssq != NULL: the GEMM ran on the un-normalised image (deferred norm): the token's 1/rms is applied here
@@ -718,9 +731,12 @@ __global__ __launch_bounds__(256) void reduce_qkv_kernel(const float* __restrict
     const int q = blockIdx.x * 256 + threadIdx.x, rbk = blockIdx.y;
     const FragPos fp = frag_decode(q, p.MT);
     const int mat = rbk / p.rb_per_mat, r = (rbk % p.rb_per_mat) * p.tile_rows + fp.row, tok = fp.tok;
+    RD_T(1, 0)
     if (tok >= p.M || r >= p.R) return;
     f4 s = sum_partials(part, p, rbk, q);
+    RD_T(1, 1)
     if (ssq) s = s * (ssq_inv(ssq, tok, p.C) / ssq_pow2(ssq_scale, tok, p.C));      // the division by a power of two is exact
+    RD_T(1, 2)
     const int pos = n_past + tok;
     if (mat < 2) {
         const int half = D >> 1, jp = (r % D) >> 1;
@@ -745,8 +761,10 @@ __global__ __launch_bounds__(256) void reduce_swiglu_ximg_kernel(const float* __
     if (r >= p.R) return;
     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     h4 hi = h4{0, 0, 0, 0}, lo = h4{0, 0, 0, 0};
+    RD_T(2, 0)
     if (tok < p.M) {
         f4 u1 = sum_partials(part, p, rbk, q), u3 = sum_partials(part, p, rbk + p.rb_per_mat, q);
+        RD_T(2, 1)
         if (ssq) { const float inv = ssq_inv(ssq, tok, p.C) / ssq_pow2(ssq_scale, tok, p.C); u1 = u1 * inv; u3 = u3 * inv; }    // deferred norm
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -757,6 +775,7 @@ __global__ __launch_bounds__(256) void reduce_swiglu_ximg_kernel(const float* __
     const size_t sub = (size_t)(r & 4) * 2;                              // second half of the piece
     *reinterpret_cast<h4*>(img + ximg_off(p.MT, 0, tok, r) + sub) = hi;
     *reinterpret_cast<h4*>(img + ximg_off(p.MT, 1, tok, r) + sub) = lo;
+    RD_T(2, 3)
 }
 
 #ifdef THK_PREFILL_TRACE

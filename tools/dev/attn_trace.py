@@ -29,4 +29,17 @@ with thk.Context(0) as ctx:
             active = w <= qt
             row = [(blk[:, w, i].mean() - t0) / 100.0 for i in range(10)]
             print(f"   wave {w} {'(has a tile)' if active else '(no tile)  '}: " + "  ".join(f"{names[i]} {row[i]:.2f}" for i in ([0, 1, 2, 3, 4, 5, 6, 7, 8, 9] if active else [0, 1, 6, 7, 8, 9])))
+    if len(sys.argv) > 2 and sys.argv[2] == "reducers":     # the three reducer kernels of the LAST layer-slab: when their workgroups start, have their partial sums, end
+        rb = (ctypes.c_ulonglong * (3 * 4096 * 4))()
+        lib.thk_debug_reduce_trace(rb)
+        r = np.frombuffer(rb, dtype=np.uint64).reshape(3, 4096, 4).astype(np.float64)
+        for k, nm in enumerate(["reduce_resid_ximg (last launch: w2's)", "reduce_qkv", "reduce_swiglu_ximg"]):
+            x = r[k]; x = x[x[:, 0] > 0]
+            if not len(x): continue
+            t0 = x[:, 0].min()
+            def pct(col, q): 
+                v = x[:, col]; v = v[v > 0]
+                return (np.percentile(v, q) - t0) / 100.0 if len(v) else float("nan")
+            print(f"{nm}: {len(x)} workgroups stamped; entry p50 {pct(0, 50):.2f} p100 {pct(0, 100):.2f} | sums in hand p50 {pct(1, 50):.2f} p100 {pct(1, 100):.2f} | "
+                  f"stamp2 p50 {pct(2, 50):.2f} p100 {pct(2, 100):.2f} | end p50 {pct(3, 50):.2f} p100 {pct(3, 100):.2f}  (us after the launch's first stamp)")
     m.close()
