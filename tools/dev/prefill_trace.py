@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import __graft_entry__ as graft
 thk = graft.load_package()
-lib = ctypes.CDLL(os.path.join(ROOT, "token-hawk_amd", "libthk.so"))
+lib = ctypes.CDLL(os.environ.get("THK_LIB") or os.path.join(ROOT, "token-hawk_amd", "libthk.so"))
 names = ["prologue issue + flush/drain", "step head (MFMAs before sync)", "wait vmcnt", "barrier", "step rest (MFMA+reads+DMA)", "flush stores", "drain", "TOTAL"]
 shape = thk.LLAMA_7B
 M = 128
