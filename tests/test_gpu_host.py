@@ -277,6 +277,25 @@ def test_device_topk_sampler_generates_the_same_text(host, ctx, model_file, para
     assert out[0] == out[1]
 
 
+@pytest.mark.parametrize("k", [1, 41, 64, 300, 1024])
+def test_model_eval_topk_equals_eval_plus_sort(thk, ctx, k):
+    """thk_model_eval_topk (the stochastic sampler's per-token call: step + two-launch top-k + keys written into host-mapped memory + polled stamp) against
+    thk_model_eval's full logits sorted on the host (value descending, ties by ascending id), over several positions and multi-token calls; k = 1024 at
+    V = 32000 takes the top-k's two merge levels."""
+    m = thk.Model(ctx, thk.TINY_Q1); m.fill_synthetic(); m.finalize()
+    r = thk.Model(ctx, thk.TINY_Q1); r.fill_synthetic(); r.finalize()
+    toks = [1, 5, 9, 31999, 77]
+    pos = 0
+    for chunk in ([toks[0]], toks[1:3], [toks[3]], [toks[4]]):
+        vals, ids = m.eval_topk(chunk, pos, k)
+        for i, t in enumerate(chunk):       # the reference side one step at a time: eval_topk steps its tokens singly too
+            lg, _ = r.eval([t], pos + i)
+        order = np.lexsort((np.arange(lg.size), -lg))[:k]
+        assert np.array_equal(ids, order.astype(np.int32)) and np.array_equal(vals.view(np.uint32), lg[order].view(np.uint32)), (pos, k)
+        pos += len(chunk)
+    m.close(); r.close()
+
+
 def test_model_logits_topk_and_read_logits(thk, ctx):
     m = thk.Model(ctx, thk.TINY_Q1); m.fill_synthetic(); m.finalize()
     lg, _ = m.eval([1, 5, 9], 0)

@@ -307,6 +307,13 @@ class Model:
                                                       None if logits is None else logits.ctypes.data), "thk_model_prefill")
         return logits
 
+    def eval_topk(self, tokens, n_past: int, k: int, seq: int = 0):
+        """thk_model_eval_topk: the step(s) and the k largest logits of the last token in one stream round trip -> (values, ids), value descending."""
+        toks = np.ascontiguousarray(tokens, np.int32)
+        vals, ids = np.empty(k, np.float32), np.empty(k, np.int32)
+        self.ctx.check(self.ctx.lib.thk_model_eval_topk(self.h, seq, toks.ctypes.data, toks.size, n_past, k, vals.ctypes.data, ids.ctypes.data), "thk_model_eval_topk")
+        return vals, ids
+
     def logits_topk(self, k: int, seq: int = 0):
         vals, ids = np.empty(k, np.float32), np.empty(k, np.int32)
         self.ctx.check(self.ctx.lib.thk_model_logits_topk(self.h, seq, k, vals.ctypes.data, ids.ctypes.data), "thk_model_logits_topk")

@@ -45,14 +45,6 @@ __device__ __forceinline__ float wave_max(float v) {
     v = row16_max(v);
     return fmaxf(fmaxf(rdlane(v, 0), rdlane(v, 16)), fmaxf(rdlane(v, 32), rdlane(v, 48)));
 }
-// The same for unsigned words (packed counters): wave-uniform result.
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
-__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
-    v += dpp_u<0xB1>(v); v += dpp_u<0x4E>(v); v += dpp_u<0x141>(v); v += dpp_u<0x140>(v);
-    return ((unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16)) +
-           ((unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48));
-}
 // Sum over aligned groups of G lanes (G = 16, 32 or 64); every lane of a group gets its group's sum.
 template <int G>
 __device__ __forceinline__ float group_sum(float v) {
