@@ -37,6 +37,19 @@ __device__ __forceinline__ float wave_sum_prefill(float v) {
     return v;
 }
 
+// Diagnostic builds (tools/dev/gemm_diag.sh; results are WRONG, only the timing is of interest - DESIGN.md 4.3 "what bounds the GEMM loop"):
+//   -DTHK_PF_FAKEW  every workgroup streams the same eight weight tiles (L2-resident): the loop with the HBM stream taken out
+//   -DTHK_PF_NOLO   the lo-piece MFMAs are skipped: the loop with half the matrix work
+#ifdef THK_PF_FAKEW
+#define THK_WTILE(RBL, CH) ((size_t)((CH) & 7))
+#else
+#define THK_WTILE(RBL, CH) ((size_t)(RBL) * nchunks + (CH))
+#endif
+#ifdef THK_PF_NOLO
+constexpr bool kNoLo = true;
+#else
+constexpr bool kNoLo = false;
+#endif
 constexpr int kKC = 32;                  // K columns per LDS stage (2 MFMA k-steps)
 
 static int current_device() { int d = 0; (void)hipGetDevice(&d); return d >= 0 && d < kMaxDevices ? d : 0; }
@@ -136,7 +149,7 @@ __device__ __forceinline__ void v3_issue_one(int k, bool real, const char* dummy
 }
 
 #ifdef THK_PREFILL_TRACE   // development build only (tools/dev/prefill_trace.py): per-wave cycle totals of the main loop's phases
-__device__ unsigned long long g_pf_trace[4 * 256 * 4 * 8];   // [launch index mod 4][workgroup][wave][phase]
+__device__ unsigned long long g_pf_trace[4 * 256 * 4 * 12];   // [launch index mod 4][workgroup][wave][phase]
 #define PF_T(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tr_[i] += now_ - tlast_; tlast_ = now_; }
 #else
 #define PF_T(i)
@@ -193,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
     char* const scratch = lds + NST * ST + wave * 1024;   // where dummy loads land
     int issued = g0;
 #ifdef THK_PREFILL_TRACE
-    unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_readcyclecounter();
+    unsigned long long tr_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast_ = __builtin_readcyclecounter();
     const unsigned long long tstart_ = tlast_, wstart_ = wall_clock64();
 #endif
 #pragma unroll
@@ -201,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
         const bool more = issued < g1;
         const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);
         const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;
-        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16
+        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + THK_WTILE(i_rbl, i_ch) * WI + lane * 16
                                     : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);
 #pragma unroll
         for (int k = 0; k < LPS; ++k) v3_issue_one<MT, NF, PK>(k, more, ximg, scratch, lds + s * ST, nx_xs, nx_w, i_rbl * TR + wave * 32 * NF + (lane >> 2), R, C, wave);
@@ -254,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
         const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);                                              \
         char* const nx_sb = lds + i_buf * ST;                                                                          \
         const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;                                                \
-        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16 \
+        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + THK_WTILE(i_rbl, i_ch) * WI + lane * 16 \
                                     : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);        \
         const int nx_row0 = i_rbl * TR + wave * 32 * NF + (lane >> 2);                                                 \
         i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;                                                                      \
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
                    Per accumulator the order stays ks0.hi ks0.lo ks1.hi ks1.lo: results do not depend on the sweep. */                    \
                 const int ks = i / (2 * NF * MT), j = i % (2 * NF * MT), hl = j / (NF * MT), t = (j % (NF * MT)) / NF, f = j % NF; \
                 if (hl == 0) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][f], fbh[S][ks][t], acc[f][t], 0, 0, 0); \
-                else acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][f], fbl[S][ks][t], acc[f][t], 0, 0, 0); \
+                else if (!kNoLo) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][f], fbl[S][ks][t], acc[f][t], 0, 0, 0); \
             }                                                                                                          \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
             if (i < SYNC_AT) {                                                                                         \
@@ -298,6 +311,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
                 }                                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
             }                                                                                                          \
+            if (i == SYNC_AT + RSLOTS - 1) { PF_T(8) }                                                                 \
         }                                                                                                              \
         buf = nbuf;                                                                                                    \
         pend_more = more; pend_sb = nx_sb; pend_xs = nx_xs; pend_w = nx_w; pend_row0 = nx_row0;                         \
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
 #ifdef THK_PREFILL_TRACE
     tr_[7] = __builtin_readcyclecounter() - tstart_;
     tr_[5] = wstart_; tr_[6] = wall_clock64();           // chip-global 100 MHz clock: when this wave started / ended
-    if (lane == 0) for (int i = 0; i < 8; ++i) g_pf_trace[((((plan.packed >> 8) & 3) * 256 + blockIdx.x) * 4 + wave) * 8 + i] = tr_[i];
+    if (lane == 0) for (int i = 0; i < 12; ++i) g_pf_trace[((((plan.packed >> 8) & 3) * 256 + blockIdx.x) * 4 + wave) * 12 + i] = tr_[i];
 #endif
 #undef THK_STEP
 #undef THK_READ_ONE
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3h_kernel(const _Float16
         const bool more = issued < g1;
         const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);
         const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;
-        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16
+        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + THK_WTILE(i_rbl, i_ch) * WI + lane * 16
                                     : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);
 #pragma unroll
         for (int k = 0; k < LPS; ++k) v3_issue_one<MT, NF, PK>(k, more, ximg, scratch, lds + s * ST, nx_xs, nx_w, i_rbl * TR + wave * 32 * NF + (lane >> 2), R, C, wave);
@@ -434,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3h_kernel(const _Float16
     {                                                                                                                  \
         const int ks = (I) / (2 * NF * MTH), j = (I) % (2 * NF * MTH), hl = j / (NF * MTH), t = (j % (NF * MTH)) / NF, f = j % NF; \
         if (hl == 0) acc[f][(TOFF) + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][f], fbh[S][ks][t], acc[f][(TOFF) + t], 0, 0, 0); \
-        else acc[f][(TOFF) + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][f], fbl[S][ks][t], acc[f][(TOFF) + t], 0, 0, 0); \
+        else if (!kNoLo) acc[f][(TOFF) + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][ks][f], fbl[S][ks][t], acc[f][(TOFF) + t], 0, 0, 0); \
     }
     // step A: tiles 0-3 from set 0; pending DMA half; this chunk's tiles 4-7 -> set 1
 #define THK_STEP_A()                                                                                                   \
@@ -463,7 +477,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3h_kernel(const _Float16
         const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);                                              \
         char* const nx_sb = lds + i_buf * ST;                                                                          \
         const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;                                                \
-        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + ((size_t)i_rbl * nchunks + i_ch) * WI + lane * 16 \
+        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + THK_WTILE(i_rbl, i_ch) * WI + lane * 16 \
                                     : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);        \
         const int nx_row0 = i_rbl * TR + wave * 32 * NF + (lane >> 2);                                                 \
         i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;                                                                      \
@@ -780,7 +794,7 @@ __global__ __launch_bounds__(256) void reduce_swiglu_ximg_kernel(const float* __
 
 #ifdef THK_PREFILL_TRACE
 extern "C" __attribute__((visibility("default"))) int thk_debug_prefill_trace(unsigned long long* out) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pf_trace), sizeof(unsigned long long) * 4 * 256 * 4 * 8);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pf_trace), sizeof(unsigned long long) * 4 * 256 * 4 * 12);
 }
 #endif
 hipError_t launch_prefill_ximg(const float* X, const float* gain, int M, int C, void* ximg, hipStream_t st, unsigned long long* ssq) {

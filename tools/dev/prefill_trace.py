@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as graft
 thk = graft.load_package()
 lib = ctypes.CDLL(os.environ.get("THK_LIB") or os.path.join(ROOT, "token-hawk_amd", "libthk.so"))
-names = ["prologue issue + flush/drain", "step head (MFMAs before sync)", "wait vmcnt", "barrier", "step rest (MFMA+reads+DMA)", "flush stores", "drain", "TOTAL"]
+names = ["prologue issue + flush/drain", "step head (MFMAs before sync)", "wait vmcnt", "barrier", "step rest (MFMA+reads+DMA)", "flush stores", "drain", "TOTAL", "step rest: read slots", "-", "-", "-"]
 shape = thk.LLAMA_7B
 M = 128
 rng = np.random.default_rng(0)
@@ -21,13 +21,13 @@ with thk.Context(0) as ctx:
     sh = dataclasses.replace(shape, n_layer=1)
     m = thk.Model(ctx, sh); m.fill_synthetic(); m.finalize()
     for _ in range(3): m.reset_kv(0); m.prefill(toks, 0)          # 4 GEMM launches per prefill: launch index mod 4 = qkv, wo, w13, w2
-    buf = (ctypes.c_ulonglong * (4 * 256 * 4 * 8))()
+    buf = (ctypes.c_ulonglong * (4 * 256 * 4 * 12))()
     rc = lib.thk_debug_prefill_trace(buf)
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(4, 256, 4, 8).astype(np.float64)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(4, 256, 4, 12).astype(np.float64)
     for k, kind in enumerate(["qkv", "wo", "w13", "w2"]):
         print(kind, "rc", rc)
         for i, n in enumerate(names):
-            if i in (5, 6): continue
+            if i in (5, 6, 9, 10, 11): continue
             print("   %-32s mean %9.0f   min %9.0f   max %9.0f cycles" % (n, a[k, :, :, i].mean(), a[k, :, :, i].min(), a[k, :, :, i].max()))
         st, en = a[k, :, :, 5], a[k, :, :, 6]
         t0 = st.min()
