@@ -140,11 +140,24 @@ def parity_check(model, om, orc, prompt, T, budget_s=75.0):
         greedy_equal = greedy_equal and int(lg.argmax()) == orc.greedy(lo)
     dt = (time.time() - t0) / early
     out = {"tolerance": 1e-3, "reference": "oracle fast flavour (CPU restatement of th_eval_gpu, th-llama.cpp:464-660), same seeded weights and prompt"}
-    if T - 1 >= early and (T - 1 - early) * dt * 0.9 < budget_s:        # the early evals carry the logits head; cache-fill evals do not
-        if T - 1 > early:
-            model.eval(prompt[early:T - 1], early, want_logits=False)
-            for i in range(early, T - 1):
-                om.eval(int(prompt[i]), i, want_logits=False, flags=0)
+    PF = 128                                                             # config C3: the first 128 tokens through the MFMA prefill path, checked at position 127
+    walk_to = T - 1 if (T - 1 >= early and (T - 1 - early) * dt * 0.9 < budget_s) else (PF - 1 if (T > PF and (PF - 1 - early) * dt * 0.9 < budget_s) else early - 1)
+    lo_pf = None
+    for i in range(early, min(walk_to, T - 2) + 1):                      # the oracle walks the prompt once; the early evals carried the logits head, cache-fill evals do not
+        if i == PF - 1 and T > PF:
+            lo_pf, _ = om.eval(int(prompt[i]), i, flags=0)
+        else:
+            om.eval(int(prompt[i]), i, want_logits=False, flags=0)
+    if lo_pf is not None:
+        try:
+            lp = model.prefill(prompt[:PF], 0)                           # rows 0..127 of sequence 0 rewritten by the prefill path
+            per["prefill_%d" % (PF - 1)] = float(np.abs(lp - lo_pf).max())
+            greedy_equal = greedy_equal and int(lp.argmax()) == orc.greedy(lo_pf)
+        except Exception as e:                                           # a report item: the decode positions are still checked
+            out["prefill_note"] = f"prefill check failed to run: {e}"
+    if walk_to == T - 1:
+        if T - 1 > 0:
+            model.eval(prompt[:T - 1], 0, want_logits=False)             # every row again through the decode path (the prefill check wrote its own)
         lg, _ = model.eval([int(prompt[T - 1])], T - 1)
         lo, _ = om.eval(int(prompt[T - 1]), T - 1, flags=0)
         per[str(T - 1)] = float(np.abs(lg - lo).max())
@@ -152,7 +165,7 @@ def parity_check(model, om, orc, prompt, T, budget_s=75.0):
         out["logit_abs_max_at_last"] = round(float(np.abs(lo).max()), 3)
     else:
         out["note"] = f"n_past={T - 1} skipped: the oracle needs ~{(T - 1 - early) * dt:.0f}s for the prompt on this host (budget {budget_s:.0f}s); tests/test_gpu_full_depth.py covers it"
-    out.update({"positions": [int(k) for k in per], "max_abs_logit_diff": float(f"{max(per.values()):.3e}"),
+    out.update({"positions": [int(k) if k.isdigit() else k for k in per], "max_abs_logit_diff": float(f"{max(per.values()):.3e}"),
                 "per_position": {k: float(f"{v:.3e}") for k, v in per.items()}, "greedy_equal": bool(greedy_equal),
                 "pass": bool(max(per.values()) < 1e-3 and greedy_equal), "wall_s": round(time.time() - t0, 1)})
     return out

@@ -79,7 +79,7 @@ def _full_depth(thk, orc, ctx, name, early, T):
             else:
                 om.eval(int(prompt[i]), i, want_logits=False, flags=0)
         # config C3 at full depth against the ORACLE (not against the HIP decode path): the first 128 tokens of the very prompt through
-        # the MFMA prefill path (GEMMs with the in-launch split-K combine, MFMA attention) on a second HIP model - logits and the final
+        # the MFMA prefill path (stream-K GEMMs + reducers, MFMA attention) on a second HIP model - logits and the final
         # hidden state at position 127 (semantics th-llama.cpp:464-660 with the batch branch :307-311)
         mp = thk.Model(ctx, shape); mp.fill_synthetic(); mp.finalize()
         try:
