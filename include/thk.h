@@ -353,7 +353,10 @@ int thk_peer_destroy(thk_peer* p);
  *            in-launch wait, kept tested);
  *            measure_skip_kernel (1..6: that kernel is not launched -- bench.py's marginal-cost
  *            measurement; results are garbage; REFUSED unless the environment has THK_MEASURE_HOOKS=1)
- *   prefill: prefill_blocks_{qkv,wo,w13,w2} (workgroups per GEMM launch, <= 256);
+ *   prefill: prefill_slab_tokens (256, default: up to 256 prompt tokens share one pass over the weights; 128 = the
+ *            four-token-tile kernels only); prefill_deferred_norm (1, default: RMSNorm's per-token scalar is applied on
+ *            the output side of the GEMM, two launches per layer fewer; 0 = norm -> image launches);
+ *            prefill_blocks_{qkv,wo,w13,w2} (workgroups per GEMM launch, <= 256; 0 = auto);
  *            prefill_tile_{...} (weight rows per workgroup, 128|256); prefill_attn_mfma;
  *            prefill_packed (default 1: the first prefill call makes tile images of the
  *            layer matrices for the GEMM's linear `nt` stream — a second copy of the layer
