@@ -45,10 +45,22 @@ __device__ __forceinline__ float wave_sum_prefill(float v) {
 #else
 #define THK_WTILE(RBL, CH) ((size_t)(RBL) * nchunks + (CH))
 #endif
+//   -DTHK_PF_NOREAD the 128-token loop never re-reads its fragments from LDS (it multiplies the first chunk's over and over): the loop without its ds_reads
+//   -DTHK_PF_NODMA  the 128-token loop issues no LDS-DMA behind the prologue's: the loop without its fill
 #ifdef THK_PF_NOLO
 constexpr bool kNoLo = true;
 #else
 constexpr bool kNoLo = false;
+#endif
+#ifdef THK_PF_NOREAD
+constexpr bool kNoRead = true;
+#else
+constexpr bool kNoRead = false;
+#endif
+#ifdef THK_PF_NODMA
+constexpr bool kNoDma = true;
+#else
+constexpr bool kNoDma = false;
 #endif
 constexpr int kKC = 32;                  // K columns per LDS stage (2 MFMA k-steps)
 
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
             __builtin_amdgcn_sched_barrier(0);                                                                         \
             if (i < SYNC_AT) {                                                                                         \
                 _Pragma("unroll") for (int k = LT + i * LH / (SYNC_AT > 0 ? SYNC_AT : 1); k < LT + (i + 1) * LH / (SYNC_AT > 0 ? SYNC_AT : 1); ++k)            \
-                    v3_issue_one<MT, NF, PK>(k, pend_more, ximg, scratch, pend_sb, pend_xs, pend_w, pend_row0, R, C, wave);     \
+                    if (!kNoDma) v3_issue_one<MT, NF, PK>(k, pend_more, ximg, scratch, pend_sb, pend_xs, pend_w, pend_row0, R, C, wave);     \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
             }                                                                                                          \
             if (i == SYNC_AT) {                                                                                        \
@@ -303,11 +315,11 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
             }                                                                                                          \
             if (i >= SYNC_AT && i < NM - 1) {                                                                          \
                 const int sl = i - SYNC_AT;                    /* behind the last chunk these reads fetch stale bytes nobody uses */ \
-                if (sl < RSLOTS) { _Pragma("unroll") for (int rr = sl * NR / RSLOTS; rr < (sl + 1) * NR / RSLOTS; ++rr) THK_READ_ONE(sbn, 1 - S, rr) } \
+                if (!kNoRead && sl < RSLOTS) { _Pragma("unroll") for (int rr = sl * NR / RSLOTS; rr < (sl + 1) * NR / RSLOTS; ++rr) THK_READ_ONE(sbn, 1 - S, rr) } \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
                 if (sl >= RSLOTS) {                                                                                    \
                     _Pragma("unroll") for (int k = (sl - RSLOTS) * LT / TSLOTS; k < (sl - RSLOTS + 1) * LT / TSLOTS; ++k) \
-                        v3_issue_one<MT, NF, PK>(k, more, ximg, scratch, nx_sb, nx_xs, nx_w, nx_row0, R, C, wave);              \
+                        if (!kNoDma) v3_issue_one<MT, NF, PK>(k, more, ximg, scratch, nx_sb, nx_xs, nx_w, nx_row0, R, C, wave);              \
                 }                                                                                                      \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
             }                                                                                                          \
@@ -333,6 +345,10 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int rr = 0; rr < NR; ++rr) THK_READ_ONE(lds, 0, rr)
+    if (kNoRead) {
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) THK_READ_ONE(lds, 1, rr)
+    }
     for (int g = g0;;) {
         THK_STEP(0)
         if (++g >= g1) break;
