@@ -419,6 +419,32 @@ def test_prefill_in_slabs_of_128(thk, ctx, M, n_past):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("M,n_past", [(127, 0), (128, 1), (255, 0), (256, 30), (257, 0), (384, 17), (385, 0), (512, 5)])
+def test_prefill_slab_edges_vs_oracle(thk, orc, ctx, M, n_past):
+    """Prompt lengths on both sides of every slab edge (one short of a slab, exactly one, one more; 256 + 128, 256 + 129, two full slabs), alone and behind
+    rows a decode step wrote, against the ORACLE fed token by token: the last prompt position's logits, then two decode steps on the cache the slabs filled
+    (a wrong K/V row, pad-tile leak or image offset at an edge would show there)."""
+    shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=576)
+    oshape = orc.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=576)
+    m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+    om = orc.OracleModel(oshape); om.fill_synthetic()
+    rng = np.random.default_rng(7 * M + n_past)
+    toks = np.concatenate([[1], rng.integers(3, 2048, n_past + M + 2)]).astype(np.int32)
+    if n_past:
+        m.eval(toks[:n_past], 0, want_logits=False)
+    lp = m.prefill(toks[n_past:n_past + M], n_past)
+    lo = None
+    for i in range(n_past + M):
+        lo, _ = om.eval(int(toks[i]), i, want_logits=(i == n_past + M - 1))
+    assert np.abs(lp - lo).max() < LOGIT_TOL, (M, n_past, float(np.abs(lp - lo).max()))
+    assert int(lp.argmax()) == orc.greedy(lo)
+    for i in (n_past + M, n_past + M + 1):
+        lg, _ = m.eval([int(toks[i])], i); lo, _ = om.eval(int(toks[i]), i)
+        assert np.abs(lg - lo).max() < LOGIT_TOL, (M, n_past, i)
+        assert int(lg.argmax()) == orc.greedy(lo)
+    m.close(); om.close()
+
+
 def test_context_beyond_512(thk, orc, ctx):
     """n_ctx is a parameter, not the reference's compile-time 512 (th-llama.hpp:105): 1100 prompt tokens through the
     slab prefill, then decode steps at T > 1100, against the oracle fed token by token."""
