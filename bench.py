@@ -71,6 +71,8 @@ def parse():
                    help="PLUMBING CHECK on a one-GPU box: all N ranks use cuda:0 and the process group runs over gloo (RCCL cannot place two ranks on "
                         "one GPU), so the whole N>1 flow - stage models, transport choice with the hand-off pattern check (peer | torch), ring, "
                         "timing protocol, JSON line - runs with real HipStages in N processes; the line is marked and its value is not a scaling number")
+    p.add_argument("--setup-timeout-s", type=float, default=180.0,
+                   help="N > 1: a transport whose set-up call (communicator bootstrap, IPC mapping) has not returned after this long counts as failed and the next one is tried")
     p.add_argument("--watchdog-s", type=float, default=900.0,
                    help="N>1: a rank whose warm-up + timed region + drain does not finish in this many seconds reports and exits 3 (a dead peer must not hang the node)")
     p.add_argument("--kv", default="f32", choices=["f32", "f16"],
@@ -504,6 +506,27 @@ def choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, log_li
 
     ctl = dev if ctl is None else ctl
 
+    def bounded(fn, seconds, what):
+        """fn() on a helper thread, given up on after `seconds`: a communicator bootstrap that never returns (a fabric the library cannot use) must cost
+        this transport, not the run - the caller reports failure, every rank agrees, and the next transport is tried.  The stuck thread is left behind."""
+        import threading
+        box = {}
+
+        def body():
+            try:
+                if torch.cuda.is_available():
+                    torch.cuda.set_device(dev)
+                box["v"] = fn()
+            except BaseException as e:       # noqa: BLE001 - handed to the caller
+                box["e"] = e
+        t = threading.Thread(target=body, daemon=True)
+        t.start(); t.join(seconds)
+        if t.is_alive():
+            raise TimeoutError(f"{what} did not return within {seconds:.0f} s")
+        if "e" in box:
+            raise box["e"]
+        return box.get("v")
+
     def agree(ok):
         flag = torch.tensor([1 if ok else 0], device=ctl, dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -531,7 +554,8 @@ def choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, log_li
                 dist.broadcast(uid, 0)
                 if agree(ok):                         # agree BEFORE the collective ncclCommInitRank inside thk_pp_create
                     torch.cuda.synchronize(dev)
-                    stage.attach_native_transport(rank, N, bytes(uid.cpu().numpy().tobytes()))
+                    uid_bytes = bytes(uid.cpu().numpy().tobytes())
+                    bounded(lambda: stage.attach_native_transport(rank, N, uid_bytes), args.setup_timeout_s, "ncclCommInitRank (thk_pp_create)")
                 else:
                     ok = False
             elif kind == "peer":
@@ -542,7 +566,7 @@ def choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, log_li
                     mine, ok, why = None, False, f"thk_peer_create/export: {e}"
                 dist.all_gather_object(handles, mine)
                 if all(h is not None for h in handles):
-                    stage.connect_peer(handles[(rank + 1) % N] if N > 1 else None)
+                    bounded(lambda: stage.connect_peer(handles[(rank + 1) % N] if N > 1 else None), args.setup_timeout_s, "thk_peer_connect (hipIpcOpenMemHandle)")
                     kind_mem = int(ctx.lib.thk_peer_memory_kind(stage.peer))
                     if kind_mem == 0 and N > 1:
                         ok, why = False, "the mailbox could only be allocated coarse-grained: not safe across GPUs"
@@ -555,7 +579,10 @@ def choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, log_li
             teardown()
             continue
         try:
-            rep = drv.validate_handoff(reps=16, sync=lambda: torch.cuda.synchronize(dev), fence=lambda: agree(True))   # fence: the mailbox has no back-pressure of its own
+            from token_hawk_amd.pipeline import Watchdog
+            # a hand-off that never completes leaves the device stream blocked: nothing to fall back to, so fail fast (exit 3) instead of hanging the node
+            with Watchdog(args.watchdog_s, f"rank {rank}: hand-off validation on the '{kind}' transport"):
+                rep = drv.validate_handoff(reps=16, sync=lambda: torch.cuda.synchronize(dev), fence=lambda: agree(True))   # fence: the mailbox has no back-pressure of its own
             if getattr(stage, "peer", None) is not None:
                 stage.peer_check()
             ok, why = rep.ok, "; ".join(rep.errors[:2])
@@ -771,13 +798,16 @@ def main():
             model.seq_set(0, int(prompts[T - 1, 0]), T - 1)
             drv = None
         else:
-            for s in range(S):
-                stage.set_seq(s, int(prompts[0, s]), 0)
-            if T > 1:
-                drv.run(T - 1, advance=True, forced_tokens=prompts[:T - 1])
-            if rank == 0:
+            from token_hawk_amd.pipeline import Watchdog
+            with Watchdog(args.watchdog_s, f"rank {rank}: pipelined KV fill ({T - 1} ring steps)"):
                 for s in range(S):
-                    stage.set_token(s, int(prompts[T - 1, s]))
+                    stage.set_seq(s, int(prompts[0, s]), 0)
+                if T > 1:
+                    drv.run(T - 1, advance=True, forced_tokens=prompts[:T - 1])
+                if rank == 0:
+                    for s in range(S):
+                        stage.set_token(s, int(prompts[T - 1, s]))
+                ctx.sync()
         ctx.sync()
         log(f"[bench r{rank}] KV filled to n_past={T - 1} in {time.time() - t_fill:.2f}s")
 
