@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""dev: where a prefill GEMM wave spends its cycles.  Needs libthk.so built with -DTHK_PREFILL_TRACE
-(tools/dev/call_pftrace.sh does that).  Runs ONE layer-shaped GEMM per kind through thk_gemm_f16_prefill and prints the
-per-wave mean of each phase in cycles."""
+"""dev: where a prefill GEMM wave spends its cycles.  Needs a libthk built with -DTHK_PREFILL_TRACE:
+    python -c "import __graft_entry__ as g; g.build_libthk(out='token-hawk_amd/libthk_pftrace.so', defs=('THK_PREFILL_TRACE=1',))"
+    THK_LIB=$PWD/token-hawk_amd/libthk_pftrace.so python tools/dev/prefill_trace.py [tunable=value ...]
+Runs a 128-token prompt through a ONE-layer 7B-width model (four GEMM launches: wq|wk|wv, wo, w1|w3, w2) and prints, per launch, the per-wave mean of each
+phase of the main loop in shader cycles, and when the waves started / ended on the 100 MHz chip clock."""
 import ctypes, sys, os
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
