@@ -144,19 +144,27 @@ def parity_check(model, om, orc, prompt, T, budget_s=75.0):
     out = {"tolerance": 1e-3, "reference": "oracle fast flavour (CPU restatement of th_eval_gpu, th-llama.cpp:464-660), same seeded weights and prompt"}
     PF = 128                                                             # config C3: the first 128 tokens through the MFMA prefill path, checked at position 127
     walk_to = T - 1 if (T - 1 >= early and (T - 1 - early) * dt * 0.9 < budget_s) else (PF - 1 if (T > PF and (PF - 1 - early) * dt * 0.9 < budget_s) else early - 1)
-    lo_pf = None
+    # round 6: the whole (T-1)-token prompt through the slab path too (T = 512: one 256-token slab + a 255-token pad-tile slab of gemm_prefill_v3h_kernel,
+    # the kernels behind extras.prefill_128.prompt_512_tokens_ms), checked at its last position T-2
+    PL = T - 1 if (T - 1 > 256 and walk_to == T - 1) else 0
+    lo_pf = lo_pl = None
     for i in range(early, min(walk_to, T - 2) + 1):                      # the oracle walks the prompt once; the early evals carried the logits head, cache-fill evals do not
         if i == PF - 1 and T > PF:
             lo_pf, _ = om.eval(int(prompt[i]), i, flags=0)
+        elif PL and i == PL - 1:
+            lo_pl, _ = om.eval(int(prompt[i]), i, flags=0)
         else:
             om.eval(int(prompt[i]), i, want_logits=False, flags=0)
-    if lo_pf is not None:
+    for n, want in ((PF, lo_pf), (PL, lo_pl)):
+        if want is None:
+            continue
         try:
-            lp = model.prefill(prompt[:PF], 0)                           # rows 0..127 of sequence 0 rewritten by the prefill path
-            per["prefill_%d" % (PF - 1)] = float(np.abs(lp - lo_pf).max())
-            greedy_equal = greedy_equal and int(lp.argmax()) == orc.greedy(lo_pf)
+            model.reset_kv(0)
+            lp = model.prefill(prompt[:n], 0)                            # rows 0..n-1 of sequence 0 rewritten by the prefill path
+            per["prefill_%d" % (n - 1)] = float(np.abs(lp - want).max())
+            greedy_equal = greedy_equal and int(lp.argmax()) == orc.greedy(want)
         except Exception as e:                                           # a report item: the decode positions are still checked
-            out["prefill_note"] = f"prefill check failed to run: {e}"
+            out["prefill_note"] = f"prefill check ({n} tokens) failed to run: {e}"
     if walk_to == T - 1:
         if T - 1 > 0:
             model.eval(prompt[:T - 1], 0, want_logits=False)             # every row again through the decode path (the prefill check wrote its own)

@@ -14,6 +14,10 @@ pytestmark = pytest.mark.gpu
 
 LOGIT_TOL = 1e-3   # north_star: logits within 1e-3
 PREFILL_TOKENS = 128   # BASELINE config C3
+# prompt lengths pushed through thk_model_prefill and compared with the ORACLE at their last position: 128 = config C3 (one 128-token slab,
+# gemm_prefill_v3_kernel), 256 = one full 256-token slab (gemm_prefill_v3h_kernel + the slab attention), 511 = 256 + 255 (the pad-tile
+# path of the second slab, attention over cached rows of the first) = the prompt behind bench.py's prompt_512_tokens_ms
+PREFILL_LENGTHS = (PREFILL_TOKENS, 256, 511)
 
 
 def _mem_available():
@@ -72,26 +76,32 @@ def _full_depth(thk, orc, ctx, name, early, T):
         mf.close(); mf = None
         # the rest of the prompt: n_past = early .. T-2 (the cache fill bench.py does), then the timed position n_past = T-1
         m.eval(prompt[early:T - 1], early, want_logits=False)
-        lo_pf = ho_pf = None
+        want = {}
         for i in range(early, T - 1):
-            if i == PREFILL_TOKENS - 1:
-                lo_pf, ho_pf = om.eval(int(prompt[i]), i, flags=0)       # what a 128-token prefill must reproduce
+            if i + 1 in PREFILL_LENGTHS:
+                want[i + 1] = om.eval(int(prompt[i]), i, flags=0)        # what a prefill of i + 1 tokens must reproduce
             else:
                 om.eval(int(prompt[i]), i, want_logits=False, flags=0)
         # config C3 at full depth against the ORACLE (not against the HIP decode path): the first 128 tokens of the very prompt through
         # the MFMA prefill path (stream-K GEMMs + reducers, MFMA attention) on a second HIP model - logits and the final
         # hidden state at position 127 (semantics th-llama.cpp:464-660 with the batch branch :307-311)
+        # round 6: the 256-token slab path (the default for every prompt > 128 tokens) against the oracle at the same widths and depth
         mp = thk.Model(ctx, shape); mp.fill_synthetic(); mp.finalize()
         try:
-            lp = mp.prefill(prompt[:PREFILL_TOKENS], 0)
-            hp = mp.debug_buffer("x")
+            for n in PREFILL_LENGTHS:
+                if n > T - 1:
+                    continue
+                mp.reset_kv(0)
+                lp = mp.prefill(prompt[:n], 0)
+                hp = mp.debug_buffer("x")
+                lo_pf, ho_pf = want[n]
+                dpl, dph = float(np.abs(lp - lo_pf).max()), float(np.abs(hp - ho_pf).max())
+                print(f"\n[full-depth {name}] {n}-token prefill vs oracle at position {n - 1}: max |dlogit| {dpl:.3e} (hidden {dph:.3e})")
+                assert dpl < LOGIT_TOL, (name, "prefill", n, dpl)
+                assert dph < LOGIT_TOL * max(1.0, float(np.abs(ho_pf).max())), (name, "prefill", n, dph)
+                assert int(lp.argmax()) == orc.greedy(lo_pf), (name, "prefill", n)
         finally:
             mp.close()
-        dpl, dph = float(np.abs(lp - lo_pf).max()), float(np.abs(hp - ho_pf).max())
-        print(f"\n[full-depth {name}] {PREFILL_TOKENS}-token prefill vs oracle at position {PREFILL_TOKENS - 1}: max |dlogit| {dpl:.3e} (hidden {dph:.3e})")
-        assert dpl < LOGIT_TOL, (name, "prefill", dpl)
-        assert dph < LOGIT_TOL * max(1.0, float(np.abs(ho_pf).max())), (name, "prefill", dph)
-        assert int(lp.argmax()) == orc.greedy(lo_pf)
         lg, hid = m.eval([int(prompt[T - 1])], T - 1, want_hidden=True)
         lo, ho = om.eval(int(prompt[T - 1]), T - 1, flags=0)
         dl, dh = float(np.abs(lg - lo).max()), float(np.abs(hid - ho).max())

@@ -419,13 +419,19 @@ def test_prefill_in_slabs_of_128(thk, ctx, M, n_past):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("M,n_past", [(127, 0), (128, 1), (255, 0), (256, 30), (257, 0), (384, 17), (385, 0), (512, 5)])
-def test_prefill_slab_edges_vs_oracle(thk, orc, ctx, M, n_past):
+# tiny width: every slab edge; 7B / 13B width (round 6: the 4096 | 11008 and 5120 | 13824 column classes of gemm_prefill_v3h_kernel and the D = 128 slab
+# attention, two layers): one full slab, slab + pad-tile slab behind decode-written rows, the 511-token prompt of bench.py's prompt_512_tokens_ms
+_SLAB_EDGE_CASES = [(512, 8, M, n_past) for M, n_past in [(127, 0), (128, 1), (255, 0), (256, 30), (257, 0), (384, 17), (385, 0), (512, 5)]] \
+    + [(4096, 32, 256, 0), (4096, 32, 257, 30), (4096, 32, 511, 0), (5120, 40, 256, 0), (5120, 40, 300, 9)]
+
+
+@pytest.mark.parametrize("E,H,M,n_past", _SLAB_EDGE_CASES)
+def test_prefill_slab_edges_vs_oracle(thk, orc, ctx, E, H, M, n_past):
     """Prompt lengths on both sides of every slab edge (one short of a slab, exactly one, one more; 256 + 128, 256 + 129, two full slabs), alone and behind
     rows a decode step wrote, against the ORACLE fed token by token: the last prompt position's logits, then two decode steps on the cache the slabs filled
-    (a wrong K/V row, pad-tile leak or image offset at an edge would show there)."""
-    shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=576)
-    oshape = orc.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=576)
+    (a wrong K/V row, pad-tile leak or image offset at an edge would show there).  Semantics: th-llama.cpp:464-660 with the batch branch :305-311."""
+    shape = thk.ModelShape(n_vocab=2048, n_embd=E, n_mult=256, n_head=H, n_layer=2, n_ctx=576)
+    oshape = orc.ModelShape(n_vocab=2048, n_embd=E, n_mult=256, n_head=H, n_layer=2, n_ctx=576)
     m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
     om = orc.OracleModel(oshape); om.fill_synthetic()
     rng = np.random.default_rng(7 * M + n_past)
