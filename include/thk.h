@@ -178,6 +178,7 @@ int thk_model_create(thk_ctx* ctx, const thk_hparams* hp, int32_t layer_begin, i
 int thk_model_destroy(thk_model* m);
 int32_t thk_model_n_ff(const thk_model* m);
 int32_t thk_model_n_embd(const thk_model* m);
+int32_t thk_model_n_ctx(const thk_model* m);
 
 /* Called by the GGML loader in file order (replaces load_weights' TensorBuffer
  * upload, th-llama-loader.cpp:121-265).  name is the ggjt tensor name; ne0 = columns
@@ -209,10 +210,23 @@ int thk_model_eval(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_t
                    float* hidden_inout, float* logits_out);
 
 /* Batched prompt prefill (config C3) through the MFMA GEMM path: same contract as
- * thk_model_eval with n_past == 0..; full-model stages only.  The first call builds the
- * weight tile images (tunable prefill_packed) and the workspace; later calls reuse them. */
+ * thk_model_eval with n_past == 0..; full-model stages (pipeline stages: thk_model_prefill_stage
+ * below).  The first call builds the weight tile images (tunable prefill_packed) and the
+ * workspace; later calls reuse them. */
 int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past,
                       float* logits_out);
+/* The same pass for ONE pipeline stage (config C3 x C4): this stage's layers [layer_begin, layer_end) over the prompt rows, so that an
+ * N-GPU pipeline ingests a prompt with one MFMA pass per stage instead of n_tokens ring revolutions.  The reference's batch branch is
+ * per layer (th-llama.cpp:305-311, :365-404) - nothing in it needs the whole model.  hidden_dev is a caller-owned DEVICE buffer of
+ * f32 [n_tokens, n_embd] (thk_buf_alloc, or the target of thk_pp_recv / thk_peer_recv_bulk), used in place:
+ *   embedding stage: tokens (host int32[n_tokens]) are the input, hidden_dev is only written;
+ *   other stages   : rows [0, n_tokens) of hidden_dev are the input (tokens may be NULL);
+ *   non-head stage : the rows are replaced by this stage's output (the next stage's input);
+ *   head stage     : logits_out (host f32[n_vocab], may be NULL) receives the last token's logits.
+ * A full-model stage may pass hidden_dev = NULL (then this IS thk_model_prefill).  Stream-ordered: the call blocks only for the token
+ * upload of an embedding stage and for the logits read-back; thk_pp_send / thk_peer_send_bulk behind it are ordered on the stream. */
+int thk_model_prefill_stage(thk_model* m, int32_t seq, const int32_t* tokens, float* hidden_dev, int32_t n_tokens, int32_t n_past,
+                            float* logits_out);
 /* The prefill GEMMs stream "tile images" of the layer matrices: a second copy of this stage's layer weights in HBM (12.4 GB for
  * 7B), built by the first thk_model_prefill call unless this call built it earlier - so that the time and the memory are paid
  * when the embedder chooses.  Returns THK_ERR_OOM (thk_last_error explains) when the copy does not fit; prefill then still works
@@ -320,7 +334,7 @@ int thk_pp_recv_token(thk_pp* pp, thk_model* m, int32_t seq, int peer);
  * No reference counterpart (the reference is single-device). */
 typedef struct thk_peer thk_peer;
 #define THK_PEER_HANDLE_BYTES 64
-enum { THK_PEER_HIDDEN = 0, THK_PEER_TOKEN = 1 };
+enum { THK_PEER_HIDDEN = 0, THK_PEER_TOKEN = 1, THK_PEER_BULK = 2 /* thk_peer_send_bulk / _recv_bulk only */ };
 /* how the mailbox was allocated: uncached / fine-grained device memory is visible to a polling kernel while ANOTHER GPU writes it;
  * coarse-grained (plain hipMalloc: the fallback when the runtime cannot allocate or IPC-export the others) only guarantees that
  * at dispatch boundaries, i.e. it is safe for rings inside one GPU only */
@@ -330,6 +344,11 @@ int thk_peer_export(thk_peer* p, void* handle_out64);
 int thk_peer_connect(thk_peer* p, const void* next_handle64);
 int thk_peer_send(thk_peer* p, int32_t seq, int kind);   /* kind: THK_PEER_HIDDEN (thk_model_hidden_out) | THK_PEER_TOKEN (thk_model_token_dev) */
 int thk_peer_recv(thk_peer* p, int32_t seq, int kind);   /* into thk_model_hidden_in | thk_model_token_dev */
+/* Bulk hand-off (round 6): `bytes` of a caller-owned device buffer - the f32 [n_tokens, n_embd] rows thk_model_prefill_stage leaves for the
+ * next stage - through the sequence's bulk slot of the mailbox (capacity n_ctx * n_embd * 4 bytes per sequence; bytes % 16 == 0).  A slot
+ * holds ONE payload: send the same sequence's next prompt only after the consumer has taken this one (synchronise + fence across ranks). */
+int thk_peer_send_bulk(thk_peer* p, int32_t seq, const void* src_dev, size_t bytes);
+int thk_peer_recv_bulk(thk_peer* p, int32_t seq, void* dst_dev, size_t bytes);
 int thk_peer_check(thk_peer* p);                         /* THK_ERR_STATE once a wait has timed out: sticky - send / recv refuse from then on, destroy and recreate */
 int thk_peer_memory_kind(const thk_peer* p);             /* THK_PEER_MEM_* of this stage's mailbox */
 int thk_peer_destroy(thk_peer* p);

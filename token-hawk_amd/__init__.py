@@ -307,6 +307,15 @@ class Model:
                                                       None if logits is None else logits.ctypes.data), "thk_model_prefill")
         return logits
 
+    def prefill_stage(self, tokens, hidden, n_tokens: int, n_past: int = 0, *, seq: int = 0, want_logits: bool = False):
+        """thk_model_prefill_stage: this stage's layers over the prompt rows; hidden = device buffer f32 [n_tokens, n_embd] (Buffer or address),
+        used in place (input unless this is the embedding stage, output unless this is the head stage)."""
+        toks = None if tokens is None else np.ascontiguousarray(tokens, np.int32)
+        logits = np.empty(self.shape.n_vocab, np.float32) if want_logits else None
+        self.ctx.check(self.ctx.lib.thk_model_prefill_stage(self.h, seq, None if toks is None else toks.ctypes.data, _ptr(hidden) or None, n_tokens, n_past,
+                                                            None if logits is None else logits.ctypes.data), "thk_model_prefill_stage")
+        return logits
+
     def eval_topk(self, tokens, n_past: int, k: int, seq: int = 0):
         """thk_model_eval_topk: the step(s) and the k largest logits of the last token in one stream round trip -> (values, ids), value descending."""
         toks = np.ascontiguousarray(tokens, np.int32)

@@ -73,6 +73,7 @@ SIGNATURES = {
     "thk_model_set_lmhead_mode": (C.c_int, [vp, C.c_int]),
     "thk_model_eval": (C.c_int, [vp, i32, vp, i32, i32, vp, vp]),
     "thk_model_prefill": (C.c_int, [vp, i32, vp, i32, i32, vp]),
+    "thk_model_prefill_stage": (C.c_int, [vp, i32, vp, vp, i32, i32, vp]),
     "thk_model_prepare_prefill": (C.c_int, [vp]),
     "thk_model_prefill_uses_tile_images": (C.c_int, [vp]),
     "thk_model_seq_set": (C.c_int, [vp, i32, i32, i32]),
@@ -97,6 +98,7 @@ SIGNATURES = {
     "thk_model_profile_step": (C.c_int, [vp, i32, i32, vp, vp, C.POINTER(i32)]),
     "thk_model_step_trace": (C.c_int, [vp, i32, vp, i64, i32, vp, C.POINTER(i32), C.POINTER(i32)]),
     "thk_model_n_embd": (i32, [vp]),
+    "thk_model_n_ctx": (i32, [vp]),
     "thk_pp_get_unique_id": (C.c_int, [vp]),
     "thk_pp_create": (C.c_int, [vp, C.c_int, C.c_int, vp, pp]),
     "thk_pp_destroy": (C.c_int, [vp]),
@@ -115,6 +117,8 @@ SIGNATURES = {
     "thk_peer_connect": (C.c_int, [vp, vp]),
     "thk_peer_send": (C.c_int, [vp, i32, C.c_int]),
     "thk_peer_recv": (C.c_int, [vp, i32, C.c_int]),
+    "thk_peer_send_bulk": (C.c_int, [vp, i32, vp, C.c_size_t]),
+    "thk_peer_recv_bulk": (C.c_int, [vp, i32, vp, C.c_size_t]),
     "thk_peer_check": (C.c_int, [vp]),
     "thk_peer_memory_kind": (C.c_int, [vp]),
     "thk_peer_destroy": (C.c_int, [vp]),

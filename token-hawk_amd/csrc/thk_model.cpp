@@ -109,6 +109,7 @@ extern "C" int thk_model_destroy(thk_model* m) {
 extern "C" int thk_model_uses_engine(const thk_model* m) { return (m && m->finalized && m->engine) ? 1 : 0; }
 extern "C" int32_t thk_model_n_ff(const thk_model* m) { return m ? m->n_ff : 0; }
 extern "C" int32_t thk_model_n_embd(const thk_model* m) { return m ? m->hp.n_embd : 0; }
+extern "C" int32_t thk_model_n_ctx(const thk_model* m) { return m ? m->hp.n_ctx : 0; }
 
 // name -> device slot; returns 0 ok, 1 = tensor belongs to another stage (ignored), <0 error
 static int tensor_slot(thk_model* m, const char* name, void** dst, int64_t* ne0, int64_t* ne1, int* dtype) {

@@ -125,7 +125,6 @@ extern "C" int thk_model_prepare_prefill(thk_model* m) {
     if (!m) return THK_ERR_INVALID;
     thk_ctx* ctx = m->ctx;
     REQUIRE(ctx, m->finalized, "thk_model_prepare_prefill before thk_model_finalize");
-    REQUIRE(ctx, (m->flags & THK_STAGE_EMBED) && (m->flags & THK_STAGE_HEAD), "thk_model_prepare_prefill needs a full-model stage (embedding + head)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PrefillBufs b{};
     int rc = prefill_workspace(m, &b);
@@ -138,7 +137,9 @@ extern "C" int thk_model_prepare_prefill(thk_model* m) {
 extern "C" int thk_model_prefill_uses_tile_images(const thk_model* m) { return (m && m->prefill_pk && !m->pk_w.empty() && !m->pk_failed) ? 1 : 0; }
 
 // one slab of M <= 256 prompt tokens at positions [n_past, n_past + M) through every layer
-static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const int32_t* tokens, int M, int n_past) {
+// hidden (device f32 [M, E], may be null on a full-model stage): the slab's rows of the stage hand-off buffer - read as the stage input when this
+// stage has no embedding table, written with the stage output when it has no head (in place: a stage turns its input rows into its output rows)
+static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const int32_t* tokens, float* hidden, int M, int n_past) {
     thk_ctx* ctx = m->ctx;
     hipStream_t st = ctx->stream;
     const int E = m->hp.n_embd, H = m->hp.n_head, D = E / H, F = m->n_ff, T = m->hp.n_ctx;
@@ -150,9 +151,13 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
     PrefillPlan &pq = pl[0], &po = pl[1], &p13 = pl[2], &p2 = pl[3];
     const bool pk = !m->pk_w.empty() && m->pk_tiles[0] == pq.tile_rows && m->pk_tiles[1] == po.tile_rows && m->pk_tiles[2] == p13.tile_rows && m->pk_tiles[3] == p2.tile_rows;
     pq.packed = po.packed = p13.packed = p2.packed = pk ? 1 : 0;
-    HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));   // tokens may be a stack buffer
-    HIPCHK(ctx, launch_embed_rows(m->tok_embeddings, b.tok, M, E, b.X, st));
+    if (m->flags & THK_STAGE_EMBED) {
+        HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));   // tokens may be a stack buffer
+        HIPCHK(ctx, launch_embed_rows(m->tok_embeddings, b.tok, M, E, b.X, st));
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(b.X, hidden, (size_t)M * E * 4, hipMemcpyDeviceToDevice, st));     // the previous stage's output rows (th-llama.cpp:305-311 is per layer: nothing ties the batch branch to a whole model)
+    }
     const int nl = m->l1 - m->l0;
     const bool defer = tun(ctx, "prefill_deferred_norm") != 0;
     if (defer) HIPCHK(ctx, hipMemsetAsync(b.ssq, 0, b.ssq_bytes, st));
@@ -194,18 +199,24 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
         if (defer && i + 1 < nl) HIPCHK(ctx, launch_prefill_reduce_resid_ximg(b.part, p2, b.X, m->layers[i + 1].attention_norm, b.imgE, ssq_of(i + 1, 0), ssq_of(i, 1), st));
         else HIPCHK(ctx, launch_prefill_reduce_store(b.part, p2, b.X, true, st));
     }
+    if (hidden && !(m->flags & THK_STAGE_HEAD)) HIPCHK(ctx, hipMemcpyAsync(hidden, b.X, (size_t)M * E * 4, hipMemcpyDeviceToDevice, st));
     return THK_OK;
 }
 
-extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past, float* logits_out) {
+// The prompt pass of ONE pipeline stage (config C3 x C4): this stage's layers [layer_begin, layer_end) over the n_tokens prompt rows, slab by slab.
+// The batch branch of the reference is per layer (th-llama.cpp:305-311, :365-404), so a contiguous layer range is as good a unit as the whole model.
+static int prefill_stage(thk_model* m, int32_t seq, const int32_t* tokens, float* hidden_dev, int32_t n_tokens, int32_t n_past, float* logits_out, const char* who) {
     if (!m) return THK_ERR_INVALID;
     thk_ctx* ctx = m->ctx;
-    REQUIRE(ctx, m->finalized, "thk_model_prefill before thk_model_finalize");
-    REQUIRE(ctx, (m->flags & THK_STAGE_EMBED) && (m->flags & THK_STAGE_HEAD), "thk_model_prefill needs a full-model stage (embedding + head)");
-    REQUIRE(ctx, seq >= 0 && seq < m->n_seq && tokens, "bad sequence %d / null tokens", seq);
+    const bool embed = m->flags & THK_STAGE_EMBED, head = m->flags & THK_STAGE_HEAD;
+    REQUIRE(ctx, m->finalized, "%s before thk_model_finalize", who);
+    REQUIRE(ctx, seq >= 0 && seq < m->n_seq, "bad sequence %d", seq);
+    REQUIRE(ctx, !embed || tokens, "%s: an embedding stage needs token ids", who);
+    REQUIRE(ctx, (embed && head) || hidden_dev, "%s: a stage without the embedding table reads its input rows from hidden_dev, a stage without the head leaves its output rows there", who);
+    REQUIRE(ctx, !logits_out || head, "%s: logits requested from a stage without the lm-head", who);
     REQUIRE(ctx, n_tokens >= 1 && n_past >= 0 && n_past + n_tokens <= m->hp.n_ctx, "n_past=%d + n_tokens=%d exceeds n_ctx=%d", n_past, n_tokens, m->hp.n_ctx);
-    REQUIRE(ctx, m->hp.n_embd % 32 == 0 && m->n_ff % 32 == 0, "thk_model_prefill needs n_embd and n_ff to be multiples of 32");
-    for (int i = 0; i < n_tokens; ++i) REQUIRE(ctx, tokens[i] >= 0 && tokens[i] < m->hp.n_vocab, "token id %d out of range", tokens[i]);
+    REQUIRE(ctx, m->hp.n_embd % 32 == 0 && m->n_ff % 32 == 0, "%s needs n_embd and n_ff to be multiples of 32", who);
+    if (embed) for (int i = 0; i < n_tokens; ++i) REQUIRE(ctx, tokens[i] >= 0 && tokens[i] < m->hp.n_vocab, "token id %d out of range", tokens[i]);
     HIPCHK(ctx, hipSetDevice(ctx->device));
     PrefillBufs b{};
     int rc = prefill_workspace(m, &b);
@@ -219,9 +230,9 @@ extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* token
     for (int m0 = 0; m0 < M; m0 += last) {    // slabs of <= 256 tokens (one weight pass each); later slabs attend to the rows earlier ones cached
         const int left = M - m0;
         last = left > 128 ? std::min(SL, left) : left;       // 129 .. 256 tokens left: ONE eight-tile pass (pad tiles are cheaper than a second weight pass)
-        if ((rc = prefill_slab(m, sb, b, tokens + m0, last, n_past + m0)) != THK_OK) return rc;
+        if ((rc = prefill_slab(m, sb, b, embed ? tokens + m0 : nullptr, hidden_dev ? hidden_dev + (size_t)m0 * E : nullptr, last, n_past + m0)) != THK_OK) return rc;
     }
-    {   // final norm + lm-head on the last token only (th-llama.cpp:253-262, aOffset = (r-1)*c)
+    if (head) {   // final norm + lm-head on the last token only (th-llama.cpp:253-262, aOffset = (r-1)*c)
         GemvArgs a{};
         a.W[0] = m->output; a.R = V; a.C = E;
         const int NR = gemv_rows_per_group(E, GEMV_EPI_HEAD, m->var_head);
@@ -232,9 +243,19 @@ extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* token
         HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, m->nt != 0, st));
         HIPCHK(ctx, hipMemcpyAsync(m->x, b.X + (size_t)(last - 1) * E, (size_t)E * 4, hipMemcpyDeviceToDevice, st));
     }
-    rc = set_seq_state(m, seq, tokens[M - 1], n_past + M - 1, false);
+    rc = set_seq_state(m, seq, embed ? tokens[M - 1] : 0, n_past + M - 1, false);
     if (rc != THK_OK) return rc;
     if (logits_out) HIPCHK(ctx, hipMemcpyAsync(logits_out, sb.logits, (size_t)V * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (logits_out || (embed && head)) HIPCHK(ctx, hipStreamSynchronize(st));     // a stage call without read-back stays stream-ordered: the hand-off behind it is too
     return THK_OK;
+}
+
+extern "C" int thk_model_prefill(thk_model* m, int32_t seq, const int32_t* tokens, int32_t n_tokens, int32_t n_past, float* logits_out) {
+    if (!m) return THK_ERR_INVALID;
+    REQUIRE(m->ctx, (m->flags & THK_STAGE_EMBED) && (m->flags & THK_STAGE_HEAD), "thk_model_prefill needs a full-model stage (embedding + head); pipeline stages call thk_model_prefill_stage");
+    REQUIRE(m->ctx, tokens, "bad sequence %d / null tokens", seq);
+    return prefill_stage(m, seq, tokens, nullptr, n_tokens, n_past, logits_out, "thk_model_prefill");
+}
+extern "C" int thk_model_prefill_stage(thk_model* m, int32_t seq, const int32_t* tokens, float* hidden_dev, int32_t n_tokens, int32_t n_past, float* logits_out) {
+    return prefill_stage(m, seq, tokens, hidden_dev, n_tokens, n_past, logits_out, "thk_model_prefill_stage");
 }

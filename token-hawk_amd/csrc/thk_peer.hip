@@ -25,11 +25,17 @@
 //     this GPU's kernel polls it, and HIP only guarantees cross-agent visibility of ordinary (coarse-grained) allocations at
 //     dispatch boundaries.  If neither flavour can be allocated AND exported over IPC the mailbox falls back to hipMalloc and
 //     thk_peer_memory_kind says so (then only same-GPU rings are safe - what tests/test_gpu_pipeline.py runs).
+//   * Bulk payloads (round 6: the [n_tokens, E] rows a stage's prompt pass hands to the next stage, thk_model_prefill_stage) have a slot of
+//     their own per sequence (n_ctx * E * 4 bytes) and a flag of their own: a wide copy kernel stores the rows into the next stage's slot,
+//     a one-thread kernel BEHIND it on the stream raises the flag (the end of the copy kernel is the release point for fine-grained memory);
+//     the consumer's one-workgroup wait kernel is followed by a wide copy out of its own mailbox.  Flow control: a sequence's bulk slot is
+//     written once per prompt; the caller synchronises + fences across ranks before the same sequence's next prompt (PipelineDriver.prefill).
 // Reference: none - the reference is single-device.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include "../../include/thk.h"
 
 struct thk_ctx;
@@ -77,6 +83,18 @@ __global__ __launch_bounds__(256) void peer_wait_kernel(const u64* slot, int n_w
     if (n_words == 0 && threadIdx.x == 0)
         *reinterpret_cast<unsigned*>(dst) = __hip_atomic_load(reinterpret_cast<const unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// bulk payload: 16-byte pieces, grid-stride; the flag travels in a kernel of its own behind this one
+__global__ __launch_bounds__(256) void peer_bulk_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+__global__ void peer_bulk_flag_kernel(u64* flag, u64* sent) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        __threadfence_system();
+        const u64 v = *sent + 1;
+        *sent = v;
+        __hip_atomic_store(flag, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 }  // namespace
 
 // Mailbox of one stage (exported): per sequence a hidden slot of E/2 words and a token slot of one word (padded to a line),
@@ -85,6 +103,7 @@ struct thk_peer {
     thk_ctx* ctx = nullptr;
     thk_model* model = nullptr;
     int n_seq = 1, hidden_words = 0;
+    size_t bulk_words = 0;       // per sequence: n_ctx * E / 2 (the rows of a whole prompt), line-rounded
     u64* box = nullptr;          // own mailbox (device)
     int box_kind = 0;            // THK_PEER_MEM_*: how it was allocated
     bool failed = false;         // a hand-off wait timed out (sticky)
@@ -95,7 +114,8 @@ struct thk_peer {
     unsigned* err = nullptr;
     size_t hidden_off(int s) const { return (size_t)s * hidden_words; }
     size_t token_off(int s) const { return (size_t)n_seq * hidden_words + (size_t)s * kLine; }
-    size_t flag_off(int s, int kind) const { return (size_t)n_seq * hidden_words + (size_t)n_seq * kLine + ((size_t)s * 2 + kind) * kLine; }
+    size_t flag_off(int s, int kind) const { return (size_t)n_seq * hidden_words + (size_t)n_seq * kLine + ((size_t)s * 3 + kind) * kLine; }
+    size_t bulk_off(int s) const { return flag_off(n_seq, 0) + (size_t)s * bulk_words; }      // behind the flags; 128-byte aligned
 };
 #define PEERCHK(p, call)                                                                                 \
     do {                                                                                                 \
@@ -111,7 +131,8 @@ extern "C" int thk_peer_create(thk_ctx* ctx, thk_model* stage, int32_t n_seq, th
     PEERCHK(ctx, hipSetDevice(thk::ctx_device(ctx)));
     thk_peer* p = new thk_peer();
     p->ctx = ctx; p->model = stage; p->n_seq = n_seq; p->hidden_words = (E / 2 + kLine - 1) / kLine * kLine;
-    p->box_words = p->flag_off(n_seq, 0);
+    p->bulk_words = ((size_t)thk_model_n_ctx(stage) * E / 2 + kLine - 1) / kLine * kLine;
+    p->box_words = p->bulk_off(n_seq);
     hipStream_t st = (hipStream_t)thk_ctx_stream(ctx);
     // its own allocation (the IPC handle covers exactly the mailbox), fine-grained if the runtime can allocate AND export that
     hipError_t e = hipErrorUnknown;
@@ -125,12 +146,12 @@ extern "C" int thk_peer_create(thk_ctx* ctx, thk_model* stage, int32_t n_seq, th
         break;
     }
     if (!p->box) { e = hipMalloc((void**)&p->box, p->box_words * 8); p->box_kind = THK_PEER_MEM_COARSE; }
-    if (e == hipSuccess) e = hipMalloc((void**)&p->counters, ((size_t)n_seq * 4 + 2) * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->counters, ((size_t)n_seq * 6 + 2) * 8);
     if (e == hipSuccess) e = hipMemsetAsync(p->box, 0, p->box_words * 8, st);
-    if (e == hipSuccess) e = hipMemsetAsync(p->counters, 0, ((size_t)n_seq * 4 + 2) * 8, st);
+    if (e == hipSuccess) e = hipMemsetAsync(p->counters, 0, ((size_t)n_seq * 6 + 2) * 8, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { hipFree(p->box); hipFree(p->counters); delete p; return thk::ctx_fail(ctx, THK_ERR_HIP, "thk_peer_create: mailbox allocation failed"); }
-    p->err = reinterpret_cast<unsigned*>(p->counters + (size_t)n_seq * 4);
+    p->err = reinterpret_cast<unsigned*>(p->counters + (size_t)n_seq * 6);
     *out = p;
     return THK_OK;
 }
@@ -163,7 +184,7 @@ static int peer_io(thk_peer* p, int32_t seq, int kind, bool send) {
     hipStream_t st = (hipStream_t)thk_ctx_stream(p->ctx);
     const int words = kind == THK_PEER_HIDDEN ? thk_model_n_embd(p->model) / 2 : 0;
     const size_t off = kind == THK_PEER_HIDDEN ? p->hidden_off(seq) : p->token_off(seq);
-    u64* cnt = p->counters + ((size_t)seq * 2 + kind) * 2;
+    u64* cnt = p->counters + ((size_t)seq * 3 + kind) * 2;
     if (send) {
         const void* src = kind == THK_PEER_HIDDEN ? thk_model_hidden_out(p->model, seq) : thk_model_token_dev(p->model, seq);
         hipLaunchKernelGGL(peer_push_kernel, dim3(1), dim3(256), 0, st, (const u64*)src, words, p->next_box + off, p->next_box + p->flag_off(seq, kind), cnt);
@@ -174,6 +195,29 @@ static int peer_io(thk_peer* p, int32_t seq, int kind, bool send) {
     PEERCHK(p->ctx, hipGetLastError());
     return THK_OK;
 }
+// bulk: bytes of a caller-owned device buffer (the [n_tokens, E] rows of thk_model_prefill_stage) through the sequence's bulk slot
+static int peer_bulk(thk_peer* p, int32_t seq, void* buf, size_t bytes, bool send) {
+    if (!p || !buf || seq < 0 || seq >= p->n_seq) return THK_ERR_INVALID;
+    if (bytes == 0 || (bytes & 15) || bytes > p->bulk_words * 8 || ((uintptr_t)buf & 15)) return thk::ctx_fail(p->ctx, THK_ERR_INVALID, "thk_peer bulk: bytes must be a multiple of 16, at most n_ctx * n_embd * 4, the buffer 16-byte aligned");
+    if (!p->next_box) return thk::ctx_fail(p->ctx, THK_ERR_STATE, "thk_peer: thk_peer_connect first");
+    if (p->failed) return thk::ctx_fail(p->ctx, THK_ERR_STATE, "thk_peer: a hand-off timed out earlier; the flag sequence is out of step - destroy this peer and create a new one");
+    PEERCHK(p->ctx, hipSetDevice(thk::ctx_device(p->ctx)));
+    hipStream_t st = (hipStream_t)thk_ctx_stream(p->ctx);
+    u64* cnt = p->counters + ((size_t)seq * 3 + THK_PEER_BULK) * 2;
+    const size_t n16 = bytes / 16;
+    const int grid = (int)std::min<size_t>(1024, (n16 + 255) / 256);
+    if (send) {
+        hipLaunchKernelGGL(peer_bulk_copy_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)buf, (uint4*)(p->next_box + p->bulk_off(seq)), n16);
+        hipLaunchKernelGGL(peer_bulk_flag_kernel, dim3(1), dim3(64), 0, st, p->next_box + p->flag_off(seq, THK_PEER_BULK), cnt);
+    } else {
+        hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(256), 0, st, (const u64*)nullptr, -1, (u64*)nullptr, (const u64*)(p->box + p->flag_off(seq, THK_PEER_BULK)), cnt + 1, p->err);
+        hipLaunchKernelGGL(peer_bulk_copy_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)(p->box + p->bulk_off(seq)), (uint4*)buf, n16);
+    }
+    PEERCHK(p->ctx, hipGetLastError());
+    return THK_OK;
+}
+extern "C" int thk_peer_send_bulk(thk_peer* p, int32_t seq, const void* src_dev, size_t bytes) { return peer_bulk(p, seq, const_cast<void*>(src_dev), bytes, true); }
+extern "C" int thk_peer_recv_bulk(thk_peer* p, int32_t seq, void* dst_dev, size_t bytes) { return peer_bulk(p, seq, dst_dev, bytes, false); }
 extern "C" int thk_peer_send(thk_peer* p, int32_t seq, int kind) { return peer_io(p, seq, kind, true); }
 extern "C" int thk_peer_recv(thk_peer* p, int32_t seq, int kind) { return peer_io(p, seq, kind, false); }
 // THK_ERR_STATE when a bounded wait gave up since the last check (the stream is synchronized first)
