@@ -42,8 +42,11 @@ def parse():
     p.add_argument("--warmup", type=int, default=20)
     p.add_argument("--model", default="7b", choices=["7b", "13b", "tiny", "tiny4"])     # tiny4: the tiny parity model with 4 layers (a 4-rank plumbing run)
     p.add_argument("--ctx", type=int, default=512, help="context length T of the timed steps")
-    p.add_argument("--kv-fill", default="prompt", choices=["prompt", "seeded"],
-                   help="prompt: run the 511-token synthetic prompt through the decode path; seeded: (N>1 default off)")
+    p.add_argument("--kv-fill", default="both", choices=["both", "prefill", "ring"],
+                   help="N>1 (pipeline path): how the (T-1)-token prompts reach the KV caches before the timed region.  ring: one ring revolution per prompt "
+                        "token through the decode path (rounds 1-5); prefill: ONE MFMA prompt pass per stage and sequence, the M x E rows handed forward as a "
+                        "bulk message (PipelineDriver.prefill, thk_model_prefill_stage); both (default): ring first, then the caches are cleared and refilled "
+                        "by the prefill pass - both times are reported (kv_fill) and the first greedy token of every sequence must agree")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-kernel-profile", action="store_true")
     p.add_argument("--no-parity-check", action="store_true",
@@ -820,17 +823,61 @@ def main():
             drv = None
         else:
             from token_hawk_amd.pipeline import Watchdog
-            with Watchdog(args.watchdog_s, f"rank {rank}: pipelined KV fill ({T - 1} ring steps)"):
-                for s in range(S):
-                    stage.set_seq(s, int(prompts[0, s]), 0)
-                if T > 1:
-                    drv.run(T - 1, advance=True, forced_tokens=prompts[:T - 1])
-                if rank == 0:
-                    for s in range(S):
-                        stage.set_token(s, int(prompts[T - 1, s]))
+            kv_fill = {}
+
+            def settle():                                  # every rank's stream drained AND every rank here: the bulk slots of the mailbox transport hold one payload
                 ctx.sync()
+                dist.barrier()
+
+            def first_pick():
+                """One hold-position step of every sequence at n_past = T-1 on the caches as they are -> the S greedy tokens (last rank; others None)."""
+                for s in range(S):
+                    stage.set_seq(s, int(prompts[T - 1, s]), T - 1)
+                drv.run(1, advance=False)
+                ctx.sync()
+                return [stage.generated(s)[-1] for s in range(S)] if stage.is_last else None
+
+            with Watchdog(args.watchdog_s, f"rank {rank}: pipelined KV fill ({args.kv_fill})"):
+                picks = {}
+                if args.kv_fill in ("both", "ring") and T > 1:
+                    settle(); t0f = time.perf_counter()
+                    for s in range(S):
+                        stage.set_seq(s, int(prompts[0, s]), 0)
+                    drv.run(T - 1, advance=True, forced_tokens=prompts[:T - 1])
+                    settle(); kv_fill["ring_s"] = round(time.perf_counter() - t0f, 4)
+                    kv_fill["ring_revolutions"] = T - 1
+                    if args.kv_fill == "both":
+                        picks["ring"] = first_pick()
+                if args.kv_fill in ("both", "prefill") and T > 1:
+                    for s in range(S):
+                        model.reset_kv(s)
+                    stage.model.prepare_prefill()          # tile images + workspace outside the timed fill (first_call cost reported separately)
+                    settle(); t0f = time.perf_counter()
+                    drv.prefill(prompts[:T - 1], 0, feed_back=False)
+                    settle(); kv_fill["prefill_s"] = round(time.perf_counter() - t0f, 4)
+                    kv_fill["prefill_passes_per_stage"] = S
+                    if args.kv_fill == "both":
+                        picks["prefill"] = first_pick()
+                if len(picks) == 2:
+                    same = torch.tensor([1 if picks["ring"] == picks["prefill"] else 0], dtype=torch.int32, device=ctl)
+                    dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                    kv_fill["first_greedy_token_equal"] = bool(int(same.item()))
+                    if not kv_fill["first_greedy_token_equal"]:
+                        log(f"[bench r{rank}] ERROR: the prefill-filled caches pick {picks['prefill']} where the ring-filled ones pick {picks['ring']}")
+                        sys.exit(5)
+                for s in range(S):
+                    stage.set_seq(s, int(prompts[T - 1, s]), T - 1)
+                ctx.sync()
+                if getattr(stage, "peer", None) is not None:
+                    stage.peer_check()
+            tk = torch.tensor([kv_fill.get("ring_s", 0.0), kv_fill.get("prefill_s", 0.0)], dtype=torch.float64, device=ctl)
+            dist.all_reduce(tk, op=dist.ReduceOp.MAX)
+            if "ring_s" in kv_fill:
+                kv_fill["ring_s"] = round(float(tk[0].item()), 4)
+            if "prefill_s" in kv_fill:
+                kv_fill["prefill_s"] = round(float(tk[1].item()), 4)
         ctx.sync()
-        log(f"[bench r{rank}] KV filled to n_past={T - 1} in {time.time() - t_fill:.2f}s")
+        log(f"[bench r{rank}] KV filled to n_past={T - 1} in {time.time() - t_fill:.2f}s" + (f" {kv_fill}" if PIPE else ""))
 
         def run_steps(k):
             if not PIPE:
@@ -930,6 +977,10 @@ def main():
                 # the lm-head, rank 0 the embedding fetch) bounds the ring
                 result["ideal_efficiency_bound"] = round(sum(stage_ms) / (N * max(stage_ms)), 4)
             result["timed_region"] = "steady ring: prime() before the warm-up, steps * S micro-steps timed, drain() after (no fill/drain inside)"
+            kv_fill["note"] = (f"{S} prompts of {T - 1} tokens into the stages' KV caches, max over ranks, host clock between two drained-stream barriers. ring: one revolution per prompt "
+                               "token through the decode path; prefill: one MFMA prompt pass per stage and sequence (thk_model_prefill_stage), rows handed forward as bulk messages; the timed "
+                               "steps run on the caches of the LAST fill listed")
+            result["kv_fill"] = kv_fill
             if N > 1 and not args.no_n1_reference:
                 if rank == 0:
                     try:

@@ -242,6 +242,66 @@ def test_pipeline_stages_on_one_gpu(thk, orc, ctx):
         mm.close()
 
 
+@pytest.mark.parametrize("E,H,cuts", [(512, 8, (0, 2, 4)), (512, 8, (0, 1, 2, 3, 4)), (4096, 32, (0, 1, 3, 4))], ids=["tiny-2-stages", "tiny-4-stages", "7B-width-3-stages"])
+@pytest.mark.parametrize("M,n_past", [(300, 0), (130, 9)])
+def test_prefill_stages_on_one_gpu(thk, orc, ctx, E, H, cuts, M, n_past):
+    """thk_model_prefill_stage (round 6): the MFMA prompt pass on layer-range stages, the M x E rows handed on in ONE device buffer, against the
+    full-model thk_model_prefill (same arithmetic per layer; a stage's first layer takes the power-of-two scale of its operand image from the row itself
+    where the full model's layer takes it from the previous layer's ffn-norm input, so 'equal' is to rounding, not to the bit) and against the ORACLE
+    fed token by token (1e-3), followed by two decode steps through the stages on the caches the pass filled.  Semantics: the reference's batch
+    branch is per layer (th-llama.cpp:305-311, :365-404)."""
+    L = cuts[-1]
+    shape = thk.ModelShape(n_vocab=2048, n_embd=E, n_mult=256, n_head=H, n_layer=L, n_ctx=448)
+    oshape = orc.ModelShape(n_vocab=2048, n_embd=E, n_mult=256, n_head=H, n_layer=L, n_ctx=448)
+    full = thk.Model(ctx, shape); full.fill_synthetic(); full.finalize()
+    stages = []
+    for k in range(len(cuts) - 1):
+        flags = (thk.THK_STAGE_EMBED if k == 0 else 0) | (thk.THK_STAGE_HEAD if k == len(cuts) - 2 else 0)
+        st = thk.Model(ctx, shape, cuts[k], cuts[k + 1], flags=flags); st.fill_synthetic(); st.finalize()
+        stages.append(st)
+    om = orc.OracleModel(oshape); om.fill_synthetic()
+    rng = np.random.default_rng(31 * M + n_past)
+    toks = np.concatenate([[1], rng.integers(3, 2048, n_past + M + 2)]).astype(np.int32)
+    rows = thk.Buffer(ctx, M * E * 4)
+
+    def through_stages(tok, pos):
+        h = None
+        for st in stages:
+            lg, h = st.eval([tok] if st is stages[0] else None, pos, hidden=h, want_logits=st is stages[-1], want_hidden=st is not stages[-1])
+        return lg
+
+    for i in range(n_past):                                 # rows a decode step wrote, on both sides
+        full.eval([int(toks[i])], i, want_logits=False)
+        through_stages(int(toks[i]), i)
+    lf = full.prefill(toks[n_past:n_past + M], n_past)
+    ls = None
+    for st in stages:
+        ls = st.prefill_stage(toks[n_past:n_past + M] if st is stages[0] else None, rows, M, n_past, want_logits=st is stages[-1])
+    ctx.sync()
+    lo = None
+    for i in range(n_past + M):
+        lo, _ = om.eval(int(toks[i]), i, want_logits=(i == n_past + M - 1))
+    d_full, d_orc = float(np.abs(ls - lf).max()), float(np.abs(ls - lo).max())
+    print(f"\n[stage prefill E={E} cuts={cuts} M={M} n_past={n_past}] vs full-model prefill {d_full:.3e}, vs oracle {d_orc:.3e}")
+    assert d_full < 1e-4, d_full
+    assert d_orc < LOGIT_TOL, d_orc
+    assert int(ls.argmax()) == orc.greedy(lo)
+    for i in (n_past + M, n_past + M + 1):                  # decode through the stages on the caches the stage passes filled
+        lg = through_stages(int(toks[i]), i); lo, _ = om.eval(int(toks[i]), i)
+        assert np.abs(lg - lo).max() < LOGIT_TOL, (i, float(np.abs(lg - lo).max()))
+        assert int(lg.argmax()) == orc.greedy(lo)
+    # argument errors: a stage without the table needs the rows, a stage without the head cannot give logits
+    with pytest.raises(thk.ThkError):
+        stages[-1].prefill_stage(None, None, M, n_past)
+    with pytest.raises(thk.ThkError):
+        stages[0].prefill_stage(toks[:4], rows, 4, 0, want_logits=True)
+    with pytest.raises(thk.ThkError):
+        stages[0].prefill(toks[:4], 0)                      # thk_model_prefill stays the full-model entry point
+    rows.free(); om.close()
+    for mm in [full] + stages:
+        mm.close()
+
+
 def test_loaded_tensors_equal_synthetic_fill(thk, orc, ctx):
     """thk_model_set_tensor (the loader's upload path) with host tensors == device-side synthetic fill."""
     shape = thk.TINY

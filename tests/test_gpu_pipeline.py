@@ -229,6 +229,8 @@ def test_bench_two_ranks_share_one_gpu():
     assert h["validated"] is True and h["payloads_checked_per_rank"] == 4 and len(h["handoff_us_per_rank"]) == 2
     ls = d["layer_split"]
     assert ls["used"] == [[0, 1], [1, 2]] and "measured" in ls and len(d["stage_ms_no_handoff"]) == 2
+    kf = d["kv_fill"]                                                 # round 6: the prompts reach the caches both ways, and the caches agree
+    assert kf["ring_s"] > 0 and kf["prefill_s"] > 0 and kf["first_greedy_token_equal"] is True and kf["ring_revolutions"] == 63 and kf["prefill_passes_per_stage"] == 2
 
 
 def test_bench_four_ranks_share_one_gpu_and_carry_the_n1_line():
@@ -251,6 +253,7 @@ def test_bench_four_ranks_share_one_gpu_and_carry_the_n1_line():
     assert d["n_gpus"] == 4 and d["ranks_joined"] == 4 and d["value"] > 0 and d["config"]["sequences"] == 4 and d["config"]["transport"] == "peer"
     assert d["layer_split"]["used"] == [[0, 1], [1, 2], [2, 3], [3, 4]] and len(d["stage_ms_no_handoff"]) == 4
     assert d["handoff"]["validated"] is True
+    assert d["kv_fill"]["first_greedy_token_equal"] is True and d["kv_fill"]["prefill_s"] > 0
     n1 = d["n1_same_invocation"]
     assert n1["n_gpus"] == 1 and n1["steps"] == 6 and n1["value"] > 0
 
@@ -286,7 +289,7 @@ def test_peer_timeout_is_sticky(thk):
     stage.model.close(); ctx.close()
 
 
-def _peer_worker(rank, world, port, n_prompt, n_gen, q):
+def _peer_worker(rank, world, port, n_prompt, n_gen, q, prefill=False):
     """One pipeline stage per PROCESS, both on GPU 0: the hidden state and the token cross the process boundary through
     hipIpc-mapped mailboxes (thk_peer_*); gloo only carries the 64-byte handles and the barriers."""
     import sys
@@ -302,7 +305,7 @@ def _peer_worker(rank, world, port, n_prompt, n_gen, q):
         thk = graft.load_package()
         from token_hawk_amd.pipeline import HipStage, PipelineDriver
         dev = torch.device("cuda", 0)
-        shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=4, n_ctx=64)
+        shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=4, n_ctx=max(64, n_prompt + n_gen + 8))
         S = world
         ctx = thk.Context(0)
         stage = HipStage(thk, ctx, shape, rank, world, S, dev)
@@ -321,7 +324,10 @@ def _peer_worker(rank, world, port, n_prompt, n_gen, q):
         prompts = rng.integers(3, 2048, (n_prompt, S)); prompts[0, :] = 1
         for s in range(S):
             stage.set_seq(s, int(prompts[0, s]), 0)
-        drv.run(n_prompt, advance=True, forced_tokens=prompts)
+        if prefill:      # round 6: ONE MFMA prompt pass per stage and sequence, the M x E rows through the mailbox's bulk slot, the pick fed back
+            drv.prefill(prompts)
+        else:
+            drv.run(n_prompt, advance=True, forced_tokens=prompts)
         drv.prime(advance=True); drv.steady(n_gen, advance=True); drv.drain(advance=True)
         ctx.sync()
         stage.peer_check()
@@ -331,13 +337,19 @@ def _peer_worker(rank, world, port, n_prompt, n_gen, q):
             ok = True
             for s in range(S):
                 full.seq_set(s, int(prompts[0, s]), 0)
-                full.eval(prompts[:, s].astype(np.int32), 0, seq=s, want_logits=False)      # logs the greedy pick after every prompt token
-                exp = full.seq_get(s)[0].tolist()
+                if prefill:
+                    lp = full.prefill(prompts[:, s].astype(np.int32), 0, seq=s)
+                    exp = [int(lp.argmax())]
+                else:
+                    full.eval(prompts[:, s].astype(np.int32), 0, seq=s, want_logits=False)      # logs the greedy pick after every prompt token
+                    exp = full.seq_get(s)[0].tolist()
                 extra = 1                                                                 # prime issues N - 1 items beyond whole steps, drain() tops the step up: every sequence ends one token ahead
                 full.seq_set(s, exp[-1], n_prompt)
                 full.decode_steps(n_gen + extra, s, advance=True)
                 exp += full.seq_get(s)[0].tolist()                                        # n_prompt + n_gen + extra picks
                 got = stage.generated(s)
+                if prefill:
+                    exp = exp[1:]                                                         # the pick behind the prompt lives in the token slot only; the log starts with the first ring step
                 ok = ok and got == exp
                 if got != exp:
                     print("MISMATCH", s, got, exp, flush=True)
@@ -364,6 +376,28 @@ def test_two_process_pipeline_through_peer_mailboxes_on_one_gpu():
         p.start()
     for p in procs:
         p.join(300)
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) is True
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_process_pipeline_ingests_the_prompt_with_one_pass_per_stage(world):
+    """Round 6 (config C3 composed with C4): two and four HipStages in as many processes on GPU 0; a 300-token prompt per sequence (one 256-token
+    slab + a 44-token one) goes through PipelineDriver.prefill - thk_model_prefill_stage on every stage, the 300 x E rows through the
+    mailbox's bulk slot, the last stage's pick back to rank 0 - and the ring continues from it.  Tokens must equal the un-split model's
+    (full-model prefill + decode)."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29700 + os.getpid() % 90 + world
+    procs = [ctxm.Process(target=_peer_worker, args=(r, world, port, 300, 6, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(400)
     for p in procs:
         if p.is_alive():
             p.terminate()

@@ -24,12 +24,28 @@ class OracleStage:
         self.hidden_in = [torch.zeros(E) for _ in range(n_seq)]
         self.hidden_out = [torch.zeros(E) for _ in range(n_seq)]
         self.token = [torch.zeros(1, dtype=torch.int32) for _ in range(n_seq)]
+        self.bulk = torch.zeros(shape.n_ctx, E)
         self.pos = [0] * n_seq
         self.gen = [[] for _ in range(n_seq)]
         self.logits = [[] for _ in range(n_seq)]
 
     def set_seq(self, s, token, pos):
         self.token[s][0] = token; self.pos[s] = pos
+
+    def prefill(self, s, tokens, n, n_past):
+        """HipStage.prefill's contract on the oracle: rows [0, n) of self.bulk in place, the last stage's pick into the token slot, position -> n_past + n
+        (the oracle has no batched pass: token by token through this stage's layers - the result the MFMA pass must reproduce)."""
+        for i in range(n):
+            last_row = i == n - 1
+            lg, hid = self.m.eval(int(tokens[i]) if self.is_first else None, n_past + i, seq=s, l0=self.l0, l1=self.l1,
+                                  hidden=None if self.is_first else self.bulk[i].numpy(), want_logits=self.is_last and last_row)
+            if not self.is_last:
+                self.bulk[i].copy_(torch.from_numpy(hid))
+            elif last_row:
+                t = self.orc.greedy(lg); self.token[s][0] = t; self.gen[s].append(t); self.logits[s].append(lg.copy())
+            else:
+                self.gen[s].append(None); self.logits[s].append(None)      # keeps one entry per prompt position, as the ring fill does
+        self.pos[s] = n_past + n
 
     def set_token(self, s, token):
         self.token[s][0] = int(token)
@@ -48,7 +64,7 @@ class OracleStage:
             self.pos[s] += 1
 
 
-def _worker(rank, world, port, n_prompt, n_gen, steady=False, split=None, validate=False):
+def _worker(rank, world, port, n_prompt, n_gen, steady=False, split=None, validate=False, prefill=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -70,8 +86,12 @@ def _worker(rank, world, port, n_prompt, n_gen, steady=False, split=None, valida
         prompts = rng.integers(3, 2048, (n_prompt, S)); prompts[0, :] = 1
         for s in range(S):
             stage.set_seq(s, int(prompts[0, s]), 0)
-        r1 = drv.run(n_prompt, advance=True, forced_tokens=prompts)       # prompt through the pipeline
-        assert r1.items == n_prompt * S
+        if prefill:      # one batched pass per stage and sequence, rows handed forward as bulk messages, the pick fed back to rank 0
+            r1 = drv.prefill(prompts)
+            assert r1.items == S and stage.pos == [n_prompt] * S
+        else:
+            r1 = drv.run(n_prompt, advance=True, forced_tokens=prompts)       # prompt through the pipeline
+            assert r1.items == n_prompt * S
         extra = [0] * S
         if not steady:
             r2 = drv.run(n_gen, advance=True)                              # greedy continuation (token ring)
@@ -120,6 +140,14 @@ def test_pipeline_ring_kept_full_matches_single_process(world):
     """prime / steady / steady / drain (no fill or drain inside a steady() call) produces the same tokens and logits."""
     port = 29600 + world + (os.getpid() % 1000)
     mp.spawn(_worker, args=(world, port, 3, 4, True), nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world,steady", [(2, False), (3, False), (3, True)])
+def test_pipeline_prompt_pass_per_stage_matches_single_process(world, steady):
+    """PipelineDriver.prefill (round 6: one batched prompt pass per stage, M x E rows handed forward, pick fed back) followed by the token
+    ring produces the tokens and logits of the un-split model - the same check the ring-fed prompt passes."""
+    port = 29650 + 2 * world + int(steady) + (os.getpid() % 1000)
+    mp.spawn(_worker, args=(world, port, 5, 4, steady, None, False, True), nprocs=world, join=True)
 
 
 @pytest.mark.parametrize("world,split", [(2, (3, 1)), (3, (1, 2, 1))])

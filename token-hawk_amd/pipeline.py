@@ -131,6 +131,37 @@ class HipStage:
         self.hidden_in = [torch.as_tensor(_CudaView(m.hidden_in_ptr(s), (E,), "<f4"), device=device) for s in range(n_seq)]
         self.hidden_out = [torch.as_tensor(_CudaView(m.hidden_out_ptr(s), (E,), "<f4"), device=device) for s in range(n_seq)]
         self.token = [torch.as_tensor(_CudaView(m.token_dev_ptr(s), (1,), "<i4"), device=device) for s in range(n_seq)]
+        # the rows a stage's prompt pass hands on (thk_model_prefill_stage works on them in place): one [n_ctx, E] f32 buffer per stage
+        self._bulk_buf = thk.Buffer(ctx, shape.n_ctx * E * 4)
+        self.bulk = torch.as_tensor(_CudaView(self._bulk_buf.ptr, (shape.n_ctx, E), "<f4"), device=device)
+        self._thk = thk
+
+    def prefill(self, seq: int, tokens, n_tokens: int, n_past: int):
+        """This stage's layers over the prompt rows on the MFMA path (config C3 on a stage of C4): rows [0, n_tokens) of self.bulk are the
+        input (token ids on the first stage) and become the output; the last stage leaves its greedy pick in the sequence's token slot.
+        Every stage's position moves to n_past + n_tokens, the next slot to evaluate."""
+        m, shape = self.model, self.model.shape
+        m.prefill_stage(tokens if self.is_first else None, self._bulk_buf.ptr, n_tokens, n_past, seq=seq)
+        if n_past + n_tokens < shape.n_ctx:
+            m.seq_set(seq, 0, n_past + n_tokens)
+        if self.is_last:                                 # llama_sample_top_p_top_k's temp <= 0 branch (th-llama.cpp:826-838) on the device, into the token slot
+            ctx = m.ctx
+            ctx.check(ctx.lib.thk_argmax(ctx.h, m.logits_dev_ptr(seq), shape.n_vocab, m.token_dev_ptr(seq)), "thk_argmax")
+
+    def native_bulk(self, send_rows, recv_rows, nxt: int, prev: int):
+        """The prompt rows over libthk's RCCL path: n_rows * E * 4 bytes - a bandwidth message (8 MB at 512 x 4096), not a latency one."""
+        ctx, lib, E = self.model.ctx, self.model.ctx.lib, self.model.shape.n_embd
+        if send_rows:
+            ctx.check(lib.thk_pp_send(self.pp, self._bulk_buf.ptr, send_rows * E * 4, nxt), "thk_pp_send")
+        if recv_rows:
+            ctx.check(lib.thk_pp_recv(self.pp, self._bulk_buf.ptr, recv_rows * E * 4, prev), "thk_pp_recv")
+
+    def peer_bulk(self, seq: int, send_rows, recv_rows):
+        ctx, lib, E = self.model.ctx, self.model.ctx.lib, self.model.shape.n_embd
+        if send_rows:
+            ctx.check(lib.thk_peer_send_bulk(self.peer, seq, self._bulk_buf.ptr, send_rows * E * 4), "thk_peer_send_bulk")
+        if recv_rows:
+            ctx.check(lib.thk_peer_recv_bulk(self.peer, seq, self._bulk_buf.ptr, recv_rows * E * 4), "thk_peer_recv_bulk")
 
     def attach_native_transport(self, rank: int, world: int, unique_id: bytes):
         """Use libthk's own RCCL point-to-point path (thk_pp_*) instead of torch.distributed P2P ops."""
@@ -327,6 +358,49 @@ class PipelineDriver:
                 fence()                                  # a slot is rewritten only after every rank has taken the previous payload
         us = spent / max(1, reps * S) * 1e6
         return HandoffReport(not errors, checked, us, errors)
+
+    def _bulk(self, seq: int, send_rows: int, recv_rows: int):
+        """The prompt rows of one sequence to the next stage / from the previous one, on the transport in use."""
+        st = self.stage
+        if getattr(st, "peer", None) is not None:
+            st.peer_bulk(seq, send_rows, recv_rows)
+        elif getattr(st, "pp", None) is not None:
+            st.native_bulk(send_rows, recv_rows, self.next, self.prev)
+        else:
+            ops = []
+            if send_rows:
+                ops.append(dist.P2POp(dist.isend, st.bulk[:send_rows], self.next))
+            if recv_rows:
+                ops.append(dist.P2POp(dist.irecv, st.bulk[:recv_rows], self.prev))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def prefill(self, prompts, n_past: int = 0, feed_back: bool = True) -> PipelineResult:
+        """Prompt ingestion with ONE batched pass per stage and sequence (round 6; config C3 composed with C4) instead of len(prompts) ring
+        revolutions: prompts[:, s] (int ids, [M, S]; only the first stage reads them) goes through stage 0's layers as one MFMA prompt pass,
+        its M x E output rows travel to stage 1 as one bandwidth message, and so on - stage r works on sequence s while stage r + 1 works
+        on s - 1.  The row hand-offs only point forward (a chain, not a ring), so nothing can dead-lock and no grouping is needed; the last
+        stage's greedy picks go back to the first stage's token slots after the last forward message (feed_back), exactly what the ring
+        leaves there after run(M, forced_tokens=prompts), so run() / prime() continue from them.  The ring must be empty.  Matches the reference's batch branch,
+        which is per layer (th-llama.cpp:305-311, :365-404)."""
+        st, S, N = self.stage, self.S, self.world
+        assert not self.primed, "prefill() needs an empty ring: drain() first"
+        M = len(prompts)
+        for s in range(S):
+            if not st.is_first:
+                self._bulk(s, 0, M)
+            st.prefill(s, [int(t) for t in prompts[:, s]] if st.is_first else None, M, n_past)
+            if not st.is_last:
+                self._bulk(s, M, 0)
+        # the picks travel back only after EVERY forward message of this rank is behind it: a send completes when its receive is posted (RCCL
+        # kernels and gloo alike), so a token send between two bulk receives would wait for rank 0, which waits for its next bulk send
+        if feed_back and N > 1:
+            for s in range(S):
+                if st.is_last:
+                    self._xfer(s, None)
+                elif st.is_first:
+                    self._xfer(None, s)
+        return PipelineResult(S, S)
 
     def _micro(self, n_micro: int, lo: int, hi, advance: bool, forced_tokens=None) -> int:
         """n_micro global micro-steps from self.j on; returns the number of items this rank processed."""
