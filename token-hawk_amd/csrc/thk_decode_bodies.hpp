@@ -756,20 +756,54 @@ __device__ __forceinline__ void gemv_quarter_body(const GemvArgs& a, const int b
 // tc_dyn (round 4): tc follows the LIVE context, tc = ceil(T / nsplit) rounded up to the wave batch (PPW * UB positions), computed
 // here from the device-resident position - every (head, split) has work at every T >= nsplit * PPW * UB instead of the splits
 // partitioning the cache capacity n_ctx (at T << n_ctx all but the first would exit empty).
-// one position's 4-element slice for this lane: f32 cache (16 bytes) or f16 cache (8 bytes, widened by v_cvt_f32_f16)
-template <bool KVH>
-__device__ __forceinline__ f4 ld_kv4(const float* base, size_t elem_off) {
-    if (KVH) {
+// A lane's slice of one cached position: EPL consecutive elements = ONE 16-byte load whatever the cache type - f32 cache: 4 elements, D/4 lanes per
+// position; binary16 cache (round 6): 8 elements, D/8 lanes per position, so a wave-instruction moves 1 KiB again (rounds 3-5 loaded 8 bytes per lane
+// with the f32 lane mapping: 512 B per wave-instruction, twice the instructions in flight for the same bytes - 40 % of the HBM peak at T = 2048
+// against the f32 cache's 56 %).  D = 64 with a binary16 cache keeps 4 elements per lane (group_sum needs groups of >= 16 lanes).
+template <bool KVH, int EPL> struct KvLane;
+template <> struct KvLane<false, 4> {
+    typedef f4 raw;
+    static __device__ __forceinline__ raw ld(const float* base, size_t elem_off) { return __builtin_nontemporal_load(reinterpret_cast<const f4*>(base + elem_off)); }
+    static __device__ __forceinline__ float dot(const float (&q)[4], const raw& k) { return q[0] * k.x + q[1] * k.y + q[2] * k.z + q[3] * k.w; }
+    static __device__ __forceinline__ void axpy(float (&o)[4], const raw& v, float p) { o[0] += v.x * p; o[1] += v.y * p; o[2] += v.z * p; o[3] += v.w * p; }
+};
+template <> struct KvLane<true, 4> {
+    typedef f4 raw;       // widened at the load (v_cvt_f32_f16)
+    static __device__ __forceinline__ raw ld(const float* base, size_t elem_off) {
         const h4 h = __builtin_nontemporal_load(reinterpret_cast<const h4*>(reinterpret_cast<const _Float16*>(base) + elem_off));
         return f4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
     }
-    return __builtin_nontemporal_load(reinterpret_cast<const f4*>(base + elem_off));
-}
+    static __device__ __forceinline__ float dot(const float (&q)[4], const raw& k) { return q[0] * k.x + q[1] * k.y + q[2] * k.z + q[3] * k.w; }
+    static __device__ __forceinline__ void axpy(float (&o)[4], const raw& v, float p) { o[0] += v.x * p; o[1] += v.y * p; o[2] += v.z * p; o[3] += v.w * p; }
+};
+template <> struct KvLane<true, 8> {
+    typedef h8 raw;       // stays packed (4 VGPRs) until it is used
+    static __device__ __forceinline__ raw ld(const float* base, size_t elem_off) {
+        return __builtin_nontemporal_load(reinterpret_cast<const h8*>(reinterpret_cast<const _Float16*>(base) + elem_off));
+    }
+    static __device__ __forceinline__ float dot(const float (&q)[8], const raw& k) {
+        return ((q[0] * (float)k[0] + q[1] * (float)k[1]) + (q[2] * (float)k[2] + q[3] * (float)k[3])) + ((q[4] * (float)k[4] + q[5] * (float)k[5]) + (q[6] * (float)k[6] + q[7] * (float)k[7]));
+    }
+    static __device__ __forceinline__ void axpy(float (&o)[8], const raw& v, float p) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += (float)v[i] * p;
+    }
+};
+#ifndef THK_ATTN_UB8
+#define THK_ATTN_UB8 4      // wave-instructions per K (and V) batch with 8-element lanes: PPW * UB = 16 positions per wave batch, as the f32 cache (every wave of the workgroup has work at T = 512 with 4 splits)
+#endif
+template <int D, bool KVH> struct AttnGeo {
+    static constexpr int EPL = (KVH && D >= 128) ? 8 : 4;    // elements per lane
+    static constexpr int LPP = D / EPL;                       // lanes per position
+    static constexpr int PPW = 64 / LPP;                      // positions per wave-instruction
+    static constexpr int UB = EPL == 8 ? THK_ATTN_UB8 : 8;    // wave-instructions per batch (K and V each)
+};
 template <int D, int WAVES, bool KVH, bool PIPE = false>
 __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
-    constexpr int LPP = D / 4;          // lanes per position
-    constexpr int PPW = 64 / LPP;       // positions per wave-instruction
-    constexpr int UB = 8;               // wave-instructions per batch (K and V each)
+    typedef AttnGeo<D, KVH> G;
+    constexpr int EPL = G::EPL, LPP = G::LPP, PPW = G::PPW, UB = G::UB;
+    typedef KvLane<KVH, EPL> KL;
+    typedef typename KL::raw kvraw;
     __shared__ float sm_o[WAVES][D];
     __shared__ float sm_ml[WAVES][2];
 
@@ -792,35 +826,45 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     if (a.tc_dyn) tc = ((div_ns(T + a.nsplit - 1) + PPW * UB - 1) / (PPW * UB)) * (PPW * UB);
     const int t0 = s * tc, t1 = min(t0 + tc, T);
 
-    const f4 q = *reinterpret_cast<const f4*>(a.q + qi * E + h * D + li * 4);
-    const size_t koff = (size_t)(h * D + li * 4);               // element offset of this lane's K (and V) slice inside a cache row
+    float q[EPL];
+    {
+        const f4 q0 = *reinterpret_cast<const f4*>(a.q + qi * E + h * D + li * EPL);
+        q[0] = q0.x; q[1] = q0.y; q[2] = q0.z; q[3] = q0.w;
+        if constexpr (EPL == 8) {
+            const f4 q1 = *reinterpret_cast<const f4*>(a.q + qi * E + h * D + li * EPL + 4);
+            q[4] = q1.x; q[5] = q1.y; q[6] = q1.z; q[7] = q1.w;
+        }
+    }
+    const size_t koff = (size_t)(h * D + li * EPL);             // element offset of this lane's K (and V) slice inside a cache row
 
     float m = -INFINITY, l = 0.f;
-    f4 o = {0.f, 0.f, 0.f, 0.f};
+    float o[EPL];
+#pragma unroll
+    for (int i = 0; i < EPL; ++i) o[i] = 0.f;
     // wave w takes positions t0 + (it*WAVES + w)*PPW*UB + u*PPW + grp.  Loads are branch-free:
     // positions past the end are clamped to a valid row and masked out of the softmax.
     // (Round 3 tried fetching the first batch BEFORE the device-resident position is known - every row below n_ctx is
     // allocated - to take the position's round trip off the critical path: 0.6 us per launch SLOWER on MI355X, removed.)
-    if constexpr (!PIPE) {
-    for (int tb = t0 + wave * (PPW * UB); tb < t1; tb += WAVES * PPW * UB) {
-        f4 kv[UB], vv[UB];
+    auto fetch = [&](int tb, kvraw (&kv)[UB], kvraw (&vv)[UB]) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int t = min(tb + u * PPW + grp, t1 - 1);
-            kv[u] = ld_kv4<KVH>(a.kcache, (size_t)t * E + koff);
+            kv[u] = KL::ld(a.kcache, (size_t)t * E + koff);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int t = min(tb + u * PPW + grp, t1 - 1);
-            vv[u] = ld_kv4<KVH>(a.vcache, (size_t)t * E + koff);
+            vv[u] = KL::ld(a.vcache, (size_t)t * E + koff);
         }
-        __builtin_amdgcn_sched_barrier(0);
+    };
+    // one batch: scores, online-softmax update, P.V
+    auto consume = [&](int tb, const kvraw (&kv)[UB], const kvraw (&vv)[UB]) {
         float sc[UB];
         float bm = -INFINITY;
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const int t = tb + u * PPW + grp;
-            float d = q.x * kv[u].x + q.y * kv[u].y + q.z * kv[u].z + q.w * kv[u].w;
+            float d = KL::dot(q, kv[u]);
             d = group_sum<LPP>(d) * a.scale;
             sc[u] = (t < t1) ? d : -INFINITY;
             bm = fmaxf(bm, sc[u]);
@@ -828,13 +872,22 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
         bm = wave_max(bm);                      // wave-uniform, finite (tb < t1 => lane group 0 valid)
         const float mn = fmaxf(m, bm);
         const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
-        l *= alpha; o *= alpha;
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) o[i] *= alpha;
         float p[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) { p[u] = expf(sc[u] - mn); l += p[u]; }   // exp(-inf) == 0 for masked positions
 #pragma unroll
-        for (int u = 0; u < UB; ++u) o += vv[u] * p[u];
+        for (int u = 0; u < UB; ++u) KL::axpy(o, vv[u], p[u]);
         m = mn;
+    };
+    if constexpr (!PIPE) {
+    for (int tb = t0 + wave * (PPW * UB); tb < t1; tb += WAVES * PPW * UB) {
+        kvraw kv[UB], vv[UB];
+        fetch(tb, kv, vv);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(tb, kv, vv);
         THK_STAMP(a.trace, bid, 1);
     }
     } else {
@@ -842,48 +895,17 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     // pipelined - the next round's K/V batch is requested BEFORE this round's softmax arithmetic, so a wave has two batches in
     // flight and the rounds are not a chain of dependent HBM round trips.  A variant of its own: the same structure cost the
     // single-round case (T <= 512 with 4 splits, the headline) 1 us per launch (profiles/r04_attention_ctx2048.txt).
-    auto fetch = [&](int tb, f4 (&kv)[UB], f4 (&vv)[UB]) {
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int t = min(tb + u * PPW + grp, t1 - 1);
-            kv[u] = ld_kv4<KVH>(a.kcache, (size_t)t * E + koff);
-        }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int t = min(tb + u * PPW + grp, t1 - 1);
-            vv[u] = ld_kv4<KVH>(a.vcache, (size_t)t * E + koff);
-        }
-    };
     constexpr int STRIDE = WAVES * PPW * UB;
     int tb = t0 + wave * (PPW * UB);
-    f4 kv[UB], vv[UB];
+    kvraw kv[UB], vv[UB];
     if (tb < t1) fetch(tb, kv, vv);
     while (tb < t1) {
-        f4 kvn[UB], vvn[UB];
+        kvraw kvn[UB], vvn[UB];
         const int tn = tb + STRIDE;
         const bool more = tn < t1;                  // wave-uniform
         if (more) fetch(tn, kvn, vvn);
         __builtin_amdgcn_sched_barrier(0);
-        float sc[UB];
-        float bm = -INFINITY;
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int t = tb + u * PPW + grp;
-            float d = q.x * kv[u].x + q.y * kv[u].y + q.z * kv[u].z + q.w * kv[u].w;
-            d = group_sum<LPP>(d) * a.scale;
-            sc[u] = (t < t1) ? d : -INFINITY;
-            bm = fmaxf(bm, sc[u]);
-        }
-        bm = wave_max(bm);                      // wave-uniform, finite (tb < t1 => lane group 0 valid)
-        const float mn = fmaxf(m, bm);
-        const float alpha = (m == -INFINITY) ? 0.f : expf(m - mn);
-        l *= alpha; o *= alpha;
-        float p[UB];
-#pragma unroll
-        for (int u = 0; u < UB; ++u) { p[u] = expf(sc[u] - mn); l += p[u]; }   // exp(-inf) == 0 for masked positions
-#pragma unroll
-        for (int u = 0; u < UB; ++u) o += vv[u] * p[u];
-        m = mn;
+        consume(tb, kv, vv);
         THK_STAMP(a.trace, bid, 1);
         if (more) {
 #pragma unroll
@@ -896,8 +918,15 @@ __device__ __forceinline__ void attn_body(const AttnArgs& a, const int bid) {
     }
     // merge the lane groups of the wave (same m)
 #pragma unroll
-    for (int off = LPP; off < 64; off <<= 1) { l += __shfl_xor(l, off); o.x += __shfl_xor(o.x, off); o.y += __shfl_xor(o.y, off); o.z += __shfl_xor(o.z, off); o.w += __shfl_xor(o.w, off); }
-    if (lane < LPP) *reinterpret_cast<f4*>(&sm_o[wave][lane * 4]) = o;
+    for (int off = LPP; off < 64; off <<= 1) {
+        l += __shfl_xor(l, off);
+#pragma unroll
+        for (int i = 0; i < EPL; ++i) o[i] += __shfl_xor(o[i], off);
+    }
+    if (lane < LPP) {
+        *reinterpret_cast<f4*>(&sm_o[wave][lane * EPL]) = f4{o[0], o[1], o[2], o[3]};
+        if constexpr (EPL == 8) *reinterpret_cast<f4*>(&sm_o[wave][lane * EPL + 4]) = f4{o[4], o[5], o[6], o[7]};
+    }
     if (lane == 0) { sm_ml[wave][0] = m; sm_ml[wave][1] = l; }
     __syncthreads();
     THK_STAMP(a.trace, bid, 2);

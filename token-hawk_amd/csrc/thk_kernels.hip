@@ -268,6 +268,13 @@ static void launch_attn_dw(const AttnArgs& a, int grid, hipStream_t st) {
     if (a.kv_f16) THK_ATTN_GO(true, false); else THK_ATTN_GO(false, false);
 #undef THK_ATTN_GO
 }
+int attn_round_positions(int D, int waves, bool kv_f16) {
+    switch (D) {
+        case 64: return waves * (kv_f16 ? AttnGeo<64, true>::PPW * AttnGeo<64, true>::UB : AttnGeo<64, false>::PPW * AttnGeo<64, false>::UB);
+        case 256: return waves * (kv_f16 ? AttnGeo<256, true>::PPW * AttnGeo<256, true>::UB : AttnGeo<256, false>::PPW * AttnGeo<256, false>::UB);
+        default: return waves * (kv_f16 ? AttnGeo<128, true>::PPW * AttnGeo<128, true>::UB : AttnGeo<128, false>::PPW * AttnGeo<128, false>::UB);
+    }
+}
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     if (a.nsplit < 1 || a.nsplit > 4096 || a.tc <= 0) return hipErrorInvalidValue;
     const int grid = a.H * a.nsplit * (a.nq > 1 ? a.nq : 1);

@@ -87,6 +87,8 @@ hipError_t launch_gemv(int pro, int epi, int nru, const GemvArgs& a, int grid, b
 bool gemv_quarter_ok(int C, int R, int grid);
 hipError_t launch_gemv_quarter(const GemvArgs& a, int grid, hipStream_t st);
 hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st);
+// positions one round of an attention workgroup covers (waves x positions per wave-instruction x wave-instructions per batch): a split longer than this takes the pipelined variant
+int attn_round_positions(int D, int waves, bool kv_f16);
 hipError_t launch_attn_combine(const float* part_o, const float* part_ml, float* out, int H, int D, int nsplit, hipStream_t st);
 hipError_t launch_rms_norm(float* x, int rows, int N, hipStream_t st);
 hipError_t launch_row_mul(float* x, const float* g, int rows, int N, hipStream_t st);

@@ -80,7 +80,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
             AttnArgs t{};
             t.q = m->q; t.kcache = kc; t.vcache = vc; t.pos_ptr = &sb.st->pos; t.H = H; t.D = D; t.nsplit = m->nsplit; t.tc = m->tc;
             t.tc_dyn = m->attn_tc_dyn;
-            t.pipe = (T + m->nsplit - 1) / m->nsplit > m->attn_waves * (64 / (D / 4)) * 8;      // a split of the full cache is longer than one round
+            t.pipe = (T + m->nsplit - 1) / m->nsplit > attn_round_positions(D, m->attn_waves, m->kv_f16 != 0);      // a split of the full cache is longer than one round
             t.scale = 1.0f / sqrtf((float)D); t.waves = m->attn_waves; t.kv_f16 = m->kv_f16;
             t.out = m->nsplit == 1 ? m->attn_out : nullptr; t.part_o = m->part_o; t.part_ml = m->part_ml;
             GemvArgs a{};

@@ -76,7 +76,7 @@ extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache
     a.H = (int)H; a.D = (int)D; a.nsplit = nsplit; a.tc = (int)((T + nsplit - 1) / nsplit);
     a.scale = 1.0f / sqrtf((float)D); a.waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
     a.tc_dyn = tun(ctx, "attn_tc_dyn") != 0;
-    a.pipe = (T + nsplit - 1) / nsplit > a.waves * (64 / ((int)D / 4)) * 8;
+    a.pipe = (T + nsplit - 1) / nsplit > attn_round_positions((int)D, a.waves, false);
     a.part_o = (float*)ctx->scratch; a.part_ml = a.part_o + (size_t)H * nsplit * D;
     a.out = nsplit == 1 ? out : nullptr;
     HIPCHK(ctx, launch_attn_decode(a, ctx->stream));
