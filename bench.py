@@ -783,6 +783,8 @@ def main():
             ctx.set_tunable(k, int(v))
         if args.kv == "f16":
             ctx.set_tunable("kv_f16", 1)
+        if args.ranks_share_gpu and not any(kv.startswith("fold_finish=") for kv in args.tunable):
+            ctx.set_tunable("fold_finish", 0)     # several PROCESSES share the CUs: the in-launch wait's 1 s bound would then depend on what the others run
         info = ctx.device_info()
         from token_hawk_amd.pipeline import HipStage, PipelineDriver, layer_range
         S = N

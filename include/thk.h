@@ -364,12 +364,14 @@ int thk_peer_destroy(thk_peer* p);
  *            attn_waves (4|8); use_graph; kv_f16 (1 = K/V caches stored as binary16, rounded RNE at the append: half the
  *            KV bytes, thk_model_bytes_per_token then counts s_kv = 2; default 0 = f32 like the reference,
  *            th-llama-loader.cpp:335); engine (1 = persistent loader/consumer launch per step when the
- *            shape allows, 0 = launches); attn_tc_dyn, fold_embed; fold_finish (1, default: the lm-head
- *            launch's highest-numbered workgroup polls the other workgroups' arg-max key slots and finishes the token inside
- *            the launch - this LEANS ON workgroups being dispatched in index order, which HIP does not promise: a workgroup
- *            that never delivers is bounded by a 1 s device time-out -> SeqState error word -> THK_ERR_STATE from
- *            thk_model_seq_get / seq_last_token, which also clear the key slots; 0 = the pick as a launch of its own, no
- *            in-launch wait, kept tested);
+ *            shape allows, 0 = launches); attn_tc_dyn, fold_embed; fold_finish (1, default: ONE workgroup
+ *            of the lm-head launch - the highest-numbered - polls the other workgroups' arg-max key slots and finishes the token inside
+ *            the launch.  Forward progress does not depend on the dispatch order: the poller holds one workgroup slot, all others keep
+ *            taking the launch's workgroups; the order only decides how long it spins.  2 = workgroup 0 polls instead (dispatched
+ *            first: the adversarial placement, kept as a tested mode).  The wait is bounded by a 1 s device time-out - only a GPU
+ *            whose CUs are held by OTHER processes for that long can trip it (bench.py --ranks-share-gpu therefore runs with 0) ->
+ *            SeqState error word -> THK_ERR_STATE from thk_model_seq_get / seq_last_token, which also clear the key slots;
+ *            0 = the pick as a launch of its own, no in-launch wait, kept tested);
  *            measure_skip_kernel (1..6: that kernel is not launched -- bench.py's marginal-cost
  *            measurement; results are garbage; REFUSED unless the environment has THK_MEASURE_HOOKS=1)
  *   prefill: prefill_slab_tokens (256, default: up to 256 prompt tokens share one pass over the weights; 128 = the

@@ -164,7 +164,7 @@ def test_folded_greedy_pick_over_many_steps_and_sequences(thk, orc, ctx):
     """The lm-head launch's last workgroup finishes the token (ticket counter zeroed for the next launch): 60 consecutive steps on
     two interleaved sequences give the tokens of the stand-alone finish_token launch, in graph replay and eagerly."""
     out = {}
-    for fold in (1, 0):
+    for fold in (1, 0, 2):       # 2: workgroup 0 is the one that waits - dispatched FIRST, it spins through the whole launch: the pick does not lean on the dispatch order
         for graph in (1, 0):
             m, om = make_pair(thk, orc, ctx, "TINY", n_seq=2, tunables={"fold_finish": fold, "use_graph": graph})
             om.close()
@@ -174,7 +174,27 @@ def test_folded_greedy_pick_over_many_steps_and_sequences(thk, orc, ctx):
             out[(fold, graph)] = (m.seq_get(0)[0].tolist(), m.seq_get(1)[0].tolist())
             assert len(out[(fold, graph)][0]) == 30
             m.close()
-    assert out[(1, 1)] == out[(0, 1)] == out[(1, 0)] == out[(0, 0)]
+    assert out[(1, 1)] == out[(0, 1)] == out[(1, 0)] == out[(0, 0)] == out[(2, 1)] == out[(2, 0)]
+
+
+def test_folded_pick_by_the_first_dispatched_workgroup_at_model_width(thk, ctx):
+    """fold_finish = 2 on the 7B-wide lm-head (V = 32000: 2048 workgroups, and with gemv_grid_head = 8192 four generations of them): workgroup 0 - on the device
+    before any other - waits for every key.  Same tokens as the default and as the stand-alone pick, no time-out: forward progress needs no dispatch order."""
+    shape = thk.ModelShape(n_layer=1)
+    outs = {}
+    for cfg in ({"fold_finish": 1}, {"fold_finish": 2}, {"fold_finish": 0}, {"fold_finish": 2, "gemv_grid_head": 8192}):
+        for k, v in cfg.items():
+            ctx.set_tunable(k, v)
+        try:
+            m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+        finally:
+            ctx.set_tunable("fold_finish", 1); ctx.set_tunable("gemv_grid_head", 0)
+        m.seq_set(0, 1, 0)
+        m.decode_steps(40, 0, advance=True)
+        outs[tuple(cfg.items())] = m.seq_get(0)[0].tolist()         # THK_ERR_STATE here if the in-launch wait had timed out
+        m.close()
+    vals = list(outs.values())
+    assert all(v == vals[0] and len(v) == 40 for v in vals)
 
 
 def test_device_step_clock(thk, ctx):

@@ -22,6 +22,7 @@ void default_tunables(thk_ctx* ctx) {
     for (const char* k : {"qkv", "wo", "w13", "w2"}) { ctx->tun[std::string("prefill_blocks_") + k] = 0; ctx->tun[std::string("prefill_tile_") + k] = 256; }   // blocks: 0 = auto (row-block-aligned shares where >= 192 workgroups remain, else 256); tile rows: 128 | 256
     ctx->tun["prefill_attn_mfma"] = 1;
     ctx->tun["prefill_slab_tokens"] = 256;   // prompt tokens per weight pass: 256 (eight token tiles, two half-steps per weight chunk) or 128 (rounds 1-4)
+    ctx->tun["prefill_wave_grid"] = 1;       // 256-token slabs: a wave owns half the tile's rows x half the slab's tokens (gemm_prefill_v3g_kernel) instead of a quarter of the rows x all tokens (v3h)
     ctx->tun["prefill_deferred_norm"] = 1;   // RMSNorm's per-token scalar is applied on the output side of the GEMM, so the residual reducers write the next
                                              // GEMM's image themselves: 9 launches per layer instead of 11 (thk_model_prefill.cpp)
     ctx->tun["prefill_packed"] = 1;       // prefill GEMMs stream tile images of the layer matrices (a second copy of the layer weights in HBM, built on

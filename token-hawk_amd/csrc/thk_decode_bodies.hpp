@@ -652,13 +652,18 @@ __device__ __forceinline__ void gemv_body(const GemvArgs& a, const int bid, cons
             // folded pick: the key crosses to another XCD inside this launch, so it is written through; nobody waits for it here
             if (a.fin.folded) st_agent_u64(a.block_best + bid, b); else a.block_best[bid] = b;
         }
-        // The greedy pick folded into this launch (round 4).  The workgroup with the HIGHEST index - dispatched last on its XCD,
-        // so it never holds a slot some not-yet-dispatched workgroup of its XCD needs - waits until every key slot is non-zero (a
-        // key is never 0 and the slots are zeroed again below), reduces them and finishes the token.  The other workgroups pay one
-        // fire-and-forget store: a first version in which every workgroup waited for its store's acknowledgement and then drew a
-        // ticket with a returning atomic lengthened the launch by 8 us (two memory round trips per workgroup on 1.6 generations of
-        // workgroups) - more than the finish_token launch and its boundary (4.3 + 2.0 us) cost.
-        if (a.fin.folded && bid == nblk - 1) {
+        // The greedy pick folded into this launch (round 4).  ONE workgroup waits until every key slot is non-zero (a key is never 0
+        // and the slots are zeroed again below), reduces them and finishes the token.  The other workgroups pay one fire-and-forget
+        // store: a first version in which every workgroup waited for its store's acknowledgement and then drew a ticket with a
+        // returning atomic lengthened the launch by 8 us (two memory round trips per workgroup on 1.6 generations of workgroups) -
+        // more than the finish_token launch and its boundary (4.3 + 2.0 us) cost.
+        // Forward progress does NOT depend on the order workgroups are dispatched in: the waiting workgroup holds one workgroup slot
+        // of one CU, every other slot of the device keeps taking the launch's remaining workgroups, so the keys arrive wherever
+        // the poller was placed (needs: the device can host two workgroups of this launch at once - true for any CU).  The
+        // dispatch order only decides how long the poller spins: folded == 1 picks the HIGHEST index (normally dispatched last:
+        // it spins for a few hundred ns), folded == 2 picks workgroup 0 (normally dispatched FIRST: it spins through the whole
+        // launch) - kept as a tested mode exactly to show that the result does not lean on the order (tunable fold_finish = 2).
+        if (a.fin.folded && bid == (a.fin.folded == 2 ? 0 : nblk - 1)) {
             __syncthreads();                     // wave 0's key store is issued; xs (the activation vector) is dead from here on
             finish_token_reduce<WPB * 64, true>(a.fin, a.block_best, nblk, reinterpret_cast<unsigned long long*>(xs));
         }

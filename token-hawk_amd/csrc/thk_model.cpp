@@ -249,7 +249,8 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->attn_waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
     m->kv_f16 = tun(ctx, "kv_f16") != 0;
     m->fold_embed = tun(ctx, "fold_embed") != 0;
-    m->fold_finish = tun(ctx, "fold_finish") != 0;
+    m->fold_finish = (int)tun(ctx, "fold_finish");   // 0 | 1 | 2
+    REQUIRE(ctx, m->fold_finish >= 0 && m->fold_finish <= 2, "fold_finish must be 0, 1 or 2");
     m->attn_tc_dyn = tun(ctx, "attn_tc_dyn") != 0;
     m->gain_alias = tun(ctx, "measure_gain_alias") != 0;
     m->var_qkv = resolve_variant(ctx, "qkv", (int)E); m->var_wo = resolve_variant(ctx, "wo", (int)E);

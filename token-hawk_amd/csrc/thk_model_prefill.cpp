@@ -150,7 +150,7 @@ static int prefill_slab(thk_model* m, SeqBuf& sb, const PrefillBufs& b, const in
     }
     PrefillPlan &pq = pl[0], &po = pl[1], &p13 = pl[2], &p2 = pl[3];
     const bool pk = !m->pk_w.empty() && m->pk_tiles[0] == pq.tile_rows && m->pk_tiles[1] == po.tile_rows && m->pk_tiles[2] == p13.tile_rows && m->pk_tiles[3] == p2.tile_rows;
-    pq.packed = po.packed = p13.packed = p2.packed = pk ? 1 : 0;
+    pq.packed = po.packed = p13.packed = p2.packed = (pk ? 1 : 0) | (tun(ctx, "prefill_wave_grid") != 0 ? 2 : 0);     // bit 1: 256-token slabs on the 2 x 2 wave grid (gemm_prefill_v3g_kernel)
     if (m->flags & THK_STAGE_EMBED) {
         HIPCHK(ctx, hipMemcpyAsync(b.tok, tokens, (size_t)M * 4, hipMemcpyHostToDevice, st));
         HIPCHK(ctx, hipStreamSynchronize(st));   // tokens may be a stack buffer

@@ -133,7 +133,7 @@ static int enqueue_step(thk_model* m, int seq, StepProf* prof) {
         f.block_best = m->block_best; f.nblocks = m->grid_head; f.st = sb.st; f.gen_log = sb.gen_log; f.log_cap = kGenLogCap; f.advance_ptr = sb.advance;
         f.n_ctx = T; f.clock_log = sb.clock_log;
         const bool fold = m->fold_finish && m->skip_kernel != 6;
-        if (fold) { a.fin = f; a.fin.folded = 1; }      // the launch's highest-numbered workgroup picks the token itself (key slots are zero between launches)
+        if (fold) { a.fin = f; a.fin.folded = m->fold_finish; }      // one workgroup of the launch (1: the highest-numbered, 2: workgroup 0) picks the token itself (key slots are zero between launches)
         MARK("norm_lmhead");
         if (m->skip_kernel != 6) HIPCHK(ctx, launch_gemv(GEMV_PRO_RMS, GEMV_EPI_HEAD, m->var_head, a, m->grid_head, nt, st));
         if (!fold) {

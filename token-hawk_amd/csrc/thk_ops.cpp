@@ -2,6 +2,7 @@
 // their WGSL, th.cpp:396-4351), explicit dimensions instead of baked shader constants.  Used by the parity tests per op;
 // the model level (thk_model.cpp) launches the fused forms directly.
 #include "thk_internal.hpp"
+#include <sched.h>
 #include <time.h>
 
 // ---------------------------------------------------------------- operators
@@ -193,13 +194,18 @@ int topk_enqueue_pinned(thk_ctx* ctx, const float* logits_dev, int64_t V, int32_
 }
 // The kernel's last act is a system-scope store of this call's epoch behind its keys: the host thread polls that word in its own memory
 // (a hipStreamSynchronize wake-up costs tens of microseconds per token); after 0.2 s of polling it falls back to the stream, so a fault
-// still surfaces as an error.
+// still surfaces as an error.  ctx->pinned_keys / topk_epoch are per CONTEXT and unlocked: like every other entry point (thk.h: "thread-compatible, not
+// thread-safe") thk_model_eval_topk is for one thread per context at a time - two models on one context take turns.
 int topk_wait_pinned(thk_ctx* ctx) {
     volatile unsigned long long* stamp = ctx->pinned_keys + 1024;
     const unsigned long long want = ctx->topk_epoch;
     timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
     for (unsigned spins = 0; *stamp != want; ++spins) {
+#if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
+#else
+        sched_yield();
+#endif
         if ((spins & 0xFFFu) == 0xFFFu) {
             timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
             if ((t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9 > 0.2) {

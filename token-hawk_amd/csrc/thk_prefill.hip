@@ -307,6 +307,7 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3_kernel(const _Float16*
             }                                                                                                          \
             if (i == SYNC_AT) {                                                                                        \
                 PF_T(1)                                                                                                \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* the fragment reads of the stage about to be refilled are back (hundreds of cycles old: free) - stated, not left to timing */ \
                 wait_vmcnt<(NST - 2) * LPS>();                 /* this wave's loads of chunk g+1 have landed (NST-2 chunks, real or dummy, were issued behind them) ... */ \
                 PF_T(2)                                                                                                \
                 __builtin_amdgcn_s_barrier();                  /* ... and everybody's; every wave holds chunk g in registers: its stage is free */ \
@@ -509,8 +510,200 @@ __global__ __launch_bounds__(256, 1) void gemm_prefill_v3h_kernel(const _Float16
             THK_MFMA_ONE(1, i, MTH)                                                                                    \
             __builtin_amdgcn_sched_barrier(0);                                                                         \
             if (i == SYNC_AT) {                                                                                        \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* step A's reads of tiles 4-7 from the stage about to be refilled are back (hundreds of cycles old: free) */ \
                 wait_vmcnt<(NST - 2) * LPS>();                 /* this wave's loads of chunk g+1 have landed ... */    \
                 __builtin_amdgcn_s_barrier();                  /* ... and everybody's; every wave holds chunk g's second half in registers: its stage is free */ \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+            if (i >= SYNC_AT && i < NM - 1) {                                                                          \
+                const int sl = i - SYNC_AT;                    /* behind the last chunk these reads fetch stale bytes nobody uses */ \
+                if (sl < RSLOTS) { _Pragma("unroll") for (int rr = sl * NRH / RSLOTS; rr < (sl + 1) * NRH / RSLOTS; ++rr) THK_READ_ONE(sbn, 0, rr, 0) } \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+                if (sl >= RSLOTS) {                                                                                    \
+                    _Pragma("unroll") for (int k = (sl - RSLOTS) * LT / TSLOTS; k < (sl - RSLOTS + 1) * LT / TSLOTS; ++k) \
+                        v3_issue_one<MT, NF, PK>(k, more, ximg, scratch, nx_sb, nx_xs, nx_w, nx_row0, R, C, wave);     \
+                }                                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+        }                                                                                                              \
+        buf = nbuf;                                                                                                    \
+        pend_more = more; pend_sb = nx_sb; pend_xs = nx_xs; pend_w = nx_w; pend_row0 = nx_row0;                         \
+        THK_PIN_ACC()                                                                                                  \
+        if (g + 1 == seg_end) {                            /* end of a row-block (or of the share): spill the tile */   \
+            flush(acc, seg);                                                                                           \
+            wait_vmcnt<0>();                               /* stores share the counter with the DMA queue: drain, then count afresh */ \
+            THK_ZERO_ACC()                                                                                             \
+            ++seg;                                                                                                     \
+            seg_end = seg_end + nchunks < g1 ? seg_end + nchunks : g1;                                                 \
+        }                                                                                                              \
+    }
+    int seg = 0, seg_end = (rbk_first + 1) * nchunks < g1 ? (rbk_first + 1) * nchunks : g1;
+    THK_ZERO_ACC()
+    wait_vmcnt<(NST - 1) * LPS>();                       // chunk g0 is in
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int rr = 0; rr < NRH; ++rr) THK_READ_ONE(lds, 0, rr, 0)
+    for (int g = g0;;) {
+        THK_STEP_A()
+        THK_STEP_B()
+        if (++g >= g1) break;
+    }
+#undef THK_STEP_A
+#undef THK_STEP_B
+#undef THK_MFMA_ONE
+#undef THK_READ_ONE
+#undef THK_ZERO_ACC
+#undef THK_PIN_ACC
+}
+
+// ---------------------------------------------------------------- 256-token slabs on a 2 x 2 WAVE GRID (round 6)
+// gemm_prefill_v3h_kernel gives every wave its own ROWS and all 256 tokens: a wave reads every token fragment of the chunk, so the X image leaves LDS four
+// times per chunk - per k-step and wave NF + 16 fragment reads (18 for a 256-row tile) for 16 NF MFMAs.  Here wave (wr, wt) owns HALF the tile's rows
+// (RF = 2 NF fragments) and HALF the slab's tokens (four tiles): a W fragment is read by two waves, an X fragment by two instead of four - RF + 8 reads per
+// k-step (12 for a 256-row tile, 10 for a 128-row one) for the same 8 RF MFMAs, same 64 NF AccVGPRs, same stages, same DMA schedule, same partial-slot format.
+// A chunk is still two half-steps, now split by K-STEP instead of by token half (one fragment set = one k-step of the wave's 2 x 2 block: 48 VGPRs):
+//   step A  k-step 0 from set 0;  between its MFMAs: the pending half of the previous refill's DMA, and the chunk's k-step 1 -> set 1 (same stage: no wait)
+//   step B  k-step 1 from set 1;  wait + the one barrier per chunk, the NEXT chunk's k-step 0 -> set 0, the DMA of chunk g + NST into the vacated stage
+// Per accumulator the order stays ks0.hi ks0.lo ks1.hi ks1.lo: bit-identical to gemm_prefill_v3h_kernel.
+template <int NF, bool PK, int NST = kNSTH>
+__global__ __launch_bounds__(256, 1) void gemm_prefill_v3g_kernel(const _Float16* __restrict__ w0, const _Float16* __restrict__ w1, const _Float16* __restrict__ w2,
+                                                                  const char* __restrict__ ximg, const int nchunks, const int per, const int rb_per_mat, const int rb_total,
+                                                                  const int R, const int C, float* __restrict__ part, const PrefillPlan plan) {
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    constexpr int MT = 8, TT = 4;                      // token tiles of the slab / of a wave
+    constexpr int RF = 2 * NF;                         // row fragments of a wave (half the tile)
+    constexpr int XI = MT * 32 * 64 * 2;
+    constexpr int TR = 128 * NF;
+    constexpr int WI = TR * 64;
+    constexpr int ST = XI + WI;
+    constexpr int LPS = MT + 2 * NF;                   // loads per wave per stage (the loader's split of a stage is the v3h one: who fetches is independent of who reads)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wt = wave & 1;           // row half, token half
+    const int li = lane & 31;
+    const int maxseg = plan.maxseg;
+    const size_t slot_floats = plan.slot_floats;
+    const int total = rb_total * nchunks;
+    const int g0 = blockIdx.x * per;
+    const int g1 = g0 + per < total ? g0 + per : total;
+    if (g0 >= g1) return;
+    const int ld_piece = swz_pos(lane >> 2, lane & 3);
+    const int rd0 = li * 64 + swz_pos(li, lane >> 5) * 16, rd1 = li * 64 + swz_pos(li, 2 + (lane >> 5)) * 16;
+    const int rbk_first = g0 / nchunks;
+    int i_mat = rbk_first / rb_per_mat, i_rbl = rbk_first % rb_per_mat, i_ch = g0 % nchunks, i_buf = 0;
+    auto flush = [&](f16v (&acc)[RF][TT], int seg) __attribute__((always_inline)) {    // accumulators -> partial slot, the fragment order of the other kernels (frag_decode with MT = 8)
+        float* slot = part + ((size_t)blockIdx.x * maxseg + seg) * slot_floats;
+#pragma unroll
+        for (int f = 0; f < RF; ++f)
+#pragma unroll
+            for (int t = 0; t < TT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f4*>(slot + (size_t)(((((wr * RF + f) * MT + (wt * TT + t)) * 4 + g) * 64 + lane) * 4)) =
+                        f4{acc[f][t][4 * g], acc[f][t][4 * g + 1], acc[f][t][4 * g + 2], acc[f][t][4 * g + 3]};
+    };
+    char* const scratch = lds + NST * ST + wave * 1024;   // where dummy loads land
+    int issued = g0;
+#pragma unroll
+    for (int s = 0; s < NST; ++s) {                      // the first NST chunks (dummy loads where the share is shorter: constant counts)
+        const bool more = issued < g1;
+        const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);
+        const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;
+        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + THK_WTILE(i_rbl, i_ch) * WI + lane * 16
+                                    : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);
+#pragma unroll
+        for (int k = 0; k < LPS; ++k) v3_issue_one<MT, NF, PK>(k, more, ximg, scratch, lds + s * ST, nx_xs, nx_w, i_rbl * TR + wave * 32 * NF + (lane >> 2), R, C, wave);
+        if (more) {
+            ++issued;
+            if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }
+        }
+    }
+    i_buf = 0;
+    h8 fa[2][RF], fbh[2][TT], fbl[2][TT];               // two sets: one per K-STEP of a chunk
+    constexpr int NM = 2 * RF * TT;                      // MFMAs per half-step per wave (hi and lo of one k-step)
+    constexpr int NRH = RF + 2 * TT;                     // fragment reads per half-step per wave
+    constexpr int SYNC_AT = NM / 4 - 1;                  // step B: the wait + barrier sit behind this MFMA
+    constexpr int SLOTS = NM - 1 - SYNC_AT;
+    constexpr int RSLOTS = SLOTS * 5 / 8 > 0 ? SLOTS * 5 / 8 : 1;
+    constexpr int TSLOTS = SLOTS - RSLOTS;
+    constexpr int LT = LPS / 2, LH = LPS - LT;           // a refill: LT loads in step B's tail, LH in the next step A's head
+    constexpr int AL = NM / 4;                           // step A: slots that carry the pending LH loads ...
+    constexpr int ARS = NM - AL - NM / 8;                // ... and the slots behind them that carry the reads of k-step 1 (back before step B's first MFMA)
+    bool pend_more = false;
+    char* pend_sb = lds;
+    const char *pend_xs = ximg, *pend_w = ximg;
+    int pend_row0 = 0;
+    f16v acc[RF][TT];
+#define THK_PIN_ACC()                                                      \
+    _Pragma("unroll") for (int f = 0; f < RF; ++f)                         \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t) asm volatile("" : "+a"(acc[f][t]));
+#define THK_ZERO_ACC()                                                     \
+    _Pragma("unroll") for (int f = 0; f < RF; ++f)                         \
+    _Pragma("unroll") for (int t = 0; t < TT; ++t)                         \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[f][t][i] = 0.f;     \
+    THK_PIN_ACC()
+    int buf = 0;
+    // fragment read number RR of k-step KS (the wave's RF row fragments, then hi/lo of its four token tiles) into set S
+#define THK_READ_ONE(SB, S, RR, KS)                                                                                    \
+    {                                                                                                                  \
+        const char* rp_ = (SB) + ((KS) == 0 ? rd0 : rd1);                                                              \
+        if ((RR) < RF) fa[S][(RR) < RF ? (RR) : 0] = *reinterpret_cast<const h8*>(rp_ + XI + (wr * RF + (RR)) * 2048); \
+        else if ((((RR) - RF) & 1) == 0) fbh[S][(RR) >= RF ? ((RR) - RF) >> 1 : 0] = *reinterpret_cast<const h8*>(rp_ + (wt * TT + (((RR) - RF) >> 1)) * 2048); \
+        else fbl[S][(RR) >= RF ? ((RR) - RF) >> 1 : 0] = *reinterpret_cast<const h8*>(rp_ + XI / 2 + (wt * TT + (((RR) - RF) >> 1)) * 2048); \
+    }
+    // MFMA number I of a half-step: hi | lo, then a sweep over all RF x TT accumulators (an accumulator is touched again only RF * TT MFMAs later)
+#define THK_MFMA_ONE(S, I)                                                                                             \
+    {                                                                                                                  \
+        const int hl = (I) / (RF * TT), t = ((I) % (RF * TT)) / RF, f = (I) % RF;                                      \
+        if (hl == 0) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][f], fbh[S][t], acc[f][t], 0, 0, 0);      \
+        else if (!kNoLo) acc[f][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][f], fbl[S][t], acc[f][t], 0, 0, 0);  \
+    }
+    // step A: k-step 0 from set 0; pending DMA half; this chunk's k-step 1 -> set 1
+#define THK_STEP_A()                                                                                                   \
+    {                                                                                                                  \
+        const char* const sbc = lds + buf * ST;                                                                        \
+        THK_PIN_ACC()                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                               \
+            THK_MFMA_ONE(0, i)                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            if (i < AL) {                                                                                              \
+                _Pragma("unroll") for (int k = LT + i * LH / AL; k < LT + (i + 1) * LH / AL; ++k)                      \
+                    v3_issue_one<MT, NF, PK>(k, pend_more, ximg, scratch, pend_sb, pend_xs, pend_w, pend_row0, R, C, wave); \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            } else if (i < AL + ARS) {                                                                                 \
+                _Pragma("unroll") for (int rr = (i - AL) * NRH / ARS; rr < (i - AL + 1) * NRH / ARS; ++rr) THK_READ_ONE(sbc, 1, rr, 1) \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+        }                                                                                                              \
+        THK_PIN_ACC()                                                                                                  \
+    }
+    // step B: k-step 1 from set 1; wait + barrier; the next chunk's k-step 0 -> set 0; refill the vacated stage
+#define THK_STEP_B()                                                                                                   \
+    {                                                                                                                  \
+        const bool more = issued < g1;                                 /* uniform */                                   \
+        const _Float16* nx_wm = i_mat == 0 ? w0 : (i_mat == 1 ? w1 : w2);                                              \
+        char* const nx_sb = lds + i_buf * ST;                                                                          \
+        const char* const nx_xs = ximg + (size_t)i_ch * XI + lane * 16;                                                \
+        const char* const nx_w = PK ? reinterpret_cast<const char*>(nx_wm) + THK_WTILE(i_rbl, i_ch) * WI + lane * 16 \
+                                    : reinterpret_cast<const char*>(nx_wm + (size_t)i_ch * kKC + ld_piece * 8);        \
+        const int nx_row0 = i_rbl * TR + wave * 32 * NF + (lane >> 2);                                                 \
+        i_buf = i_buf + 1 == NST ? 0 : i_buf + 1;                                                                      \
+        if (more) {                                                                                                    \
+            ++issued;                                                                                                  \
+            if (++i_ch == nchunks) { i_ch = 0; if (++i_rbl == rb_per_mat) { i_rbl = 0; ++i_mat; } }                    \
+        }                                                                                                              \
+        const int nbuf = buf + 1 == NST ? 0 : buf + 1;                                                                 \
+        const char* const sbn = lds + nbuf * ST;                                                                       \
+        THK_PIN_ACC()                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                               \
+            THK_MFMA_ONE(1, i)                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            if (i == SYNC_AT) {                                                                                        \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   /* this wave's k-step-1 reads of the stage about to be refilled are back (they are hundreds of cycles old: free) */ \
+                wait_vmcnt<(NST - 2) * LPS>();                 /* this wave's loads of chunk g+1 have landed ... */    \
+                __builtin_amdgcn_s_barrier();                  /* ... and everybody's; every wave holds chunk g's second k-step in registers: its stage is free */ \
                 __builtin_amdgcn_sched_barrier(0);                                                                     \
             }                                                                                                          \
             if (i >= SYNC_AT && i < NM - 1) {                                                                          \
@@ -609,7 +802,10 @@ __device__ __forceinline__ void ximg_store8(char* img, int MT, int tok, int col,
 // it out again (it reads the same word and derives the same power of two).
 constexpr float kSsqScale = 4294967296.f;    // 2^32: a 64-bit word holds sums up to 2^32, and a workgroup's share of a row with rms 1e-4 still has four digits
                                              // (2^24, rounds 3-4, left percent-level errors in 1/rms for residual streams of rms < 1e-3; advisor, round 4)
-__device__ __forceinline__ unsigned long long ssq_fixed(float ss) { return (unsigned long long)__float2ull_rn(ss * kSsqScale); }
+// RANGE: a token's sum of squares must stay below 2^32 (rms < 1024 at E = 4096, < 2896 at E = 512; LLaMA's residual stream with its outlier channels is
+// three orders of magnitude below) - the integer atomic would wrap silently beyond it.  One share is clamped to 2^62 so that a single huge row saturates
+// instead of wrapping; rows that large belong on prefill_deferred_norm = 0 (tests: test_prefill_deferred_norm_range).
+__device__ __forceinline__ unsigned long long ssq_fixed(float ss) { return (unsigned long long)__float2ull_rn(fminf(ss * kSsqScale, 4.611686e18f)); }
 __device__ __forceinline__ void ssq_add(unsigned long long* ssq, int tok, float ss) { atomicAdd(ssq + tok, ssq_fixed(ss)); }
 __device__ __forceinline__ float ssq_inv_of(unsigned long long v, int C) {
     const float ss = (float)((double)v * (1.0 / 4294967296.0));
@@ -856,9 +1052,23 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& plan
         if (e == hipSuccess) hipLaunchKernelGGL((gemm_prefill_v3h_kernel<NFV, PKV>), dim3(p.G), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, \
                                                 p.nchunks, p.per, p.rb_per_mat, p.rb_total, p.R, p.C, part, p);         \
     }
-    if (p.MT == 8) {                       // 129 .. 256 tokens: the two-half kernel
-        if (p.tile_rows == 128) { if (p.packed & 1) THK_V3HK(1, true) else THK_V3HK(1, false) }
-        else { if (p.packed & 1) THK_V3HK(2, true) else THK_V3HK(2, false) }
+#define THK_V3GK(NFV, PKV)                                                                                               \
+    {                                                                                                                    \
+        const size_t lds = (ximg_stage_bytes(8) + (size_t)NFV * 8192) * kNSTH + 4096;                                    \
+        static bool attr_done[kMaxDevices] = {};                                                                         \
+        const int dev = current_device();                                                                                \
+        if (!attr_done[dev]) { e = hipFuncSetAttribute((const void*)gemm_prefill_v3g_kernel<NFV, PKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[dev] = (e == hipSuccess); } \
+        if (e == hipSuccess) hipLaunchKernelGGL((gemm_prefill_v3g_kernel<NFV, PKV>), dim3(p.G), dim3(256), lds, st, w0, w1, w2, (const char*)ximg, \
+                                                p.nchunks, p.per, p.rb_per_mat, p.rb_total, p.R, p.C, part, p);         \
+    }
+    if (p.MT == 8) {                       // 129 .. 256 tokens: the two-half kernels (packed bit 1: the 2 x 2 wave grid, round 6)
+        if (p.packed & 2) {
+            if (p.tile_rows == 128) { if (p.packed & 1) THK_V3GK(1, true) else THK_V3GK(1, false) }
+            else { if (p.packed & 1) THK_V3GK(2, true) else THK_V3GK(2, false) }
+        } else {
+            if (p.tile_rows == 128) { if (p.packed & 1) THK_V3HK(1, true) else THK_V3HK(1, false) }
+            else { if (p.packed & 1) THK_V3HK(2, true) else THK_V3HK(2, false) }
+        }
         return e != hipSuccess ? e : hipGetLastError();
     }
     if (p.tile_rows == 128) switch (p.MT) {
@@ -875,6 +1085,7 @@ hipError_t launch_prefill_gemm(const uint16_t* const* W, const PrefillPlan& plan
 #undef THK_V3
 #undef THK_V3K
 #undef THK_V3HK
+#undef THK_V3GK
     return e != hipSuccess ? e : hipGetLastError();
 }
 hipError_t launch_prefill_reduce_store(const float* part, const PrefillPlan& p, float* Y, bool residual, hipStream_t st) {
