@@ -295,34 +295,60 @@ def extra_prefill_128(thk, model, shape, ctx, stream=None, torch=None):
             torch.cuda.synchronize()
             ev.append(e0.elapsed_time(e1))
         ev_ms = round(float(np.median(ev)), 3)
-    long_ms = None
-    if shape.n_ctx >= 512:                        # a 512-token prompt = four 128-token slabs, later slabs attend to the rows earlier ones cached
-        toks512 = np.concatenate([[1], np.random.default_rng(512).integers(3, shape.n_vocab, 511)]).astype(np.int32)
+    long_ms = long_ev_ms = None
+    M512 = 511
+    if shape.n_ctx >= 512:                        # a 512-token prompt (511 ids): one 256-token slab + one 255-token slab, the second attends to the rows the first cached
+        toks512 = np.concatenate([[1], np.random.default_rng(512).integers(3, shape.n_vocab, M512 - 1)]).astype(np.int32)
         tl = []
         for _ in range(3):
             model.reset_kv(0); ctx.sync()
             t0 = time.perf_counter(); model.prefill(toks512, 0); tl.append(time.perf_counter() - t0)
         long_ms = round(float(np.median(tl)) * 1e3, 3)
+        if stream is not None and torch is not None:
+            ev = []
+            for _ in range(3):
+                model.reset_kv(0); ctx.sync()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream); model.prefill(toks512, 0, want_logits=False); e1.record(stream)
+                torch.cuda.synchronize()
+                ev.append(e0.elapsed_time(e1))
+            long_ev_ms = round(float(np.median(ev)), 3)
     flops = 2.0 * (shape.weight_bytes(head=False) / 2) * M + 2.0 * shape.n_vocab * shape.n_embd
     # roofline of the prompt pass: the larger of one weight pass at the HBM peak and the MFMA time of the contraction as it is computed
-    # (f32 activations x f16 weights on f16 matrix cores = TWO f16 MFMAs per product, hi + lo halves of the activation: 2 x flops at the dense f16 peak)
+    # (f32 activations x f16 weights on f16 matrix cores = TWO f16 MFMAs per product, hi + lo halves of the activation: 2 x flops at the dense f16 peak).
+    # The fraction is taken against the HIP-EVENT time of the call (device time on the libthk stream) when it was measured: the host wall time of another
+    # loop, seconds apart and at another thermal state, came out SHORTER than the event time in round 5 - event_ms is the figure to quote.
+    t_meas = (ev_ms * 1e-3) if ev_ms else t
     t_hbm = shape.weight_bytes() / (HBM_PEAK_GBS * 1e9)
     t_mfma = 2.0 * flops / (MFMA_F16_PEAK_TFLOPS * 1e12)
     bound = "hbm" if t_hbm >= t_mfma else "mfma"
     t_roof = max(t_hbm, t_mfma)
-    roof = {"bound": bound, "achieved": round((shape.weight_bytes() / t / 1e9) if bound == "hbm" else (2.0 * flops / t / 1e12), 1),
-            "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_F16_PEAK_TFLOPS, "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(t_roof / t, 4),
+    roof512 = None
+    if long_ms is not None:
+        # 511 tokens = TWO weight passes (256 + 255 tokens); the contraction's hi/lo MFMA time of 511 tokens is the larger term
+        fl512 = 2.0 * (shape.weight_bytes(head=False) / 2) * M512 + 2.0 * shape.n_vocab * shape.n_embd
+        t512 = (long_ev_ms or long_ms) * 1e-3
+        th, tm = 2 * shape.weight_bytes(head=False) / (HBM_PEAK_GBS * 1e9) + shape.n_vocab * shape.n_embd * 2 / (HBM_PEAK_GBS * 1e9), 2.0 * fl512 / (MFMA_F16_PEAK_TFLOPS * 1e12)
+        b512 = "hbm" if th >= tm else "mfma"
+        roof512 = {"bound": b512, "achieved": round((2 * shape.weight_bytes(head=False) / t512 / 1e9) if b512 == "hbm" else (2.0 * fl512 / t512 / 1e12), 1),
+                   "peak": HBM_PEAK_GBS if b512 == "hbm" else MFMA_F16_PEAK_TFLOPS, "unit": "GB/s" if b512 == "hbm" else "TFLOP/s", "frac": round(max(th, tm) / t512, 4),
+                   "two_weight_passes_ms_at_hbm_peak": round(th * 1e3, 3), "hi_lo_mfma_ms_at_f16_dense_peak": round(tm * 1e3, 3), "time_basis": "event_ms" if long_ev_ms else "host wall",
+                   "traffic": None}
+    roof = {"bound": bound, "achieved": round((shape.weight_bytes() / t_meas / 1e9) if bound == "hbm" else (2.0 * flops / t_meas / 1e12), 1),
+            "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_F16_PEAK_TFLOPS, "unit": "GB/s" if bound == "hbm" else "TFLOP/s", "frac": round(t_roof / t_meas, 4),
+            "time_basis": "event_ms" if ev_ms else "host wall",
             "weight_pass_ms_at_hbm_peak": round(t_hbm * 1e3, 3), "hi_lo_mfma_ms_at_f16_dense_peak": round(t_mfma * 1e3, 3),
             "traffic": "profiles/r05_prefill_pmc_*.csv (FETCH_SIZE / WRITE_SIZE per launch of the same prompt; not collected live)",
             "clock_note": "the prompt chain runs at the package power limit: sclk 2.04-2.09 GHz at 1280-1290 W of 1400 W (1.85 GHz inside the GEMM launches) against the 2.4 GHz "
                           "the dense peak is quoted at - profiles/r05_clock_power.txt, builder-box samples, not measured in this run; at 1.85 GHz the hi/lo MFMA time is "
                           f"{round(t_mfma * 1e3 * 2.4 / 1.85, 3)} ms"}
     return {"workload": f"LLaMA-7B f16, {M}-token prompt prefill (n_past=0), 1 GPU, logits of the last token read back", "ms": round(t * 1e3, 3), "event_ms": ev_ms, "roofline": roof, "prompt_512_tokens_ms": long_ms,
+            "prompt_512_tokens_event_ms": long_ev_ms, "prompt_512_roofline": roof512, "prefill_wave_grid": int(ctx.get_tunable("prefill_wave_grid")),
             "ms_min": round(min(ts) * 1e3, 3), "tok_s": round(M / t, 1), "tflops": round(flops / t / 1e12, 2), "mfma_peak_tflops_f16_dense": 2500,
             "frac_of_mfma_peak": round(flops / t / 2.5e15, 4), "weight_pass_hbm_ms": round(shape.weight_bytes() / (HBM_PEAK_GBS * 1e9) * 1e3, 3),
             "first_call_ms": round(t_first * 1e3, 1), "timing": "host wall time around thk_model_prefill (host-to-device token copy and 128 KB logits read-back included), median of 5",
             "prefill_slab_tokens": int(ctx.get_tunable("prefill_slab_tokens")),
-            "prompt_512_note": "four 128-token slabs in rounds 1-4 (24.4-25.0 ms); since round 5 two slabs of 256 tokens = two weight passes (gemm_prefill_v3h_kernel)"}
+            "prompt_512_note": "four 128-token slabs in rounds 1-4 (24.4-25.0 ms); since round 5 two slabs of 256 tokens = two weight passes (round 5: gemm_prefill_v3h_kernel, 19.4 ms; round 6: gemm_prefill_v3g_kernel, 2 x 2 wave grid); checked against the oracle at full depth: parity_check.per_position.prefill_510"}
 
 
 def extra_decode_ctx2048(thk, ctx, stream, torch, kv_f16, steps=60, warmup=10):
@@ -556,11 +582,13 @@ def choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, log_li
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return int(flag.item()) == 1
 
-    def teardown():
-        if getattr(stage, "pp", None) is not None:
+    wedged = []      # transports whose set-up call never returned: their native objects are LEAKED, not destroyed (the stuck thread may still be inside them)
+
+    def teardown(leak=False):
+        if getattr(stage, "pp", None) is not None and not leak:
             ctx.lib.thk_pp_destroy(stage.pp)
         stage.pp = None
-        if getattr(stage, "peer", None) is not None:
+        if getattr(stage, "peer", None) is not None and not leak:
             ctx.lib.thk_peer_destroy(stage.peer)
         stage.peer = None
 
@@ -579,7 +607,9 @@ def choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, log_li
                 if agree(ok):                         # agree BEFORE the collective ncclCommInitRank inside thk_pp_create
                     torch.cuda.synchronize(dev)
                     uid_bytes = bytes(uid.cpu().numpy().tobytes())
-                    bounded(lambda: stage.attach_native_transport(rank, N, uid_bytes), args.setup_timeout_s, "ncclCommInitRank (thk_pp_create)")
+                    # the helper thread only CREATES the communicator; it is attached to the stage here, on the main thread, and only if the call came back in time -
+                    # a late return can then never hand a transport to a stage that has moved on
+                    stage.pp = bounded(lambda: stage.create_native_transport(rank, N, uid_bytes), args.setup_timeout_s, "ncclCommInitRank (thk_pp_create)")
                 else:
                     ok = False
             elif kind == "peer":
@@ -596,8 +626,19 @@ def choose_transport(args, stage, drv, ctx, dist, torch, dev, rank, N, S, log_li
                         ok, why = False, "the mailbox could only be allocated coarse-grained: not safe across GPUs"
                 else:
                     ok = False
+        except TimeoutError as e:
+            ok, why = False, f"TimeoutError: {e}"
+            wedged.append(kind)
         except Exception as e:
             ok, why = False, f"{type(e).__name__}: {e}"
+        stuck = torch.tensor([1 if kind in wedged else 0], device=ctl, dtype=torch.int32)
+        dist.all_reduce(stuck, op=dist.ReduceOp.MAX)
+        if int(stuck.item()):
+            # a set-up call that never returned holds runtime locks on SOME rank and may still touch the stage later: every rank drops the objects of this
+            # transport without destroying them, and the run stops here instead of building the next transport on top of a wedged thread
+            log_lines.append(f"{kind}: set-up did not return within {args.setup_timeout_s:.0f} s on some rank" + (f" (rank {rank}: {why})" if why else "") + " - aborting the run")
+            teardown(leak=True)
+            return None
         if not agree(ok):
             log_lines.append(f"{kind}: set-up failed on some rank" + (f" (rank {rank}: {why})" if why else ""))
             teardown()
@@ -1042,6 +1083,18 @@ def main():
                 builder["rocprof_frac"] = round(kp[dom]["alg_bytes"] / (builder["rocprof_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
             roof["traffic"] = builder.get("traffic")             # PMC HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE x2, committed summary)
             roof["builder_box"] = dict(builder, source="profiles/pmc_traffic.json, profiles/kernel_durations.json: rocprofv3 summaries committed by the builder, NOT measured in this run")
+            try:      # does the counter set describe the library this process loaded?  (size + sha256/16 recorded by tools/make_pmc_traffic.py)
+                import hashlib
+                rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("_binary")
+                blob = open(graft.LIB, "rb").read()
+                mine = {"libthk_so_bytes": len(blob), "libthk_so_sha256_16": hashlib.sha256(blob).hexdigest()[:16]}
+                roof["builder_box"]["binary_recorded"] = rec
+                roof["builder_box"]["binary_loaded"] = mine
+                roof["builder_box"]["binary_matches"] = bool(rec) and all(rec.get(k) == v for k, v in mine.items())
+                roof["builder_box"]["binary_size_matches"] = bool(rec) and rec.get("libthk_so_bytes") == mine["libthk_so_bytes"]     # a rebuild from the same sources keeps the size; the hash also pins the bytes
+            except Exception as e:
+                roof["builder_box"]["binary_matches"] = None
+                roof["builder_box"]["binary_note"] = str(e)
             # The eager figure above carries the 2-3 us dispatch gap of un-graphed launches.  What the kernel costs in the
             # configuration that is actually timed (graph replay) is measured as a difference: the same K-step loop, HIP
             # events on the same stream, on a second model instance whose graph omits that kernel.

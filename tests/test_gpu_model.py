@@ -531,6 +531,35 @@ def test_prefill_slab_edges_vs_oracle(thk, orc, ctx, E, H, M, n_past):
     m.close(); om.close()
 
 
+@pytest.mark.parametrize("rms", [1.0, 60.0, 1000.0])
+def test_prefill_deferred_norm_range(thk, ctx, rms):
+    """The deferred norm carries a token's sum of squares as 2^-32 fixed point in 64 bits (thk_prefill.hip, ssq_fixed): rows up to a sum of squares of 2^32
+    are inside its range - rms < 2896 at E = 512, < 1024 at E = 4096; LLaMA's residual stream with its outlier channels has rms of a few tens.  An embedding
+    table scaled to rms 1, 60 and 1000: the 9-launch prompt pass, the explicit-norm pass (prefill_deferred_norm = 0) and token-by-token decode
+    (RMSNorm in f32 inside the mat-vec prologue) agree on the logits."""
+    shape = thk.ModelShape(n_vocab=2048, n_embd=512, n_mult=256, n_head=8, n_layer=2, n_ctx=320)
+    rng = np.random.default_rng(int(rms))
+    table = (rng.standard_normal((shape.n_vocab, shape.n_embd)) * rms).astype(np.float16)
+    toks = np.concatenate([[1], rng.integers(3, 2048, 299)]).astype(np.int32)
+    out = {}
+    for name in ("deferred", "explicit", "decode"):
+        m = thk.Model(ctx, shape); m.fill_synthetic(); m.set_tensor("tok_embeddings.weight", table); m.finalize()
+        if name == "decode":
+            out[name], _ = m.eval(toks, 0)
+        else:
+            ctx.set_tunable("prefill_deferred_norm", 1 if name == "deferred" else 0)
+            try:
+                out[name] = m.prefill(toks, 0)
+            finally:
+                ctx.set_tunable("prefill_deferred_norm", 1)
+        m.close()
+    assert np.isfinite(out["deferred"]).all()
+    d1, d2 = float(np.abs(out["deferred"] - out["decode"]).max()), float(np.abs(out["explicit"] - out["decode"]).max())
+    print(f"\n[deferred-norm range] residual rms {rms:g}: deferred vs decode {d1:.3e}, explicit vs decode {d2:.3e}")
+    assert d1 < LOGIT_TOL and d2 < LOGIT_TOL
+    assert int(out["deferred"].argmax()) == int(out["decode"].argmax())
+
+
 def test_context_beyond_512(thk, orc, ctx):
     """n_ctx is a parameter, not the reference's compile-time 512 (th-llama.hpp:105): 1100 prompt tokens through the
     slab prefill, then decode steps at T > 1100, against the oracle fed token by token."""

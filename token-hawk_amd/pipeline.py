@@ -163,13 +163,18 @@ class HipStage:
         if recv_rows:
             ctx.check(lib.thk_peer_recv_bulk(self.peer, seq, self._bulk_buf.ptr, recv_rows * E * 4), "thk_peer_recv_bulk")
 
-    def attach_native_transport(self, rank: int, world: int, unique_id: bytes):
-        """Use libthk's own RCCL point-to-point path (thk_pp_*) instead of torch.distributed P2P ops."""
+    def create_native_transport(self, rank: int, world: int, unique_id: bytes):
+        """thk_pp_create (ncclCommInitRank inside: collective, may block) -> the handle; nothing of the stage is touched, so the call may run on a helper
+        thread that the caller gives up on."""
         import ctypes as C
         ctx = self.model.ctx
         pp = C.c_void_p()
         ctx.check(ctx.lib.thk_pp_create(ctx.h, world, rank, unique_id, C.byref(pp)), "thk_pp_create")
-        self.pp = pp
+        return pp
+
+    def attach_native_transport(self, rank: int, world: int, unique_id: bytes):
+        """Use libthk's own RCCL point-to-point path (thk_pp_*) instead of torch.distributed P2P ops."""
+        self.pp = self.create_native_transport(rank, world, unique_id)
 
     def native_exchange(self, sends, recvs):
         """sends/recvs: lists of (kind, seq, peer), kind in {'hidden','token'}; one grouped RCCL step."""
