@@ -104,6 +104,29 @@ def test_native_rccl_hand_off_between_two_stages(thk, orc, ctx):
     gf, nf, pf = full.seq_get(0)
     gb, nb, pb = sb.seq_get(0)
     assert nf == nb == 6 and pf == pb == 6 and gf.tolist() == gb.tolist()
+    # round 6: the prompt pass per stage - the M x E rows stage A leaves travel to stage B's buffer as ONE thk_pp message (a bandwidth message: 0.8 MB here,
+    # 8 MB in the second round below), stage B finishes the pass; logits of the un-split prompt pass
+    E, M = shape.n_embd, 40
+    toks = np.concatenate([[1], np.random.default_rng(5).integers(3, shape.n_vocab, M - 1)]).astype(np.int32)
+    rows_a, rows_b = thk.Buffer(ctx, M * E * 4), thk.Buffer(ctx, M * E * 4)
+    for mm in (full, sa, sb):
+        mm.reset_kv(0)
+    lf = full.prefill(toks, 0)
+    sa.prefill_stage(toks, rows_a, M, 0)
+    ctx.check(lib.thk_pp_group_begin(pp), "group_begin")
+    ctx.check(lib.thk_pp_send(pp, C.c_void_p(rows_a.ptr), M * E * 4, 0), "send rows")
+    ctx.check(lib.thk_pp_recv(pp, C.c_void_p(rows_b.ptr), M * E * 4, 0), "recv rows")
+    ctx.check(lib.thk_pp_group_end(pp), "group_end")
+    ls = sb.prefill_stage(None, rows_b, M, 0, want_logits=True)
+    assert np.abs(ls - lf).max() < 1e-4 and int(ls.argmax()) == int(lf.argmax())
+    big = np.random.default_rng(6).standard_normal(2 * 1024 * 1024).astype(np.float32)      # 8 MB = 511 x 4096 x 4: the 7B prompt's message size
+    src, dst = ctx.from_numpy(big), ctx.alloc(big.nbytes)
+    ctx.check(lib.thk_pp_group_begin(pp), "group_begin")
+    ctx.check(lib.thk_pp_send(pp, C.c_void_p(src.ptr), big.nbytes, 0), "send 8 MB")
+    ctx.check(lib.thk_pp_recv(pp, C.c_void_p(dst.ptr), big.nbytes, 0), "recv 8 MB")
+    ctx.check(lib.thk_pp_group_end(pp), "group_end")
+    ctx.sync()
+    assert (dst.download(np.float32, big.size) == big).all()
     assert lib.thk_pp_destroy(pp) == 0
     for m in (full, sa, sb):
         m.close()

@@ -83,9 +83,16 @@ __global__ __launch_bounds__(256) void peer_wait_kernel(const u64* slot, int n_w
     if (n_words == 0 && threadIdx.x == 0)
         *reinterpret_cast<unsigned*>(dst) = __hip_atomic_load(reinterpret_cast<const unsigned*>(slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-// bulk payload: 16-byte pieces, grid-stride; the flag travels in a kernel of its own behind this one
-__global__ __launch_bounds__(256) void peer_bulk_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+// bulk payload, grid-stride over 8-byte words; the flag travels in a kernel of its own behind this one.  The mailbox side of the copy uses the same
+// system-scope accesses as the small payloads above (PUSH: stores into the NEXT stage's mailbox; !PUSH: loads from this stage's own mailbox, which
+// another GPU wrote): no cached copy on either side is trusted, whatever flavour of fine-grained memory the mailbox got
+template <bool PUSH>
+__global__ __launch_bounds__(256) void peer_bulk_copy_kernel(const u64* __restrict__ src, u64* __restrict__ dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        if (PUSH) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        else dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (PUSH) { __threadfence_system(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }      // every thread's stores are on their way out before the kernel ends; the flag kernel follows on the stream
 }
 __global__ void peer_bulk_flag_kernel(u64* flag, u64* sent) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -204,14 +211,14 @@ static int peer_bulk(thk_peer* p, int32_t seq, void* buf, size_t bytes, bool sen
     PEERCHK(p->ctx, hipSetDevice(thk::ctx_device(p->ctx)));
     hipStream_t st = (hipStream_t)thk_ctx_stream(p->ctx);
     u64* cnt = p->counters + ((size_t)seq * 3 + THK_PEER_BULK) * 2;
-    const size_t n16 = bytes / 16;
-    const int grid = (int)std::min<size_t>(1024, (n16 + 255) / 256);
+    const size_t n8 = bytes / 8;
+    const int grid = (int)std::min<size_t>(1024, (n8 + 255) / 256);
     if (send) {
-        hipLaunchKernelGGL(peer_bulk_copy_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)buf, (uint4*)(p->next_box + p->bulk_off(seq)), n16);
+        hipLaunchKernelGGL(peer_bulk_copy_kernel<true>, dim3(grid), dim3(256), 0, st, (const u64*)buf, p->next_box + p->bulk_off(seq), n8);
         hipLaunchKernelGGL(peer_bulk_flag_kernel, dim3(1), dim3(64), 0, st, p->next_box + p->flag_off(seq, THK_PEER_BULK), cnt);
     } else {
         hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(256), 0, st, (const u64*)nullptr, -1, (u64*)nullptr, (const u64*)(p->box + p->flag_off(seq, THK_PEER_BULK)), cnt + 1, p->err);
-        hipLaunchKernelGGL(peer_bulk_copy_kernel, dim3(grid), dim3(256), 0, st, (const uint4*)(p->box + p->bulk_off(seq)), (uint4*)buf, n16);
+        hipLaunchKernelGGL(peer_bulk_copy_kernel<false>, dim3(grid), dim3(256), 0, st, (const u64*)(p->box + p->bulk_off(seq)), (u64*)buf, n8);
     }
     PEERCHK(p->ctx, hipGetLastError());
     return THK_OK;
