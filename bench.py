@@ -891,10 +891,28 @@ def main():
                     kv_fill["ring_revolutions"] = T - 1
                     if args.kv_fill == "both":
                         picks["ring"] = first_pick()
-                if args.kv_fill in ("both", "prefill") and T > 1:
+                pf_ok = args.kv_fill in ("both", "prefill") and T > 1
+                if pf_ok:
+                    # pre-flight, agreed by all ranks BEFORE any row message is posted: tile images + workspace (the one step of the prefill fill that can
+                    # fail synchronously - memory); a rank that cannot prepare keeps every rank on the ring-filled caches instead of leaving peers in a receive
+                    try:
+                        stage.model.prepare_prefill()      # also keeps the one-off cost out of the timed fill
+                        mine = 1
+                    except Exception as e:
+                        mine = 0
+                        log(f"[bench r{rank}] prefill fill not possible on this rank: {e}")
+                    flag = torch.tensor([mine], dtype=torch.int32, device=ctl)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    pf_ok = bool(int(flag.item()))
+                    if not pf_ok:
+                        kv_fill["prefill_skipped"] = "thk_model_prepare_prefill failed on some rank (see stderr); the caches are the ring-filled ones"
+                        if args.kv_fill == "prefill":      # nothing filled the caches yet
+                            for s in range(S):
+                                stage.set_seq(s, int(prompts[0, s]), 0)
+                            drv.run(T - 1, advance=True, forced_tokens=prompts[:T - 1])
+                if pf_ok:
                     for s in range(S):
                         model.reset_kv(s)
-                    stage.model.prepare_prefill()          # tile images + workspace outside the timed fill (first_call cost reported separately)
                     settle(); t0f = time.perf_counter()
                     drv.prefill(prompts[:T - 1], 0, feed_back=False)
                     settle(); kv_fill["prefill_s"] = round(time.perf_counter() - t0f, 4)
