@@ -740,6 +740,28 @@ def test_prefill_256_token_slabs_equal_128_token_slabs(thk, dims, M, n_past):
     assert np.abs(nxt[256] - nxt[128]).max() < 5e-5
 
 
+@pytest.mark.parametrize("dims", [(512, 8), (4096, 32), (5120, 40)], ids=["tiny-width", "7B-width", "13B-width"])
+def test_prefill_wave_grid_equals_round5_slab_kernel_bit_for_bit(thk, dims):
+    """gemm_prefill_v3g_kernel (round 6: a wave owns half the tile's rows x half the slab's tokens, half-steps by k-step) accumulates every output element in the order
+    gemm_prefill_v3h_kernel does (ks0.hi ks0.lo ks1.hi ks1.lo per chunk, chunks in share order, shares summed in workgroup order by the same reducers): the logits of a
+    300-token prompt (one full slab + a 44-token tail) and of a 200-token one (pad tiles) are the same BITS with prefill_wave_grid = 1 and 0."""
+    E, H = dims
+    shape = thk.ModelShape(n_vocab=2048, n_embd=E, n_mult=256, n_head=H, n_layer=2, n_ctx=320)
+    rng = np.random.default_rng(E)
+    with thk.Context(0) as ctx:
+        m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+        for M in (300, 200):
+            toks = np.concatenate([[1], rng.integers(3, 2048, M - 1)]).astype(np.int32)
+            out = {}
+            for wg in (1, 0):
+                ctx.set_tunable("prefill_wave_grid", wg)
+                m.reset_kv(0)
+                out[wg] = m.prefill(toks, 0)
+            ctx.set_tunable("prefill_wave_grid", 1)
+            assert np.array_equal(out[0], out[1]), (dims, M, float(np.abs(out[0] - out[1]).max()))
+        m.close()
+
+
 def test_prefill_256_token_slab_with_f16_kv_cache_and_generic_attention(thk):
     """The eight-tile slab with the binary16 K/V cache option (the reducer rounds the rows it appends, attention widens them) and with the generic causal
     attention (`prefill_attn_mfma = 0`: attn_body with 200 queries, then an image launch of eight tiles): both against 128-token slabs."""
