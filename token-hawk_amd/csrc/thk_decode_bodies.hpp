@@ -748,8 +748,8 @@ __device__ __forceinline__ void gemv_quarter_body(const GemvArgs& a, const int b
 }
 // ---------------------------------------------------------------- attention (decode)
 // grid = H * nsplit blocks; block (h, s) owns positions [s*tc, (s+1)*tc) of head h.
-// A position's head slice is D contiguous floats; D/4 lanes x float4 cover it, so a wave-instruction fetches PPW = 64/(D/4)
-// positions of K (and of V).  Each wave runs an online softmax over its positions, the waves are merged through LDS, and the block
+// A position's head slice is D contiguous elements; D/EPL lanes x 16 bytes cover it (EPL = 4 f32 elements, or 8 binary16 ones: KvLane / AttnGeo below),
+// so a wave-instruction fetches PPW = 64/(D/EPL) positions of K (and of V).  Each wave runs an online softmax over its positions, the waves are merged through LDS, and the block
 // writes (m, l, o[D]) for the split (or the normalised output when nsplit == 1).
 // Scores: S = (q.k) * 1/sqrt(D) scaled after the sum (th.cpp:527-529, th-llama.cpp:518); softmax K10 th.cpp:1901-1957.
 // WAVES waves per block share one (head, split): more waves = fewer positions per wave, so every wave needs a single load batch
