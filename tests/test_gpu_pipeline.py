@@ -226,6 +226,41 @@ def test_driver_with_peer_mailbox_transport_single_rank_ring(thk, orc):
     stage.model.close(); ctx.close()
 
 
+def test_peer_bulk_slot_round_trip_and_argument_errors(thk):
+    """thk_peer_send_bulk / thk_peer_recv_bulk (round 6) on a single-stage ring (the stage is its own successor): the rows of a prompt pass go through the sequence's
+    bulk slot of the mailbox and come back bit for bit, twice (flags only grow), for two sequences; sizes that are not multiples of 16 bytes, exceed the slot
+    (n_ctx x n_embd x 4) or come before thk_peer_connect are refused with a message."""
+    import ctypes as C
+    import torch
+    from token_hawk_amd.pipeline import HipStage
+    dev = torch.device("cuda", 0)
+    ctx = thk.Context(0)
+    lib = ctx.lib
+    stage = HipStage(thk, ctx, thk.TINY, 0, 1, 2, dev)
+    stage.attach_peer_transport(2)
+    E, n_ctx = thk.TINY.n_embd, thk.TINY.n_ctx
+    src, dst = thk.Buffer(ctx, n_ctx * E * 4), thk.Buffer(ctx, n_ctx * E * 4)
+    assert lib.thk_peer_send_bulk(stage.peer, 0, C.c_void_p(src.ptr), 1024) != 0 and b"connect" in lib.thk_last_error(ctx.h)
+    stage.connect_peer(None)
+    rng = np.random.default_rng(3)
+    for rnd in range(2):
+        for seq, rows in ((0, n_ctx), (1, 17)):
+            a = rng.standard_normal(rows * E).astype(np.float32)
+            src.upload(a)
+            dst.upload(np.zeros(rows * E, np.float32))
+            ctx.check(lib.thk_peer_send_bulk(stage.peer, seq, C.c_void_p(src.ptr), a.nbytes), "send_bulk")
+            ctx.check(lib.thk_peer_recv_bulk(stage.peer, seq, C.c_void_p(dst.ptr), a.nbytes), "recv_bulk")
+            stage.peer_check()
+            assert np.array_equal(dst.download(np.float32, rows * E), a), (rnd, seq)
+    for bad in (24, n_ctx * E * 4 + 16, 0):
+        assert lib.thk_peer_send_bulk(stage.peer, 0, C.c_void_p(src.ptr), bad) != 0
+        assert lib.thk_peer_recv_bulk(stage.peer, 0, C.c_void_p(dst.ptr), bad) != 0
+    assert lib.thk_peer_send_bulk(stage.peer, 2, C.c_void_p(src.ptr), 1024) != 0      # no such sequence
+    stage.peer_check()                                                                 # refused calls enqueue nothing and raise no flag
+    lib.thk_peer_destroy(stage.peer)
+    stage.model.close(); ctx.close()
+
+
 def test_bench_two_ranks_share_one_gpu():
     """`bench.py --gpus 2 --ranks-share-gpu`: the benchmark's whole N = 2 flow with REAL stages in two processes (self-launch through
     torch.distributed.run, two HipStages of the tiny model on cuda:0, process group over gloo, transport chosen by the hand-off
