@@ -346,7 +346,8 @@ int thk_peer_send(thk_peer* p, int32_t seq, int kind);   /* kind: THK_PEER_HIDDE
 int thk_peer_recv(thk_peer* p, int32_t seq, int kind);   /* into thk_model_hidden_in | thk_model_token_dev */
 /* Bulk hand-off (round 6): `bytes` of a caller-owned device buffer - the f32 [n_tokens, n_embd] rows thk_model_prefill_stage leaves for the
  * next stage - through the sequence's bulk slot of the mailbox (capacity n_ctx * n_embd * 4 bytes per sequence; bytes % 16 == 0).  A slot
- * holds ONE payload: send the same sequence's next prompt only after the consumer has taken this one (synchronise + fence across ranks). */
+ * holds ONE payload: send the same sequence's next prompt only after the consumer has taken this one (synchronise + fence across ranks).
+ * A receive whose wait times out (~2 s) copies nothing and raises the sticky error word thk_peer_check reports. */
 int thk_peer_send_bulk(thk_peer* p, int32_t seq, const void* src_dev, size_t bytes);
 int thk_peer_recv_bulk(thk_peer* p, int32_t seq, void* dst_dev, size_t bytes);
 int thk_peer_check(thk_peer* p);                         /* THK_ERR_STATE once a wait has timed out: sticky - send / recv refuse from then on, destroy and recreate */

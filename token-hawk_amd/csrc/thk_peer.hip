@@ -27,7 +27,7 @@
 //     thk_peer_memory_kind says so (then only same-GPU rings are safe - what tests/test_gpu_pipeline.py runs).
 //   * Bulk payloads (round 6: the [n_tokens, E] rows a stage's prompt pass hands to the next stage, thk_model_prefill_stage) have a slot of
 //     their own per sequence (n_ctx * E * 4 bytes) and a flag of their own: a wide copy kernel stores the rows into the next stage's slot,
-//     a one-thread kernel BEHIND it on the stream raises the flag (the end of the copy kernel is the release point for fine-grained memory);
+//     a one-thread kernel BEHIND it on the stream raises the flag (the copy kernel's threads fence their system-scope stores before it ends);
 //     the consumer's one-workgroup wait kernel is followed by a wide copy out of its own mailbox.  Flow control: a sequence's bulk slot is
 //     written once per prompt; the caller synchronises + fences across ranks before the same sequence's next prompt (PipelineDriver.prefill).
 // Reference: none - the reference is single-device.
@@ -86,8 +86,11 @@ __global__ __launch_bounds__(256) void peer_wait_kernel(const u64* slot, int n_w
 // bulk payload, grid-stride over 8-byte words; the flag travels in a kernel of its own behind this one.  The mailbox side of the copy uses the same
 // system-scope accesses as the small payloads above (PUSH: stores into the NEXT stage's mailbox; !PUSH: loads from this stage's own mailbox, which
 // another GPU wrote): no cached copy on either side is trusted, whatever flavour of fine-grained memory the mailbox got
+// err (!PUSH): the error word of the wait kernel ahead of this one on the stream - after a time-out nothing arrived, so nothing is copied (the destination keeps
+// what it held; thk_peer_check reports the failure)
 template <bool PUSH>
-__global__ __launch_bounds__(256) void peer_bulk_copy_kernel(const u64* __restrict__ src, u64* __restrict__ dst, size_t n8) {
+__global__ __launch_bounds__(256) void peer_bulk_copy_kernel(const u64* __restrict__ src, u64* __restrict__ dst, size_t n8, const unsigned* err) {
+    if (!PUSH && err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
         if (PUSH) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         else dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -214,11 +217,11 @@ static int peer_bulk(thk_peer* p, int32_t seq, void* buf, size_t bytes, bool sen
     const size_t n8 = bytes / 8;
     const int grid = (int)std::min<size_t>(1024, (n8 + 255) / 256);
     if (send) {
-        hipLaunchKernelGGL(peer_bulk_copy_kernel<true>, dim3(grid), dim3(256), 0, st, (const u64*)buf, p->next_box + p->bulk_off(seq), n8);
+        hipLaunchKernelGGL(peer_bulk_copy_kernel<true>, dim3(grid), dim3(256), 0, st, (const u64*)buf, p->next_box + p->bulk_off(seq), n8, (const unsigned*)nullptr);
         hipLaunchKernelGGL(peer_bulk_flag_kernel, dim3(1), dim3(64), 0, st, p->next_box + p->flag_off(seq, THK_PEER_BULK), cnt);
     } else {
         hipLaunchKernelGGL(peer_wait_kernel, dim3(1), dim3(256), 0, st, (const u64*)nullptr, -1, (u64*)nullptr, (const u64*)(p->box + p->flag_off(seq, THK_PEER_BULK)), cnt + 1, p->err);
-        hipLaunchKernelGGL(peer_bulk_copy_kernel<false>, dim3(grid), dim3(256), 0, st, (const u64*)(p->box + p->bulk_off(seq)), (u64*)buf, n8);
+        hipLaunchKernelGGL(peer_bulk_copy_kernel<false>, dim3(grid), dim3(256), 0, st, (const u64*)(p->box + p->bulk_off(seq)), (u64*)buf, n8, (const unsigned*)p->err);
     }
     PEERCHK(p->ctx, hipGetLastError());
     return THK_OK;
