@@ -78,7 +78,7 @@ def test_tiny_model_every_token_vs_oracle(thk, orc, ctx, splits, use_graph):
 R03_STEP = {"attn_tc_dyn": 0, "fold_finish": 0, "attn_splits": 4}     # the launch geometry of round 3's step
 
 
-@pytest.mark.parametrize("tunables", [{"attn_waves": 4}, {"attn_waves": 4, "attn_splits": 8}, {"fold_embed": 0}, {"fold_embed": 0, "use_graph": 0},
+@pytest.mark.parametrize("tunables", [{"attn_waves": 4}, {"attn_waves": 4, "attn_splits": 8}, {"attn_waves": 8}, {"attn_waves": 8, "attn_splits": 8}, {"fold_embed": 0}, {"fold_embed": 0, "use_graph": 0},
                                       {"attn_tc_dyn": 0}, {"attn_tc_dyn": 0, "attn_waves": 4},
                                       {"fold_finish": 0}, {"fold_finish": 0, "use_graph": 0}, {"fold_finish": 1, "use_graph": 0}, R03_STEP,
                                       {"gemv_grid_qkv": 5, "gemv_grid_wo": 3, "gemv_grid_w13": 7, "gemv_grid_w2": 1, "gemv_grid_head": 11}])
@@ -599,6 +599,36 @@ def test_context_beyond_512(thk, orc, ctx):
         assert np.abs(lg - lo).max() < LOGIT_TOL
         assert int(lg.argmax()) == orc.greedy(lo)
     m.close()
+
+
+def test_long_f32_cache_takes_16_wave_attention_workgroups(thk, orc, ctx):
+    """attn_waves = 0 (auto, round 6): an f32 cache longer than 1024 rows with D = 128 runs attention with 16 waves per workgroup (a 256-position split = one round,
+    every wave's single K/V batch in flight at once).  One 7B-wide layer, a 1536-row cache, 1100 prompt tokens through the slab prefill, then decode steps at
+    T = 1101.. against the ORACLE fed token by token - and the same steps with attn_waves = 8 (the pipelined two-round kernel) agree to rounding."""
+    shape = thk.ModelShape(n_vocab=2048, n_embd=4096, n_mult=256, n_head=32, n_layer=1, n_ctx=1536)
+    oshape = orc.ModelShape(n_vocab=2048, n_embd=4096, n_mult=256, n_head=32, n_layer=1, n_ctx=1536)
+    rng = np.random.default_rng(1536)
+    toks = np.concatenate([[1], rng.integers(3, 2048, 1103)]).astype(np.int32)
+    out = {}
+    for aw in (0, 8):
+        ctx.set_tunable("attn_waves", aw)
+        try:
+            m = thk.Model(ctx, shape); m.fill_synthetic(); m.finalize()
+        finally:
+            ctx.set_tunable("attn_waves", 0)
+        m.prefill(toks[:1100], 0, want_logits=False)
+        out[aw] = [m.eval([int(toks[i])], i)[0] for i in (1100, 1101, 1102)]
+        m.close()
+    om = orc.OracleModel(oshape); om.fill_synthetic()
+    with fast_oracle(orc, True) as fl:
+        for i in range(1100):
+            om.eval(int(toks[i]), i, want_logits=False, flags=fl)
+        for k, i in enumerate((1100, 1101, 1102)):
+            lo, _ = om.eval(int(toks[i]), i, flags=fl)
+            assert np.abs(out[0][k] - lo).max() < LOGIT_TOL, (i, float(np.abs(out[0][k] - lo).max()))
+            assert int(out[0][k].argmax()) == orc.greedy(lo)
+            assert np.abs(out[0][k] - out[8][k]).max() < 2e-5
+    om.close()
 
 
 @pytest.mark.parametrize("dims", [(512, 8, 2), (4096, 32, 2)], ids=["tiny-width", "7B-width"])

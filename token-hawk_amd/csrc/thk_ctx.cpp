@@ -36,7 +36,7 @@ void default_tunables(thk_ctx* ctx) {
     ctx->tun["attn_splits"] = 0;          // context splits per head: 0 = auto (4; 8 when n_ctx > 1024), or 1, 2, 4, 8
     ctx->tun["attn_tc_dyn"] = 1;          // 1 = the splits partition the live context T (tc computed on the device), 0 = the cache capacity n_ctx
     ctx->tun["fold_finish"] = 1;          // the lm-head launch's last workgroup reduces the arg-max keys and finishes the token (no launch of its own)
-    ctx->tun["attn_waves"] = 8;           // waves per attention block (4 or 8)
+    ctx->tun["attn_waves"] = 0;           // waves per attention block: 0 = auto (8; 16 for f32 caches longer than 1024 rows), 4 | 8 | 16
     ctx->tun["fold_embed"] = 1;           // the embedding row is fetched by layer 0's qkv prologue instead of a launch of its own
     ctx->tun["use_graph"] = 1;            // replay a captured hipGraph per decode step
     ctx->tun["measure_skip_kernel"] = 0;  // bench.py: marginal cost of one kernel = step time with minus without it (results are garbage then);

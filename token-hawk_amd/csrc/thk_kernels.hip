@@ -281,7 +281,7 @@ hipError_t launch_attn_decode(const AttnArgs& a, hipStream_t st) {
     const bool w8 = a.waves == 8;
     switch (a.D) {
         case 64: if (w8) launch_attn_dw<64, 8>(a, grid, st); else launch_attn_dw<64, 4>(a, grid, st); break;
-        case 128: if (w8) launch_attn_dw<128, 8>(a, grid, st); else launch_attn_dw<128, 4>(a, grid, st); break;
+        case 128: if (a.waves == 16) launch_attn_dw<128, 16>(a, grid, st); else if (w8) launch_attn_dw<128, 8>(a, grid, st); else launch_attn_dw<128, 4>(a, grid, st); break;
         case 256: if (w8) launch_attn_dw<256, 8>(a, grid, st); else launch_attn_dw<256, 4>(a, grid, st); break;
         default: return hipErrorInvalidValue;
     }

@@ -246,8 +246,14 @@ extern "C" int thk_model_finalize(thk_model* m) {
     m->nt = true;
     m->use_graph = tun(ctx, "use_graph") != 0;
     m->skip_kernel = (int)tun(ctx, "measure_skip_kernel");
-    m->attn_waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
     m->kv_f16 = tun(ctx, "kv_f16") != 0;
+    {   // waves per attention workgroup.  0 = auto: 8 - or 16 for an f32 cache longer than 1024 rows (D = 128): a split of 256 positions is then ONE round of the workgroup,
+        // every wave issues its single K/V batch at once (round 6, same-box A/B at T = 2048: step 2.6506 -> 2.6163 ms; the binary16 cache and T = 512 are faster with 8)
+        const int64_t aw = tun(ctx, "attn_waves");
+        REQUIRE(ctx, aw == 0 || aw == 4 || aw == 8 || aw == 16, "attn_waves must be 0 (auto), 4, 8 or 16");
+        REQUIRE(ctx, aw != 16 || D == 128, "attn_waves = 16 exists for head dimension 128 only");
+        m->attn_waves = aw != 0 ? (int)aw : ((T > 1024 && !m->kv_f16 && D == 128) ? 16 : 8);
+    }
     m->fold_embed = tun(ctx, "fold_embed") != 0;
     m->fold_finish = (int)tun(ctx, "fold_finish");   // 0 | 1 | 2
     REQUIRE(ctx, m->fold_finish >= 0 && m->fold_finish <= 2, "fold_finish must be 0, 1 or 2");

@@ -75,7 +75,7 @@ extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache
     AttnArgs a{};
     a.q = q; a.kcache = kcache; a.vcache = vcache; a.pos_ptr = nullptr; a.pos_val = (int)T - 1;
     a.H = (int)H; a.D = (int)D; a.nsplit = nsplit; a.tc = (int)((T + nsplit - 1) / nsplit);
-    a.scale = 1.0f / sqrtf((float)D); a.waves = tun(ctx, "attn_waves") == 4 ? 4 : 8;
+    a.scale = 1.0f / sqrtf((float)D); a.waves = tun(ctx, "attn_waves") == 4 ? 4 : (tun(ctx, "attn_waves") == 16 && D == 128 ? 16 : 8);     // (0 = auto is 8 here: the operator has no cache capacity to go by)
     a.tc_dyn = tun(ctx, "attn_tc_dyn") != 0;
     a.pipe = (T + nsplit - 1) / nsplit > attn_round_positions((int)D, a.waves, false);
     a.part_o = (float*)ctx->scratch; a.part_ml = a.part_o + (size_t)H * nsplit * D;
