@@ -134,21 +134,24 @@ def oracle_attention(orc, q, Kc, Vc, T, H, D):
     return orc.mat_mul(P, Vw, False, 1.0).reshape(H * D)
 
 
-@pytest.mark.parametrize("geom", [(1,), (0,), (1, 16)], ids=["dyn", "static", "dyn-16-waves"])
+_ATTN_SHAPES = [(1, 32, 128, 512), (2, 32, 128, 512), (17, 8, 64, 64), (64, 8, 64, 64), (129, 32, 128, 512), (512, 32, 128, 512), (300, 40, 128, 512),
+                (50, 12, 64, 64), (33, 4, 256, 64), (700, 32, 128, 2048)]
+# (splits follow the live context | the cache capacity) x every shape, and - round 6 - 16 waves per workgroup on the D = 128 shapes (+ a 2048-position one: a
+# 256-position split is exactly one round of 16 waves)
+_ATTN_CASES = [(g, sh) for g in ((1,), (0,)) for sh in _ATTN_SHAPES] + [((1, 16), sh) for sh in _ATTN_SHAPES + [(2048, 32, 128, 2048)] if sh[2] == 128]
+
+
 @pytest.mark.parametrize("splits", [1, 2, 4, 8])
-@pytest.mark.parametrize("T,H,D,n_ctx", [(1, 32, 128, 512), (2, 32, 128, 512), (17, 8, 64, 64), (64, 8, 64, 64),
-                                         (129, 32, 128, 512), (512, 32, 128, 512), (300, 40, 128, 512),
-                                         (50, 12, 64, 64), (33, 4, 256, 64), (700, 32, 128, 2048)])
-def test_attn_decode(ctx, orc, splits, T, H, D, n_ctx, geom):
+@pytest.mark.parametrize("geom,shape", _ATTN_CASES, ids=[("dyn", "static")[1 - g[0]] + ("-16-waves" if len(g) > 1 else "") + "-%d-%d-%d-%d" % sh for g, sh in _ATTN_CASES])
+def test_attn_decode(ctx, orc, splits, geom, shape):
     """K8+K9+K10+K9+K8 in one launch, in every launch geometry: splits follow the live context T | the cache capacity.  H = 12 / H = 4
     make H * splits a non-multiple of 8, D = 256 is the widest head, T = 700 of 2048 leaves most of the capacity unused (static
     splits: one workgroup per head gets everything)."""
+    T, H, D, n_ctx = shape
     rng = np.random.default_rng(T * 31 + H)
     E = H * D
     q, Kc, Vc = rnd(rng, E), rnd(rng, n_ctx, E), rnd(rng, n_ctx, E)
     Kc[T:] = 1e6; Vc[T:] = 1e6   # rows beyond T must never be read
-    if len(geom) > 1 and D != 128:
-        pytest.skip("16-wave attention workgroups exist for D = 128")
     names = ("attn_splits", "attn_tc_dyn", "attn_waves")[:1 + len(geom)]
     old = {k: ctx.get_tunable(k) for k in names}
     try:
