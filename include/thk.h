@@ -361,7 +361,7 @@ int thk_peer_destroy(thk_peer* p);
  *            (-1 = per-shape default; 0, 1, 2 batch loops - row pairs, single rows, row pairs in half batches -, 5, 6
  *            software-pipelined loops - row pairs, single rows; for qkv and w13 single rows meet their RoPE / SwiGLU partner
  *            in LDS -, w2 only: 8 = a workgroup per row, a wave per quarter of it; 3, 4, 7, 9 are retired numbers);
- *            gemv_grid_{...} (> 0: that many workgroups, whatever gemv_bpc_* says); attn_splits (1|2|4|8);
+ *            gemv_grid_{...} (> 0: that many workgroups, whatever gemv_bpc_* says); attn_splits (0 = auto: 4, or 8 for caches longer than 512 rows; 1|2|4|8);
  *            attn_waves (0 = auto: 8 waves per attention workgroup, 16 for f32 caches longer than 1024 rows; 4|8|16); use_graph; kv_f16 (1 = K/V caches stored as binary16, rounded RNE at the append: half the
  *            KV bytes, thk_model_bytes_per_token then counts s_kv = 2; default 0 = f32 like the reference,
  *            th-llama-loader.cpp:335); engine (1 = persistent loader/consumer launch per step when the

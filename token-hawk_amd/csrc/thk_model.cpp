@@ -240,7 +240,8 @@ extern "C" int thk_model_finalize(thk_model* m) {
     const int nl = m->l1 - m->l0;
     // launch geometry
     m->nsplit = (int)tun(ctx, "attn_splits");
-    if (m->nsplit == 0) m->nsplit = T > 1024 ? 8 : 4;       // auto: 4 context splits per head (x 2 workgroups per split), 8 for long caches
+    if (m->nsplit == 0) m->nsplit = T > 512 ? 8 : 4;        // auto: 4 context splits per head, 8 for caches longer than 512 rows (round 6: a 1024-row cache in 8 splits is ONE round of an
+                                                            // 8-wave workgroup - same-box A/B 2.4495 -> 2.409 ms per step at T = 1024; round 4 switched at 1024 rows)
     REQUIRE(ctx, valid_splits(m->nsplit), "attn_splits must be 0 (auto), 1, 2, 4 or 8");
     m->tc = (int)((T + m->nsplit - 1) / m->nsplit);
     m->nt = true;

@@ -67,7 +67,7 @@ extern "C" int thk_attn_decode(thk_ctx* ctx, const float* q, const float* kcache
     REQUIRE(ctx, q && kcache && vcache && out && T > 0 && H > 0, "thk_attn_decode: bad arguments");
     REQUIRE(ctx, valid_head_dim(D), "thk_attn_decode: head dim %lld not in {64,128,256}", (long long)D);
     int nsplit = (int)tun(ctx, "attn_splits");
-    if (nsplit == 0) nsplit = T > 1024 ? 8 : 4;
+    if (nsplit == 0) nsplit = T > 512 ? 8 : 4;
     REQUIRE(ctx, valid_splits(nsplit), "attn_splits must be 0 (auto), 1, 2, 4 or 8");
     const size_t need = (size_t)H * nsplit * (D + 2) * 4;
     int rc = ensure_scratch(ctx, need < (1u << 20) ? (1u << 20) : need);
